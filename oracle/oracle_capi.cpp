@@ -1,0 +1,254 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle/README.md).
+//
+// C entry points (ctypes-friendly) over the scalar restatement in
+// chain_model.hpp / pantr_oracle.hpp, plus the closed-loop MPC experiment of
+// drivers/mpc-driver.cpp:123-210 and a threaded batch driver used as the CPU
+// baseline ("port") by bench.py.
+#include "pantr_oracle.hpp"
+#include <atomic>
+#include <thread>
+
+using namespace oracle;
+using Prob = SingleShooting<Chain>;
+
+extern "C" {
+
+/// Flat parameter block (doubles first, then ints) mirrored by tests/oracle_binding.py.
+struct OracleParams {
+    // solver.* (PANTRParams)
+    double L_0, lip_eps, lip_delta, Lgamma_factor, max_time_s, L_min, L_max,
+        quadratic_upperbound_tolerance_factor, TR_tolerance_factor, ratio_threshold_acceptable,
+        ratio_threshold_good, radius_factor_rejected, radius_factor_acceptable, radius_factor_good,
+        initial_radius, min_radius;
+    // dir.*, accel.*
+    double hessian_vec_factor, tol_scale, tol_scale_root, tol_max, max_iter_factor;
+    // alm.*
+    double alm_tolerance, alm_max_time_s;
+    int32_t max_iter, stop_crit, max_no_progress, disable_acceleration;
+};
+
+struct OracleStats {
+    double eps, final_gamma, final_psi, final_fbe, final_radius, elapsed_s;
+    int32_t status, iterations, cg_iterations, accepted, rejected, qub_backtracks;
+    int32_t n_psi, n_grad_psi, n_psi_grad_psi, n_grad_L, n_hess_psi_prod, n_prox_grad_step;
+};
+
+/// Defaults = alpaqa defaults + mpc-driver.cpp:51-53,109-111.
+void oracle_default_params(OracleParams *p) {
+    PANTRParams a;
+    NewtonTRDirectionParams d;
+    SteihaugCGParams c;
+    ALMParams alm;
+    p->L_0 = a.L_0; p->lip_eps = a.lip_eps; p->lip_delta = a.lip_delta;
+    p->Lgamma_factor = a.Lgamma_factor; p->max_time_s = a.max_time_s;
+    p->L_min = a.L_min; p->L_max = a.L_max;
+    p->quadratic_upperbound_tolerance_factor = a.quadratic_upperbound_tolerance_factor;
+    p->TR_tolerance_factor = a.TR_tolerance_factor;
+    p->ratio_threshold_acceptable = a.ratio_threshold_acceptable;
+    p->ratio_threshold_good = a.ratio_threshold_good;
+    p->radius_factor_rejected = a.radius_factor_rejected;
+    p->radius_factor_acceptable = a.radius_factor_acceptable;
+    p->radius_factor_good = a.radius_factor_good;
+    p->initial_radius = a.initial_radius; p->min_radius = a.min_radius;
+    p->hessian_vec_factor = d.hessian_vec_factor;
+    p->tol_scale = c.tol_scale; p->tol_scale_root = c.tol_scale_root; p->tol_max = c.tol_max;
+    p->max_iter_factor = c.max_iter_factor;
+    p->alm_tolerance = alm.tolerance; p->alm_max_time_s = alm.max_time_s;
+    p->max_iter = 50000;          // mpc-driver.cpp:51
+    p->stop_crit = FPRNorm;       // mpc-driver.cpp:53
+    p->max_no_progress = a.max_no_progress;
+    p->disable_acceleration = 0;
+}
+
+/// The PANTR option set of new-benchmarks-paper/dodo.py:12-33 on top of the defaults.
+void oracle_dodo_params(OracleParams *p) {
+    oracle_default_params(p);
+    p->alm_max_time_s = 30;               // alm.max_time=30s
+    p->stop_crit = ProjGradUnitNorm;      // solver.stop_crit=ProjGradUnitNorm
+    p->alm_tolerance = 1e-8;              // alm.tolerance
+    p->radius_factor_rejected = 0.35;
+    p->radius_factor_acceptable = 0.99;
+    p->radius_factor_good = 10;
+    p->ratio_threshold_acceptable = 0.3;
+    p->ratio_threshold_good = 0.5;
+    p->hessian_vec_factor = 1;
+    p->tol_scale = 1e-2;
+}
+
+static PANTRSolver<Prob> make_solver(const OracleParams &p) {
+    PANTRSolver<Prob> s;
+    auto &a = s.params;
+    a.L_0 = p.L_0; a.lip_eps = p.lip_eps; a.lip_delta = p.lip_delta;
+    a.Lgamma_factor = p.Lgamma_factor; a.max_time_s = p.max_time_s;
+    a.L_min = p.L_min; a.L_max = p.L_max;
+    a.quadratic_upperbound_tolerance_factor = p.quadratic_upperbound_tolerance_factor;
+    a.TR_tolerance_factor = p.TR_tolerance_factor;
+    a.ratio_threshold_acceptable = p.ratio_threshold_acceptable;
+    a.ratio_threshold_good = p.ratio_threshold_good;
+    a.radius_factor_rejected = p.radius_factor_rejected;
+    a.radius_factor_acceptable = p.radius_factor_acceptable;
+    a.radius_factor_good = p.radius_factor_good;
+    a.initial_radius = p.initial_radius; a.min_radius = p.min_radius;
+    a.max_iter = p.max_iter; a.stop_crit = p.stop_crit; a.max_no_progress = p.max_no_progress;
+    a.disable_acceleration = p.disable_acceleration;
+    s.dir_params.hessian_vec_factor = p.hessian_vec_factor;
+    s.accel_params.tol_scale = p.tol_scale; s.accel_params.tol_scale_root = p.tol_scale_root;
+    s.accel_params.tol_max = p.tol_max; s.accel_params.max_iter_factor = p.max_iter_factor;
+    return s;
+}
+
+static void export_stats(const Stats &s, OracleStats *o) {
+    o->eps = s.eps; o->final_gamma = s.final_gamma; o->final_psi = s.final_psi;
+    o->final_fbe = s.final_fbe; o->final_radius = s.final_radius; o->elapsed_s = s.elapsed_s;
+    o->status = s.status; o->iterations = s.iterations; o->cg_iterations = s.cg_iterations;
+    o->accepted = s.accepted; o->rejected = s.rejected; o->qub_backtracks = s.qub_backtracks;
+    o->n_psi = (int32_t)s.n_psi; o->n_grad_psi = (int32_t)s.n_grad_psi;
+    o->n_psi_grad_psi = (int32_t)s.n_psi_grad_psi; o->n_grad_L = (int32_t)s.n_grad_L;
+    o->n_hess_psi_prod = (int32_t)s.n_hess_psi_prod;
+    o->n_prox_grad_step = (int32_t)s.n_prox_grad_step;
+}
+
+// ---- problem functions --------------------------------------------------------------------
+int oracle_chain_nx(void) { return Chain::nx; }
+int oracle_chain_nu(void) { return Chain::nu; }
+void oracle_chain_initial_state(double *x0) { Chain::initial_state(x0); }
+void oracle_chain_box(double *lb, double *ub) {
+    for (int c = 0; c < Chain::nu; ++c) {
+        lb[c] = Chain::u_lb(c);
+        ub[c] = Chain::u_ub(c);
+    }
+}
+void oracle_chain_fc(const double *s, const double *u, double *ds) {
+    Chain::Springs<double> sp;
+    Chain::fc(s, u, ds, sp);
+}
+void oracle_chain_simulate(const double *x, const double *u, double *xn) {
+    Prob::simulate_dynamics(x, u, xn);
+}
+double oracle_chain_psi(int N, const double *x0, const double *u) {
+    Prob p(N);
+    std::copy(x0, x0 + Chain::nx, p.x0.begin());
+    return p.eval_psi(u);
+}
+double oracle_chain_psi_grad(int N, const double *x0, const double *u, double *grad) {
+    Prob p(N);
+    std::copy(x0, x0 + Chain::nx, p.x0.begin());
+    return p.eval_psi_grad_psi(u, grad);
+}
+void oracle_chain_hess_prod(int N, const double *x0, const double *u, const double *v, double *Hv) {
+    Prob p(N);
+    std::copy(x0, x0 + Chain::nx, p.x0.begin());
+    p.eval_hess_psi_prod(u, v, Hv);
+}
+void oracle_chain_prox_grad_step(int N, double gamma, const double *x, const double *grad,
+                                 double *xh, double *p, double *pTp, double *gradTp) {
+    Prob pr(N);
+    pr.eval_prox_grad_step(gamma, x, grad, xh, p);
+    *pTp    = dot(p, p, pr.n());
+    *gradTp = dot(p, grad, pr.n());
+}
+double oracle_dot(const double *a, const double *b, int n) { return dot(a, b, n); }
+
+// ---- one solve --------------------------------------------------------------------------
+int oracle_chain_solve(int N, const OracleParams *prm, const double *x0, double *u,
+                       OracleStats *st, double *trace /*cap x 11*/, int trace_cap, int *trace_len) {
+    Prob p(N);
+    std::copy(x0, x0 + Chain::nx, p.x0.begin());
+    auto solver = make_solver(*prm);
+    std::vector<TraceRow> tr;
+    if (trace)
+        solver.trace = &tr;
+    Stats s = solver(p, prm->alm_tolerance, prm->alm_max_time_s, true, u);
+    export_stats(s, st);
+    if (trace) {
+        int len = std::min<int>((int)tr.size(), trace_cap);
+        for (int i = 0; i < len; ++i) {
+            const TraceRow &r = tr[i];
+            double *o = trace + 11 * i;
+            o[0] = r.eps; o[1] = r.psi; o[2] = r.pnorm; o[3] = r.gamma; o[4] = r.radius;
+            o[5] = r.rho; o[6] = r.q_model; o[7] = r.fbe; o[8] = r.nJ; o[9] = r.cg_its;
+            o[10] = r.accepted;
+        }
+        *trace_len = (int)tr.size();
+    }
+    return s.status;
+}
+
+/// B independent solves over `nthreads` host threads (dynamic work queue).
+void oracle_chain_solve_batch(int N, const OracleParams *prm, int B, const double *x0s,
+                              double *us, OracleStats *stats, int nthreads) {
+    const int n = Chain::nu * N;
+    std::atomic<int> next{0};
+    auto worker = [&] {
+        auto solver = make_solver(*prm);
+        for (int b; (b = next.fetch_add(1)) < B;) {
+            Prob p(N);
+            std::copy(x0s + b * Chain::nx, x0s + (b + 1) * Chain::nx, p.x0.begin());
+            Stats s = solver(p, prm->alm_tolerance, prm->alm_max_time_s, true, us + (size_t)b * n);
+            export_stats(s, &stats[b]);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t)
+        th.emplace_back(worker);
+    worker();
+    for (auto &t : th)
+        t.join();
+}
+
+/// Closed-loop MPC experiment, drivers/mpc-driver.cpp:123-210 (single shooting, m = 0).
+/// Outputs: states (num_sim+1) x nx, inputs num_sim x n (row per step: the whole optimal u),
+/// guesses num_sim x n (the warm/cold start each timed solve began from), stats num_sim.
+void oracle_chain_mpc(int N, const OracleParams *prm, int num_sim, int warm, int num_dist,
+                      const double *u_dist, double *states, double *inputs, double *guesses,
+                      OracleStats *stats) {
+    const int nx = Chain::nx, nu = Chain::nu, n = nu * N;
+    Prob p(N);
+    auto solver = make_solver(*prm);
+    std::vector<double> x0(nx), xn(nx), u(n, 0.0), u_initial(n, 0.0); // hanging_chain.cpp:135
+    Chain::initial_state(x0.data());
+    for (int i = 0; i < num_dist; ++i) { // mpc-driver.cpp:153-154
+        Prob::simulate_dynamics(x0.data(), u_dist, xn.data());
+        x0 = xn;
+    }
+    p.x0 = x0;
+    solver(p, prm->alm_tolerance, prm->alm_max_time_s, true, u.data()); // untimed, :158
+    Prob::simulate_dynamics(x0.data(), u.data(), xn.data());           // :160-161
+    x0 = xn;
+    for (int i = 0; i < num_sim; ++i) {
+        if (warm) // shift by nu, last block kept (:170)
+            std::copy(u.begin() + nu, u.end(), u.begin());
+        else
+            u = u_initial;
+        std::copy(u.begin(), u.end(), guesses + (size_t)i * n);
+        p.x0 = x0;
+        Stats s = solver(p, prm->alm_tolerance, prm->alm_max_time_s, true, u.data());
+        export_stats(s, &stats[i]);
+        std::copy(x0.begin(), x0.end(), states + (size_t)i * nx);
+        std::copy(u.begin(), u.end(), inputs + (size_t)i * n);
+        Prob::simulate_dynamics(x0.data(), u.data(), xn.data()); // :205
+        x0 = xn;
+    }
+    std::copy(x0.begin(), x0.end(), states + (size_t)num_sim * nx);
+}
+
+/// Steihaug CG on a dense symmetric matrix (cross-check against SciPy).
+double oracle_steihaug_dense(int n, const double *H /*n x n row-major*/, const double *g,
+                             double radius, double tol_scale, double tol_scale_root,
+                             double max_iter_factor, double *step, int *cg_its) {
+    SteihaugCGParams prm;
+    prm.tol_scale = tol_scale; prm.tol_scale_root = tol_scale_root;
+    prm.max_iter_factor = max_iter_factor;
+    std::vector<double> wz(n), wr(n), wd(n), wBd(n), wev(n);
+    auto hp = [&](const double *p, double *Bp) {
+        for (int i = 0; i < n; ++i) {
+            double acc = 0;
+            for (int j = 0; j < n; ++j)
+                acc += H[i * n + j] * p[j];
+            Bp[i] = acc;
+        }
+    };
+    return steihaug_solve(prm, n, n, g, hp, radius, step, wz, wr, wd, wBd, wev, *cg_its);
+}
+
+} // extern "C"
