@@ -1,0 +1,147 @@
+/* pantr_mi355x.h — C ABI of the MI355X-native batched PANTR solver.
+ *
+ * This is the drop-in boundary for the PANTR hot path of
+ * kul-optec/pantr-cdc2023-experiments.  Every entry point names the reference
+ * interface it replaces (file:line relative to the reference tree).  Plain
+ * pointers and sizes only; no exceptions cross this boundary: every function
+ * returns PANTR_OK or a negative error code and pantr_last_error() gives the
+ * message (the reference throws C++ exceptions instead, mpc-driver.cpp:441-445).
+ *
+ * Layout conventions: fp64 everywhere (alpaqa_real_t = double,
+ * problems/problems/formulation.hpp:12); batches are instance-major contiguous
+ * rows: x0[B][nx], u[B][n], stats[B].  One handle per host thread.
+ */
+#ifndef PANTR_MI355X_H
+#define PANTR_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PANTR_OK 0
+#define PANTR_ERR_INVALID_ARGUMENT (-1) /* std::invalid_argument in the reference */
+#define PANTR_ERR_OUT_OF_RANGE (-2)     /* std::out_of_range */
+#define PANTR_ERR_NO_DEVICE (-3)        /* no usable gfx950 device / HIP failure */
+#define PANTR_ERR_RUNTIME (-4)          /* std::runtime_error */
+
+/* alpaqa::SolverStatus as printed by mpc-driver.cpp:218 and tested at :219 */
+enum pantr_status {
+    PANTR_STATUS_BUSY = 0,
+    PANTR_STATUS_CONVERGED = 1,
+    PANTR_STATUS_MAX_TIME = 2,
+    PANTR_STATUS_MAX_ITER = 3,
+    PANTR_STATUS_NOT_FINITE = 4,
+    PANTR_STATUS_NO_PROGRESS = 5,
+    PANTR_STATUS_INTERRUPTED = 6,
+    PANTR_STATUS_EXCEPTION = 7
+};
+
+/* Per-instance result: the fields of alpaqa's PANTRStats/ALMStats the reference reads
+ * (stats.status, stats.elapsed_time: mpc-driver.cpp:217-221) plus the evaluation counters
+ * the reference logs through alpaqa::EvalCounter (drivers/results.hpp:63-87). */
+typedef struct pantr_stats {
+    double eps;          /* final stop-criterion value */
+    double final_gamma;  /* final step size */
+    double final_psi;    /* psi(xhat) at exit */
+    double final_fbe;    /* forward-backward envelope at exit */
+    double final_radius; /* final trust radius */
+    double elapsed_s;    /* in-kernel solve time of this instance (100 MHz device clock) */
+    int32_t status;      /* enum pantr_status */
+    int32_t iterations;  /* PANTR iterations */
+    int32_t cg_iterations;
+    int32_t accepted, rejected, qub_backtracks;
+    int32_t n_psi, n_grad_psi, n_psi_grad_psi, n_grad_L, n_hess_psi_prod, n_prox_grad_step;
+} pantr_stats_t;
+
+typedef struct pantr_params pantr_params_t; /* solver option set */
+typedef struct pantr_batch pantr_batch_t;   /* problem + device resources */
+
+/* ---- options: replaces alpaqa::params::set_params(obj, prefix, opts) ---------------------
+ * (call sites mpc-driver.cpp:54,61,62,113).  `kv` is one "prefix.key=value" string with
+ * prefix solver. (PANTRParams), dir. (NewtonTRDirectionParams), accel. (SteihaugCGParams)
+ * or alm. (ALMParams).  Strings with another prefix or without a '.' are ignored, as
+ * set_params ignores options addressed to other objects; an unknown key under a known
+ * prefix or an unparsable value is PANTR_ERR_INVALID_ARGUMENT.  Durations accept "30s",
+ * "500ms", "2min"; enums their alpaqa names ("ProjGradUnitNorm").
+ * pantr_params_create applies the reference driver's defaults (mpc-driver.cpp:51-53,
+ * 109-111) on top of alpaqa's. */
+int pantr_params_create(pantr_params_t **out);
+void pantr_params_destroy(pantr_params_t *p);
+int pantr_params_set(pantr_params_t *p, const char *kv);
+int pantr_params_get(const pantr_params_t *p, const char *key, double *value);
+
+/* ---- problem: replaces load_benchmark_problem / load_benchmark_dl_problem ---------------
+ * (drivers/casadi-dll-wrapper.cpp:25-67,69-129) for the problems this library carries as
+ * compiled device code.  `problem` is the reference's problem name ("hanging_chain"),
+ * `horizon` the N of "<name>_<formulation>_<N>.so" (casadi-dll-wrapper.cpp:29-31).
+ * `max_instances` sizes the device workspace; `device` is the HIP device ordinal. */
+int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instances,
+                       int32_t device, pantr_batch_t **out);
+void pantr_batch_destroy(pantr_batch_t *b);
+
+/* get_n/get_m (mpc-driver.cpp:131), get_nx/get_nu/get_nc/get_nc_N (casadi-dll-wrapper.cpp:109-113) */
+int pantr_batch_dims(const pantr_batch_t *b, int32_t *n, int32_t *m, int32_t *nx, int32_t *nu,
+                     int32_t *nc, int32_t *nc_N);
+/* get_box_C() (mpc-driver.cpp:140; formulation.hpp:220-227): lb[n], ub[n] */
+int pantr_batch_get_box_C(const pantr_batch_t *b, double *lb, double *ub);
+/* "initial_guess" (casadi-dll-wrapper.cpp:100-106; hanging_chain.cpp:135): u[n] */
+int pantr_batch_get_initial_guess(const pantr_batch_t *b, double *u);
+/* "get_initial_state" (hanging_chain.cpp:154-155,121-124): x0[nx] */
+int pantr_batch_get_initial_state(const pantr_batch_t *b, double *x0);
+
+/* options of this handle's solver (same grammar as pantr_params_set) */
+int pantr_batch_set_param(pantr_batch_t *b, const char *kv);
+int pantr_batch_get_param(const pantr_batch_t *b, const char *key, double *value);
+
+/* ---- the hot path: replaces stats = solver(problem, u, y) -------------------------------
+ * (mpc-driver.cpp:217: ALMSolver<PANTRSolver<NewtonTRDirection>>::operator()) for B
+ * independent instances.  x0[B][nx] is the problem parameter each instance is solved for
+ * (the reference writes it through initial_state(), mpc-driver.cpp:126); u[B][n] holds the
+ * initial guesses on entry and the solutions on exit; y[B][m] likewise (m = 0 for
+ * hanging_chain: pass NULL).  Host pointers; copies in, one launch, copies out. */
+int pantr_batch_solve(pantr_batch_t *b, int32_t B, const double *x0, double *u, double *y,
+                      pantr_stats_t *stats);
+/* Same with device pointers (inputs already resident in HBM), asynchronous on `stream`
+ * (a hipStream_t, NULL = default stream).  d_stats is device memory, B records. */
+int pantr_batch_solve_device(pantr_batch_t *b, int32_t B, const double *d_x0, double *d_u,
+                             pantr_stats_t *d_stats, void *stream);
+/* Duration of the most recent solve kernel, measured with HIP events recorded on the stream
+ * it was launched on (synchronises on the stop event). */
+int pantr_batch_last_kernel_ms(pantr_batch_t *b, float *ms);
+/* Launch order: order[B] lists instance indices in the order workgroups should start them
+ * (longest-expected-first); NULL restores identity.  Used by the next solve calls. */
+int pantr_batch_set_launch_order(pantr_batch_t *b, int32_t B, const int32_t *order);
+/* Per-iteration trace of the first `instances` instances (cap rows of 11 doubles each:
+ * eps, psi, ||p||, gamma, radius, rho, q_model, fbe, |J|, cg_its, accepted) — what
+ * solver.print_interval would print in the reference (mpc-driver.cpp:52). */
+int pantr_batch_set_trace(pantr_batch_t *b, int32_t instances, int32_t cap);
+int pantr_batch_get_trace(pantr_batch_t *b, double *out /* [instances][cap][11] */);
+
+/* ---- problem functions on the device (parity tests of the individual rows) --------------
+ * eval_psi / eval_psi_grad_psi / eval_hess_psi_prod: formulation.hpp:145-168;
+ * eval_prox_grad_step: C signature problems/problems/lasso.cpp:72-84, box semantics
+ * drivers/results.hpp:268-271; simulate_dynamics: formulation.hpp:258-261. Host pointers. */
+int pantr_batch_eval_psi(pantr_batch_t *b, int32_t B, const double *x0, const double *u, double *psi);
+int pantr_batch_eval_psi_grad_psi(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
+                                  double *psi, double *grad);
+int pantr_batch_eval_hess_psi_prod(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
+                                   const double *v, double *Hv);
+/* scalars[B][4] = { p'p, grad'p, ||Pi_C(x-grad)-x||_inf, |J(gamma)| } */
+int pantr_batch_eval_prox_grad_step(pantr_batch_t *b, int32_t B, double gamma, const double *x,
+                                    const double *grad, double *xhat, double *p, double *scalars);
+int pantr_batch_simulate_dynamics(pantr_batch_t *b, int32_t B, const double *x, const double *u,
+                                  double *x_next);
+
+/* ---- misc -------------------------------------------------------------------------------- */
+const char *pantr_last_error(void);
+const char *pantr_version(void);
+int pantr_device_count(void);
+/* Bytes of LDS per workgroup and of HBM workspace per instance for this handle. */
+int pantr_batch_footprint(const pantr_batch_t *b, int64_t *lds_bytes, int64_t *ws_bytes_per_instance);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANTR_MI355X_H */

@@ -112,8 +112,11 @@ double steihaug_solve(const SteihaugCGParams &prm, int n, int nJ, const double *
         std::fill(step, step + n, 0.0);
         return grad_mag == 0.0 ? 0.0 : NaN;
     }
-    double tolerance = std::fmin(
-        prm.tol_max, prm.tol_scale * grad_mag * std::fmin(1.0, std::pow(grad_mag, prm.tol_scale_root)));
+    // tol_scale_root = 1/2 (the only value the reference uses) goes through sqrt, which is
+    // correctly rounded on every platform; other exponents fall back to pow.
+    double rooted    = prm.tol_scale_root == 0.5 ? std::sqrt(grad_mag)
+                                                 : std::pow(grad_mag, prm.tol_scale_root);
+    double tolerance = std::fmin(prm.tol_max, (prm.tol_scale * grad_mag) * std::fmin(1.0, rooted));
     auto eval = [&](const double *p) {
         hess_prod(p, ev);
         return dot(p, grad, n) + 0.5 * dot(p, ev, n);
@@ -254,8 +257,10 @@ struct PANTRSolver {
             curr->L     = params.L_0;
             curr->psi_x = problem.eval_psi_grad_psi(curr->x.data(), curr->grad.data());
         }
-        if (!std::isfinite(curr->L))
-            return finish(NotFinite, NaN, NaN);
+        if (!std::isfinite(curr->L)) { // nothing usable to return: leave x untouched
+            s.status = NotFinite;
+            return s;
+        }
         curr->gamma = params.Lgamma_factor / curr->L;
         prox_grad_step(*curr);
         eval_psi_xh(*curr);

@@ -1,0 +1,501 @@
+// C ABI (include/pantr_mi355x.h) over the gfx950 kernels.  Host side only: option parsing,
+// device buffers, launches.  There is deliberately no CPU solve path in this library: every
+// compute entry point needs a HIP device and fails with PANTR_ERR_NO_DEVICE without one.
+#include "../../include/pantr_mi355x.h"
+#include "../host/params.hpp"
+#include "chain_model.hip.h"
+#include "pantr_kernel.hip.h"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace pantr;
+using pantr::host::SolverOptions;
+
+static_assert(sizeof(pantr_stats_t) == sizeof(DeviceStats), "stats layout mismatch");
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(PANTR_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+enum class ProblemId { HangingChain };
+
+} // namespace
+
+struct pantr_params {
+    SolverOptions opts = SolverOptions::driver_defaults();
+};
+
+struct pantr_batch {
+    ProblemId problem = ProblemId::HangingChain;
+    std::string name;
+    int32_t N = 0, n = 0, m = 0, nx = 0, nu = 0, nc = 0, nc_N = 0;
+    int32_t npad = 0, nj = 0, maxB = 0, device = 0;
+    size_t ws_per_instance = 0; ///< doubles
+    size_t lds_bytes       = 0;
+    SolverOptions opts = SolverOptions::driver_defaults();
+    // device memory
+    double *d_x0 = nullptr, *d_u = nullptr, *d_v = nullptr, *d_o1 = nullptr, *d_o2 = nullptr,
+           *d_s = nullptr, *d_ws = nullptr, *d_trace = nullptr;
+    DeviceStats *d_stats = nullptr;
+    int32_t *d_order     = nullptr;
+    bool have_order      = false;
+    int32_t trace_instances = 0, trace_cap = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(T *&p, size_t count) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+    return PANTR_OK;
+}
+
+int check_supported(const SolverOptions &o) {
+    // Options whose non-default value would select a code path the device solver does not have.
+    if (o.dir.finite_diff)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "dir.finite_diff=true is not supported by the device solver");
+    if (o.solver.compute_ratio_using_new_stepsize)
+        return fail(PANTR_ERR_INVALID_ARGUMENT,
+                    "solver.compute_ratio_using_new_stepsize=true is not supported by the device solver");
+    if (!o.solver.ratio_approx_fbe_quadratic_model)
+        return fail(PANTR_ERR_INVALID_ARGUMENT,
+                    "solver.ratio_approx_fbe_quadratic_model=false is not supported by the device solver");
+    using host::PANOCStopCrit;
+    if (o.solver.stop_crit != PANOCStopCrit::ProjGradUnitNorm && o.solver.stop_crit != PANOCStopCrit::FPRNorm)
+        return fail(PANTR_ERR_INVALID_ARGUMENT,
+                    std::string("solver.stop_crit=") + host::enum_name(o.solver.stop_crit) +
+                        " is not supported by the device solver (ProjGradUnitNorm, FPRNorm)");
+    return PANTR_OK;
+}
+
+KernelParams to_kernel_params(const SolverOptions &o, int m) {
+    KernelParams k{};
+    const auto &s = o.solver;
+    k.L_0 = s.Lipschitz.L_0; k.lip_eps = s.Lipschitz.epsilon; k.lip_delta = s.Lipschitz.delta;
+    k.Lgamma_factor = s.Lipschitz.Lgamma_factor;
+    // m == 0: ALM performs one inner solve with alm.tolerance and alm.max_time
+    k.max_time_s = std::fmin(s.max_time, o.alm.max_time);
+    k.L_min = s.L_min; k.L_max = s.L_max;
+    k.quadratic_upperbound_tolerance_factor = s.quadratic_upperbound_tolerance_factor;
+    k.TR_tolerance_factor = s.TR_tolerance_factor;
+    k.ratio_threshold_acceptable = s.ratio_threshold_acceptable;
+    k.ratio_threshold_good = s.ratio_threshold_good;
+    k.radius_factor_rejected = s.radius_factor_rejected;
+    k.radius_factor_acceptable = s.radius_factor_acceptable;
+    k.radius_factor_good = s.radius_factor_good;
+    k.initial_radius = s.initial_radius; k.min_radius = s.min_radius;
+    k.hessian_vec_factor = o.dir.hessian_vec_factor;
+    k.tol_scale = o.accel.tol_scale; k.tol_scale_root = o.accel.tol_scale_root;
+    k.tol_max = o.accel.tol_max; k.max_iter_factor = o.accel.max_iter_factor;
+    k.tolerance = o.alm.tolerance;
+    k.max_iter = s.max_iter; k.stop_crit = static_cast<int32_t>(s.stop_crit);
+    k.max_no_progress = s.max_no_progress; k.disable_acceleration = s.disable_acceleration ? 1 : 0;
+    k.always_overwrite_results = 1;
+    (void)m;
+    return k;
+}
+
+int set_option(SolverOptions &o, const char *kv) {
+    if (!kv)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null option string");
+    std::string err;
+    switch (host::set_option(o, kv, err)) {
+    case host::SetResult::Ok:
+    case host::SetResult::Ignored: return PANTR_OK;
+    default: return fail(PANTR_ERR_INVALID_ARGUMENT, err);
+    }
+}
+
+int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, DeviceStats *d_stats,
+                 hipStream_t stream) {
+    if (int rc = check_supported(b->opts))
+        return rc;
+    SolveArgs a{};
+    a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj;
+    a.trace_cap = b->trace_cap; a.trace_instances = b->trace_instances;
+    a.x0 = d_x0; a.u = d_u; a.ws = b->d_ws; a.stats = d_stats;
+    a.trace = b->trace_instances > 0 ? b->d_trace : nullptr;
+    a.order = b->have_order ? b->d_order : nullptr;
+    a.prm   = to_kernel_params(b->opts, b->m);
+    HIP_TRY(hipEventRecord(b->ev_start, stream));
+    hipLaunchKernelGGL(pantr_solve_kernel<ChainModel>, dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->ev_stop, stream));
+    b->timed = true;
+    return PANTR_OK;
+}
+
+int check_batch(const pantr_batch *b, int32_t B) {
+    if (!b)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
+    if (B < 1 || B > b->maxB)
+        return fail(PANTR_ERR_OUT_OF_RANGE, "batch size " + std::to_string(B) + " outside [1, " +
+                                                std::to_string(b->maxB) + "]");
+    return PANTR_OK;
+}
+
+int run_eval(pantr_batch *b, int32_t B, int mode, double gamma, const double *x0, const double *u,
+             const double *v, double *out_s, double *out_v, double *out_v2) {
+    if (int rc = check_batch(b, B))
+        return rc;
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t nb = (size_t)B * b->n * sizeof(double);
+    if (x0)
+        HIP_TRY(hipMemcpy(b->d_x0, x0, (size_t)B * b->nx * sizeof(double), hipMemcpyHostToDevice));
+    else
+        HIP_TRY(hipMemset(b->d_x0, 0, (size_t)B * b->nx * sizeof(double)));
+    HIP_TRY(hipMemcpy(b->d_u, u, nb, hipMemcpyHostToDevice));
+    if (v)
+        HIP_TRY(hipMemcpy(b->d_v, v, nb, hipMemcpyHostToDevice));
+    EvalArgs a{};
+    a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj; a.mode = mode;
+    a.x0 = b->d_x0; a.u = b->d_u; a.v = v ? b->d_v : nullptr;
+    a.out_s = b->d_s; a.out_v = b->d_o1; a.out_v2 = b->d_o2; a.ws = b->d_ws; a.gamma = gamma;
+    hipLaunchKernelGGL(pantr_eval_kernel<ChainModel>, dim3(B), dim3(WAVE), 4 * b->npad * sizeof(double), 0, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<double> s((size_t)B * 4);
+    HIP_TRY(hipMemcpy(s.data(), b->d_s, s.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_s)
+        std::memcpy(out_s, s.data(), s.size() * sizeof(double));
+    if (out_v)
+        HIP_TRY(hipMemcpy(out_v, b->d_o1, nb, hipMemcpyDeviceToHost));
+    if (out_v2)
+        HIP_TRY(hipMemcpy(out_v2, b->d_o2, nb, hipMemcpyDeviceToHost));
+    return PANTR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *pantr_last_error(void) { return g_last_error.c_str(); }
+const char *pantr_version(void) { return "pantr-mi355x 0.1 (gfx950)"; }
+int pantr_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess)
+        return 0;
+    return c;
+}
+
+// ---- options ---------------------------------------------------------------------------
+int pantr_params_create(pantr_params_t **out) {
+    if (!out)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null output pointer");
+    *out = new pantr_params;
+    return PANTR_OK;
+}
+void pantr_params_destroy(pantr_params_t *p) { delete p; }
+int pantr_params_set(pantr_params_t *p, const char *kv) {
+    if (!p)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null params handle");
+    return set_option(p->opts, kv);
+}
+int pantr_params_get(const pantr_params_t *p, const char *key, double *value) {
+    if (!p || !key || !value)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    if (!host::get_option(p->opts, key, *value))
+        return fail(PANTR_ERR_OUT_OF_RANGE, std::string("Invalid key '") + key + "'");
+    return PANTR_OK;
+}
+
+// ---- problem ---------------------------------------------------------------------------
+int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instances, int32_t device,
+                       pantr_batch_t **out) {
+    if (!problem || !out)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    std::string name = problem;
+    while (name.rfind("dl:", 0) == 0) // casadi-dll-wrapper.cpp:74-76
+        name = name.substr(3);
+    if (name != "hanging_chain")
+        return fail(PANTR_ERR_OUT_OF_RANGE, "unknown problem '" + name + "' (available: hanging_chain)");
+    if (horizon < 1)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "horizon must be >= 1");
+    if (max_instances < 1)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "max_instances must be >= 1");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
+        return fail(PANTR_ERR_NO_DEVICE, "no HIP device available: the PANTR solver has no CPU path");
+    if (device < 0 || device >= count)
+        return fail(PANTR_ERR_OUT_OF_RANGE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    auto b = std::make_unique<pantr_batch>();
+    b->name = name; b->device = device;
+    b->N = horizon; b->nx = ChainModel::nx; b->nu = ChainModel::nu;
+    b->n = b->nu * b->N; b->m = 0; b->nc = 0; b->nc_N = 0;
+    b->nj   = (b->n + WAVE - 1) / WAVE;
+    b->npad = b->nj * WAVE;
+    if (b->nj > 32)
+        return fail(PANTR_ERR_OUT_OF_RANGE, "horizon too long: n = nu*N must be <= 2048");
+    b->maxB            = max_instances;
+    b->ws_per_instance = (size_t)2 * (b->N + 1) * WAVE;
+    b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double);
+    if (b->lds_bytes > 160 * 1024)
+        return fail(PANTR_ERR_OUT_OF_RANGE, "decision vectors do not fit the 160 KiB LDS");
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_solve_kernel<ChainModel>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+    const size_t B  = b->maxB;
+    const size_t nv = std::max(b->n, b->nx); // the vector buffers also carry nx-sized rows
+    int rc;
+    if ((rc = dev_alloc(b->d_x0, B * b->nx)) || (rc = dev_alloc(b->d_u, B * nv)) ||
+        (rc = dev_alloc(b->d_v, B * nv)) || (rc = dev_alloc(b->d_o1, B * nv)) ||
+        (rc = dev_alloc(b->d_o2, B * nv)) || (rc = dev_alloc(b->d_s, B * 4)) ||
+        (rc = dev_alloc(b->d_ws, B * b->ws_per_instance)) || (rc = dev_alloc(b->d_stats, B)) ||
+        (rc = dev_alloc(b->d_order, B))) {
+        pantr_batch_destroy(b.release());
+        return rc;
+    }
+    HIP_TRY(hipMemset(b->d_ws, 0, B * b->ws_per_instance * sizeof(double)));
+    HIP_TRY(hipEventCreate(&b->ev_start));
+    HIP_TRY(hipEventCreate(&b->ev_stop));
+    *out = b.release();
+    return PANTR_OK;
+}
+
+void pantr_batch_destroy(pantr_batch_t *b) {
+    if (!b)
+        return;
+    (void)hipSetDevice(b->device);
+    for (void *p : {(void *)b->d_x0, (void *)b->d_u, (void *)b->d_v, (void *)b->d_o1, (void *)b->d_o2,
+                    (void *)b->d_s, (void *)b->d_ws, (void *)b->d_trace, (void *)b->d_stats,
+                    (void *)b->d_order})
+        if (p)
+            (void)hipFree(p);
+    if (b->ev_start)
+        (void)hipEventDestroy(b->ev_start);
+    if (b->ev_stop)
+        (void)hipEventDestroy(b->ev_stop);
+    delete b;
+}
+
+int pantr_batch_dims(const pantr_batch_t *b, int32_t *n, int32_t *m, int32_t *nx, int32_t *nu,
+                     int32_t *nc, int32_t *nc_N) {
+    if (!b)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
+    if (n) *n = b->n;
+    if (m) *m = b->m;
+    if (nx) *nx = b->nx;
+    if (nu) *nu = b->nu;
+    if (nc) *nc = b->nc;
+    if (nc_N) *nc_N = b->nc_N;
+    return PANTR_OK;
+}
+
+int pantr_batch_get_box_C(const pantr_batch_t *b, double *lb, double *ub) {
+    if (!b || !lb || !ub)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    for (int i = 0; i < b->n; ++i) { // formulation.hpp:220-227: U tiled N times
+        lb[i] = ChainModel::u_lb(i % b->nu);
+        ub[i] = ChainModel::u_ub(i % b->nu);
+    }
+    return PANTR_OK;
+}
+
+int pantr_batch_get_initial_guess(const pantr_batch_t *b, double *u) {
+    if (!b || !u)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    std::fill(u, u + b->n, 0.0); // hanging_chain.cpp:135
+    return PANTR_OK;
+}
+
+int pantr_batch_get_initial_state(const pantr_batch_t *b, double *x0) {
+    if (!b || !x0)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    for (int l = 0; l < b->nx; ++l)
+        x0[l] = ChainModel::initial_state(l);
+    return PANTR_OK;
+}
+
+int pantr_batch_set_param(pantr_batch_t *b, const char *kv) {
+    if (!b)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
+    return set_option(b->opts, kv);
+}
+int pantr_batch_get_param(const pantr_batch_t *b, const char *key, double *value) {
+    if (!b || !key || !value)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    if (!host::get_option(b->opts, key, *value))
+        return fail(PANTR_ERR_OUT_OF_RANGE, std::string("Invalid key '") + key + "'");
+    return PANTR_OK;
+}
+
+int pantr_batch_footprint(const pantr_batch_t *b, int64_t *lds_bytes, int64_t *ws_bytes_per_instance) {
+    if (!b)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
+    if (lds_bytes) *lds_bytes = (int64_t)b->lds_bytes;
+    if (ws_bytes_per_instance) *ws_bytes_per_instance = (int64_t)(b->ws_per_instance * sizeof(double));
+    return PANTR_OK;
+}
+
+// ---- the hot path ------------------------------------------------------------------------
+int pantr_batch_solve(pantr_batch_t *b, int32_t B, const double *x0, double *u, double *y,
+                      pantr_stats_t *stats) {
+    if (int rc = check_batch(b, B))
+        return rc;
+    if (!x0 || !u || !stats)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    (void)y; // m == 0: no multipliers
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpy(b->d_x0, x0, (size_t)B * b->nx * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_u, u, (size_t)B * b->n * sizeof(double), hipMemcpyHostToDevice));
+    if (int rc = launch_solve(b, B, b->d_x0, b->d_u, b->d_stats, nullptr))
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(u, b->d_u, (size_t)B * b->n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(stats, b->d_stats, (size_t)B * sizeof(DeviceStats), hipMemcpyDeviceToHost));
+    return PANTR_OK;
+}
+
+int pantr_batch_solve_device(pantr_batch_t *b, int32_t B, const double *d_x0, double *d_u,
+                             pantr_stats_t *d_stats, void *stream) {
+    if (int rc = check_batch(b, B))
+        return rc;
+    if (!d_x0 || !d_u || !d_stats)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(b->device));
+    return launch_solve(b, B, d_x0, d_u, reinterpret_cast<DeviceStats *>(d_stats),
+                        static_cast<hipStream_t>(stream));
+}
+
+int pantr_batch_last_kernel_ms(pantr_batch_t *b, float *ms) {
+    if (!b || !ms)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    if (!b->timed)
+        return fail(PANTR_ERR_RUNTIME, "no solve has been launched on this handle");
+    HIP_TRY(hipEventSynchronize(b->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, b->ev_start, b->ev_stop));
+    return PANTR_OK;
+}
+
+int pantr_batch_set_launch_order(pantr_batch_t *b, int32_t B, const int32_t *order) {
+    if (!b)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
+    if (!order) {
+        b->have_order = false;
+        return PANTR_OK;
+    }
+    if (int rc = check_batch(b, B))
+        return rc;
+    std::vector<char> seen(B, 0);
+    for (int i = 0; i < B; ++i) {
+        if (order[i] < 0 || order[i] >= B || seen[order[i]])
+            return fail(PANTR_ERR_INVALID_ARGUMENT, "launch order is not a permutation of 0..B-1");
+        seen[order[i]] = 1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpy(b->d_order, order, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice));
+    b->have_order = true;
+    return PANTR_OK;
+}
+
+int pantr_batch_set_trace(pantr_batch_t *b, int32_t instances, int32_t cap) {
+    if (!b)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
+    if (instances < 0 || instances > b->maxB || cap < 0)
+        return fail(PANTR_ERR_OUT_OF_RANGE, "trace size out of range");
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->d_trace) {
+        HIP_TRY(hipFree(b->d_trace));
+        b->d_trace = nullptr;
+    }
+    b->trace_instances = instances;
+    b->trace_cap       = cap;
+    if (instances > 0 && cap > 0) {
+        size_t cnt = (size_t)instances * cap * TRACE_COLS;
+        if (int rc = dev_alloc(b->d_trace, cnt))
+            return rc;
+        HIP_TRY(hipMemset(b->d_trace, 0, cnt * sizeof(double)));
+    } else {
+        b->trace_instances = b->trace_cap = 0;
+    }
+    return PANTR_OK;
+}
+
+int pantr_batch_get_trace(pantr_batch_t *b, double *out) {
+    if (!b || !out)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    if (!b->d_trace)
+        return fail(PANTR_ERR_RUNTIME, "tracing is not enabled on this handle");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpy(out, b->d_trace, (size_t)b->trace_instances * b->trace_cap * TRACE_COLS * sizeof(double),
+                      hipMemcpyDeviceToHost));
+    return PANTR_OK;
+}
+
+// ---- problem functions -------------------------------------------------------------------
+int pantr_batch_eval_psi(pantr_batch_t *b, int32_t B, const double *x0, const double *u, double *psi) {
+    if (!x0 || !u || !psi)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    std::vector<double> s((size_t)(B > 0 ? B : 0) * 4);
+    if (int rc = run_eval(b, B, EVAL_PSI, 0, x0, u, nullptr, s.data(), nullptr, nullptr))
+        return rc;
+    for (int i = 0; i < B; ++i)
+        psi[i] = s[(size_t)i * 4];
+    return PANTR_OK;
+}
+
+int pantr_batch_eval_psi_grad_psi(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
+                                  double *psi, double *grad) {
+    if (!x0 || !u || !psi || !grad)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    std::vector<double> s((size_t)(B > 0 ? B : 0) * 4);
+    if (int rc = run_eval(b, B, EVAL_PSI_GRAD, 0, x0, u, nullptr, s.data(), grad, nullptr))
+        return rc;
+    for (int i = 0; i < B; ++i)
+        psi[i] = s[(size_t)i * 4];
+    return PANTR_OK;
+}
+
+int pantr_batch_eval_hess_psi_prod(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
+                                   const double *v, double *Hv) {
+    if (!x0 || !u || !v || !Hv)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    return run_eval(b, B, EVAL_HESS_PROD, 0, x0, u, v, nullptr, Hv, nullptr);
+}
+
+int pantr_batch_eval_prox_grad_step(pantr_batch_t *b, int32_t B, double gamma, const double *x,
+                                    const double *grad, double *xhat, double *p, double *scalars) {
+    if (!x || !grad || !xhat || !p || !scalars)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    return run_eval(b, B, EVAL_PROX, gamma, nullptr, x, grad, scalars, xhat, p);
+}
+
+int pantr_batch_simulate_dynamics(pantr_batch_t *b, int32_t B, const double *x, const double *u,
+                                  double *x_next) {
+    if (int rc = check_batch(b, B))
+        return rc;
+    if (!x || !u || !x_next)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpy(b->d_x0, x, (size_t)B * b->nx * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_v, u, (size_t)B * b->nu * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pantr_simulate_kernel<ChainModel>, dim3(B), dim3(WAVE), 0, 0, B, b->d_x0, b->d_v,
+                       b->d_o1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(x_next, b->d_o1, (size_t)B * b->nx * sizeof(double), hipMemcpyDeviceToHost));
+    return PANTR_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,732 @@
+// Batched PANTR inner solver for gfx950: one 64-wide wavefront (= one workgroup) solves one
+// MPC instance from start to finish inside a single launch.
+//
+// What it replaces (the reference only *names* these; their source is the absent alpaqa
+// submodule, .gitmodules:1-4):
+//   alpaqa::ALMSolver<PANTRSolver<NewtonTRDirection>>::operator()   drivers/mpc-driver.cpp:104-115,217,364-370
+//   PANTRParams / NewtonTRDirectionParams / SteihaugCGParams          new-benchmarks-paper/dodo.py:12-33
+//   problem functions psi, psi_grad_psi, hess_psi_prod, grad_L        problems/problems/formulation.hpp:79-99
+//   box prox step / inactive set                                      problems/problems/formulation.hpp:220-227
+//
+// Data placement (DESIGN.md "Layout"):
+//   LDS     : the 20 decision-space vectors of the solve (3 iterates x {x, xhat, grad, p}, q,
+//             Hv output, r_J, and the CG vectors z, r, d, Bd, step), n_pad doubles each
+//   HBM/L2  : the state trajectory X[(N+1)][64] and its tangent Xt written by the forward
+//             sweeps and re-read (one stage ahead) by the reverse sweeps, one 512-byte row
+//             per stage per wavefront
+//   VGPR    : the stage state (one component per lane), adjoints, RK4 intermediates
+//   SGPR    : every scalar of the algorithm (psi, gamma, L, radius, rho, ...), made uniform
+//             with readfirstlane after each butterfly reduction
+#pragma once
+#include "wave_math.hip.h"
+#include <stdint.h>
+
+namespace pantr {
+
+enum SolverStatus : int32_t {
+    Busy = 0, Converged = 1, MaxTime = 2, MaxIter = 3, NotFinite = 4, NoProgress = 5,
+    Interrupted = 6, Exception = 7,
+};
+enum StopCrit : int32_t {
+    ApproxKKT = 0, ApproxKKT2, ProjGradNorm, ProjGradNorm2, ProjGradUnitNorm, ProjGradUnitNorm2,
+    FPRNorm, FPRNorm2, IpoptCrit, LBFGSBpp,
+};
+
+/// Solver options as the kernel consumes them (filled from PANTRParams & co. on the host).
+struct KernelParams {
+    double L_0, lip_eps, lip_delta, Lgamma_factor, max_time_s, L_min, L_max;
+    double quadratic_upperbound_tolerance_factor, TR_tolerance_factor;
+    double ratio_threshold_acceptable, ratio_threshold_good;
+    double radius_factor_rejected, radius_factor_acceptable, radius_factor_good;
+    double initial_radius, min_radius;
+    double hessian_vec_factor, tol_scale, tol_scale_root, tol_max, max_iter_factor;
+    double tolerance;
+    int32_t max_iter, stop_crit, max_no_progress, disable_acceleration;
+    int32_t always_overwrite_results, pad0;
+};
+
+/// Per-instance result record (mirrors pantr_stats_t in include/pantr_mi355x.h).
+struct DeviceStats {
+    double eps, final_gamma, final_psi, final_fbe, final_radius, elapsed_s;
+    int32_t status, iterations, cg_iterations, accepted, rejected, qub_backtracks;
+    int32_t n_psi, n_grad_psi, n_psi_grad_psi, n_grad_L, n_hess_psi_prod, n_prox_grad_step;
+};
+
+constexpr int TRACE_COLS = 11;
+constexpr int NUM_VEC    = 20;
+
+struct SolveArgs {
+    int32_t B, N, n, npad, nj;
+    int32_t trace_cap, trace_instances, pad0;
+    const double *x0;      ///< [B][nx] initial states (the problem parameter)
+    double *u;             ///< [B][n]  in: initial guess, out: solution
+    double *ws;            ///< [B][2][(N+1)][64] trajectory workspace
+    DeviceStats *stats;    ///< [B]
+    double *trace;         ///< [trace_instances][trace_cap][TRACE_COLS] or nullptr
+    const int32_t *order;  ///< optional launch order (instance index per workgroup) or nullptr
+    KernelParams prm;
+};
+
+// ---------------------------------------------------------------------------------------
+// Wave-cooperative problem functions of the single-shooting problem
+// ---------------------------------------------------------------------------------------
+template <class M>
+struct WaveProblem {
+    using Lane = typename M::Lane;
+    const Lane &L;
+    double *lds; ///< base of this wavefront's vectors
+    int N, n, npad, nj;
+    double x0;  ///< this lane's initial-state component
+    double *X;  ///< global: primal trajectory rows, X[k*64 + lane]
+    double *Xt; ///< global: tangent trajectory rows
+
+    __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
+
+    /// psi(u) = sum_k l(x_k,u_k) + l_N(x_N); optionally stores the trajectory.
+    template <bool STORE>
+    __device__ __forceinline__ double psi_forward(const double *u) const {
+        wave_sync(); // u was written by its owner lanes
+        double s = x0, acc = 0.0;
+        for (int k = 0; k < N; ++k) {
+            double uc = u[M::nu * k + L.uidx];
+            if (STORE)
+                X[k * WAVE + L.l] = s;
+            acc = M::cost_accumulate(L, s, uc, true, acc);
+            s   = M::rk4(L, s, uc);
+        }
+        if (STORE)
+            X[N * WAVE + L.l] = s;
+        acc = M::cost_accumulate(L, s, 0.0, false, acc);
+        return uniform(wave_sum(acc));
+    }
+
+    /// psi and grad psi (forward sweep, then adjoint sweep over the stored trajectory).
+    __device__ __forceinline__ double psi_grad(const double *u, double *grad) const {
+        double psi = psi_forward<true>(u);
+        wave_sync(); // the sweep below re-reads rows this wavefront has just written
+        double lam = M::cost_grad_x_add(L, X[N * WAVE + L.l], 0.0);
+        double s   = X[(N - 1) * WAVE + L.l];
+        for (int k = N - 1; k >= 0; --k) {
+            double s_prev = k > 0 ? X[(k - 1) * WAVE + L.l] : 0.0; // one stage ahead
+            double uc     = u[M::nu * k + L.uidx];
+            double sbar, ubar;
+            M::rk4_adj(L, s, uc, lam, sbar, ubar);
+            if (L.isE)
+                grad[M::nu * k + L.uidx] = ubar + M::c2g * uc;
+            lam = M::cost_grad_x_add(L, s, sbar);
+            s   = s_prev;
+        }
+        wave_sync(); // grad was written by lanes 27..29
+        return psi;
+    }
+
+    /// Hv = d/du (grad psi(u)^T v), forward-over-reverse on dual numbers.
+    __device__ __forceinline__ void hess_prod(const double *u, const double *v, double *Hv) const {
+        wave_sync();
+        dual s = {x0, 0.0};
+        for (int k = 0; k < N; ++k) {
+            dual uc             = {u[M::nu * k + L.uidx], v[M::nu * k + L.uidx]};
+            X[k * WAVE + L.l]   = s.v;
+            Xt[k * WAVE + L.l]  = s.t;
+            s                   = M::rk4(L, s, uc);
+        }
+        X[N * WAVE + L.l]  = s.v;
+        Xt[N * WAVE + L.l] = s.t;
+        wave_sync();
+        dual lam = M::cost_grad_x_add(L, s, dual{0.0, 0.0});
+        s        = {X[(N - 1) * WAVE + L.l], Xt[(N - 1) * WAVE + L.l]};
+        for (int k = N - 1; k >= 0; --k) {
+            dual s_prev = {0.0, 0.0};
+            if (k > 0)
+                s_prev = {X[(k - 1) * WAVE + L.l], Xt[(k - 1) * WAVE + L.l]};
+            dual uc = {u[M::nu * k + L.uidx], v[M::nu * k + L.uidx]};
+            dual sbar, ubar;
+            M::rk4_adj(L, s, uc, lam, sbar, ubar);
+            if (L.isE)
+                Hv[M::nu * k + L.uidx] = (ubar + M::c2g * uc).t;
+            lam = M::cost_grad_x_add(L, s, sbar);
+            s   = s_prev;
+        }
+        wave_sync();
+    }
+
+    // ---- vector helpers over the LDS vectors: lane l owns i = l, l+64, ... ------------------
+    __device__ __forceinline__ double dot(const double *a, const double *b) const {
+        double acc = 0.0;
+        for (int j = 0; j < nj; ++j) {
+            int i = j * WAVE + L.l;
+            if (i < n)
+                acc = acc + a[i] * b[i];
+        }
+        return uniform(wave_sum(acc));
+    }
+    /// dot(a, mask ? b : 0)
+    __device__ __forceinline__ double dot_masked(const double *a, const double *b, uint32_t mask) const {
+        double acc = 0.0;
+        for (int j = 0; j < nj; ++j) {
+            int i = j * WAVE + L.l;
+            if (i < n)
+                acc = acc + a[i] * ((mask >> j) & 1u ? b[i] : 0.0);
+        }
+        return uniform(wave_sum(acc));
+    }
+    __device__ __forceinline__ double norm_inf(const double *a) const {
+        double r = 0.0;
+        for (int j = 0; j < nj; ++j) {
+            int i = j * WAVE + L.l;
+            if (i < n)
+                r = fmax(r, fabs(a[i]));
+        }
+        return uniform(wave_max(r));
+    }
+
+    /// Box prox-gradient step: p = min(max(-gamma grad, lb - x), ub - x), xhat = x + p.
+    /// Returns p'p and grad'p.
+    __device__ __forceinline__ void prox_grad_step(double gamma, const double *x, const double *grad,
+                                                   double *xh, double *p, double &pTp,
+                                                   double &gradTp) const {
+        double a1 = 0.0, a2 = 0.0;
+        for (int j = 0; j < nj; ++j) {
+            int i = j * WAVE + L.l;
+            if (i < n) {
+                int c     = i % M::nu;
+                double xi = x[i], gi = grad[i];
+                double t  = (-gamma) * gi;
+                double pi = fmin(fmax(t, M::u_lb(c) - xi), M::u_ub(c) - xi);
+                p[i]      = pi;
+                xh[i]     = xi + pi;
+                a1        = a1 + pi * pi;
+                a2        = a2 + pi * gi;
+            }
+        }
+        pTp    = uniform(wave_sum(a1));
+        gradTp = uniform(wave_sum(a2));
+    }
+
+    /// || Pi_C(x - grad) - x ||_inf  (ProjGradUnitNorm)
+    __device__ __forceinline__ double proj_grad_unit_norm(const double *x, const double *grad) const {
+        double r = 0.0;
+        for (int j = 0; j < nj; ++j) {
+            int i = j * WAVE + L.l;
+            if (i < n) {
+                int c     = i % M::nu;
+                double xi = x[i];
+                double t  = (-1.0) * grad[i];
+                double pi = fmin(fmax(t, M::u_lb(c) - xi), M::u_ub(c) - xi);
+                r         = fmax(r, fabs(pi));
+            }
+        }
+        return uniform(wave_max(r));
+    }
+
+    /// Inactive set J = { i : lb < x_i - gamma grad_i < ub } as one bit per owned element.
+    __device__ __forceinline__ uint32_t inactive_mask(double gamma, const double *x, const double *grad,
+                                                      int &nJ) const {
+        uint32_t mask = 0;
+        int cnt       = 0;
+        for (int j = 0; j < nj; ++j) {
+            int i = j * WAVE + L.l;
+            if (i < n) {
+                int c      = i % M::nu;
+                double xfw = x[i] - gamma * grad[i];
+                bool in    = M::u_lb(c) < xfw && xfw < M::u_ub(c);
+                mask |= (in ? 1u : 0u) << j;
+                cnt += in ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+            cnt += __shfl_xor(cnt, m);
+        nJ = uniform(cnt);
+        return mask;
+    }
+};
+
+struct IterateRef {
+    int base; ///< first of 4 consecutive vector slots: x, xhat, grad, p
+    double psi_x = __builtin_nan(""), psi_xh = __builtin_nan(""), gamma = __builtin_nan(""),
+           L = __builtin_nan(""), pTp = __builtin_nan(""), gradTp = __builtin_nan("");
+    __device__ __forceinline__ double fbe() const { return (psi_x + pTp / (2.0 * gamma)) + gradTp; }
+};
+
+__device__ __forceinline__ void swap_iter(IterateRef &a, IterateRef &b) {
+    IterateRef t = a;
+    a            = b;
+    b            = t;
+}
+
+__device__ __forceinline__ bool is_finite(double v) { return fabs(v) < __builtin_huge_val(); }
+
+// ---------------------------------------------------------------------------------------
+// The solve kernel
+// ---------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if (inst >= a.B)
+        return;
+    const long long t_start = wall_clock64(); // 100 MHz constant clock
+    const KernelParams &P   = a.prm;
+    typename M::Lane L(lane);
+
+    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, 0.0, nullptr, nullptr};
+    pb.x0 = lane < M::nx ? a.x0[(size_t)inst * M::nx + lane] : 0.0;
+    pb.X  = a.ws + (size_t)inst * 2 * (a.N + 1) * WAVE;
+    pb.Xt = pb.X + (size_t)(a.N + 1) * WAVE;
+    const int n = a.n, nj = a.nj;
+
+    // vector slots
+    enum { S_IT0 = 0, S_IT1 = 4, S_IT2 = 8, S_Q = 12, S_WORK = 13, S_RJ = 14, S_Z = 15, S_R = 16,
+           S_D = 17, S_BD = 18, S_STEP = 19 };
+    for (int i = lane; i < NUM_VEC * a.npad; i += WAVE)
+        lds[i] = 0.0;
+    wave_sync();
+
+    IterateRef curr{S_IT0}, prox{S_IT1}, cand{S_IT2};
+    auto X_  = [&](const IterateRef &it) { return pb.vec(it.base + 0); };
+    auto XH_ = [&](const IterateRef &it) { return pb.vec(it.base + 1); };
+    auto G_  = [&](const IterateRef &it) { return pb.vec(it.base + 2); };
+    auto P_  = [&](const IterateRef &it) { return pb.vec(it.base + 3); };
+
+    DeviceStats st{};
+    st.eps = st.final_gamma = st.final_psi = st.final_fbe = st.final_radius = __builtin_nan("");
+    int status       = Busy;
+    double eps_k     = __builtin_nan("");
+    double radius    = __builtin_nan("");
+    const bool trace = a.trace != nullptr && inst < a.trace_instances;
+
+    // ---- load the initial guess ----
+    for (int j = 0; j < nj; ++j) {
+        int i = j * WAVE + lane;
+        if (i < n)
+            X_(curr)[i] = a.u[(size_t)inst * n + i];
+    }
+
+    // ---- Lipschitz estimate: finite difference of the gradient along the gradient ----
+    curr.psi_x = pb.psi_grad(X_(curr), G_(curr));
+    ++st.n_psi_grad_psi;
+    if (P.L_0 <= 0) {
+        double *h = pb.vec(S_WORK);
+        for (int j = 0; j < nj; ++j) {
+            int i = j * WAVE + lane;
+            if (i < n) {
+                double g  = G_(curr)[i];
+                double hh = g > 0 ? fmax(g * P.lip_eps, P.lip_delta) : fmin(g * P.lip_eps, -P.lip_delta);
+                h[i]         = hh;
+                XH_(curr)[i] = X_(curr)[i] - hh;
+            }
+        }
+        double norm_h = __builtin_sqrt(pb.dot(h, h));
+        pb.psi_grad(XH_(curr), G_(cand));
+        ++st.n_grad_psi;
+        for (int j = 0; j < nj; ++j) {
+            int i = j * WAVE + lane;
+            if (i < n)
+                h[i] = G_(cand)[i] - G_(curr)[i];
+        }
+        double Lest = __builtin_sqrt(pb.dot(h, h)) / norm_h;
+        curr.L      = fmin(fmax(Lest, P.L_min), P.L_max);
+    } else {
+        curr.L = P.L_0;
+    }
+
+    int k = 0, no_progress = 0;
+    if (!is_finite(curr.L)) {
+        status = NotFinite;
+    } else {
+        curr.gamma = P.Lgamma_factor / curr.L;
+        pb.prox_grad_step(curr.gamma, X_(curr), G_(curr), XH_(curr), P_(curr), curr.pTp, curr.gradTp);
+        ++st.n_prox_grad_step;
+        radius = P.initial_radius;
+        if (!is_finite(radius) || radius == 0)
+            radius = 0.1 * __builtin_sqrt(pb.dot(G_(curr), G_(curr)));
+        radius = fmax(radius, P.min_radius);
+    }
+
+    // `which` names the iterate whose psi(xhat) and quadratic-upper-bound backtracking are
+    // pending: 0 = the initial iterate, 1 = the accepted candidate, 2 = the prox iterate.
+    int which = 0;
+    while (status == Busy) {
+        if (which == 1)
+            swap_iter(curr, cand);
+        else if (which == 2)
+            swap_iter(curr, prox);
+        // ---- psi(xhat) + quadratic upper bound backtracking on the new current iterate ----
+        while (true) {
+            curr.psi_xh = pb.template psi_forward<false>(XH_(curr));
+            ++st.n_psi;
+            double margin = (1.0 + fabs(curr.psi_x)) * P.quadratic_upperbound_tolerance_factor;
+            bool violated = curr.psi_xh > ((curr.psi_x + curr.gradTp) + (0.5 * curr.L) * curr.pTp) + margin;
+            if (!(curr.L < P.L_max && violated))
+                break;
+            curr.gamma = curr.gamma / 2.0;
+            curr.L     = curr.L * 2.0;
+            pb.prox_grad_step(curr.gamma, X_(curr), G_(curr), XH_(curr), P_(curr), curr.pTp,
+                              curr.gradTp);
+            ++st.n_prox_grad_step;
+            ++st.qub_backtracks;
+        }
+        if (which != 0) {
+            // did x move at all?  (the previous iterate now sits in cand or prox)
+            const double *xo = pb.vec(which == 1 ? cand.base : prox.base);
+            const double *xn = X_(curr);
+            bool same = true;
+            for (int j = 0; j < nj; ++j) {
+                int i = j * WAVE + lane;
+                if (i < n)
+                    same = same && xn[i] == xo[i];
+            }
+            bool all_same = __builtin_amdgcn_readfirstlane(__all(same ? 1 : 0)) != 0;
+            no_progress   = all_same ? no_progress + 1 : 0;
+            ++k;
+        }
+
+        // ---- stop criterion ----
+        if (P.stop_crit == ProjGradUnitNorm) {
+            eps_k = pb.proj_grad_unit_norm(X_(curr), G_(curr));
+            ++st.n_prox_grad_step;
+        } else if (P.stop_crit == FPRNorm) {
+            eps_k = pb.norm_inf(P_(curr)) / curr.gamma;
+        } else {
+            eps_k = __builtin_nan("");
+        }
+        double elapsed   = (double)(wall_clock64() - t_start) * 1e-8;
+        bool converged   = eps_k <= P.tolerance;
+        bool out_of_time = elapsed > P.max_time_s;
+        bool out_of_iter = k == P.max_iter;
+        bool not_finite  = !is_finite(eps_k);
+        bool stalled     = no_progress > P.max_no_progress;
+        status = converged ? Converged : out_of_time ? MaxTime : out_of_iter ? MaxIter
+                 : not_finite ? NotFinite : stalled ? NoProgress : Busy;
+        status = uniform(status);
+        if (status != Busy)
+            break;
+
+        // ---- forward-backward step: prox iterate xbar = xhat_k, grad via grad_L(xhat) ----
+        for (int j = 0; j < nj; ++j) {
+            int i = j * WAVE + lane;
+            if (i < n)
+                X_(prox)[i] = XH_(curr)[i];
+        }
+        prox.psi_x = curr.psi_xh;
+        pb.psi_grad(X_(prox), G_(prox));
+        ++st.n_grad_L;
+        prox.gamma = curr.gamma;
+        prox.L     = curr.L;
+        pb.prox_grad_step(prox.gamma, X_(prox), G_(prox), XH_(prox), P_(prox), prox.pTp, prox.gradTp);
+        ++st.n_prox_grad_step;
+
+        // ---- Newton trust-region direction at xbar (Steihaug-Toint CG on the inactive set) ----
+        bool accept    = false;
+        double rho     = __builtin_nan(""), q_model = __builtin_nan("");
+        int nJ = 0, cg_its = 0;
+        if (!P.disable_acceleration) {
+            double *q = pb.vec(S_Q), *work = pb.vec(S_WORK), *rJ = pb.vec(S_RJ), *z = pb.vec(S_Z),
+                   *r = pb.vec(S_R), *d = pb.vec(S_D), *Bd = pb.vec(S_BD), *step = pb.vec(S_STEP);
+            const uint32_t mask = pb.inactive_mask(prox.gamma, X_(prox), G_(prox), nJ);
+            const double inv_gamma = -1.0 / prox.gamma;
+            for (int j = 0; j < nj; ++j) {
+                int i = j * WAVE + lane;
+                if (i < n) {
+                    bool in   = (mask >> j) & 1u;
+                    double pi = P_(prox)[i];
+                    rJ[i]     = in ? inv_gamma * pi : 0.0;
+                    q[i]      = in ? 0.0 : pi;
+                }
+            }
+            enum { KTERM, CGSTART, CG, EVAL_A, EVAL_B, EVAL_STEP };
+            int state = (P.hessian_vec_factor != 0 && nJ < n) ? KTERM : CGSTART;
+            const double *vin = q;
+            double r_sq = 0, tolerance = 0, qa = 0;
+            int cg_i = 0;
+            const int cg_max = (int)lround((double)nJ * P.max_iter_factor);
+            while (true) {
+                if (state == CGSTART) {
+                    for (int j = 0; j < nj; ++j) {
+                        int i = j * WAVE + lane;
+                        if (i < n) {
+                            double g = rJ[i];
+                            z[i]     = 0.0;
+                            r[i]     = g;
+                            d[i]     = -g;
+                        }
+                    }
+                    r_sq            = pb.dot(r, r);
+                    double grad_mag = __builtin_sqrt(r_sq);
+                    if (!(grad_mag > 0.0)) {
+                        for (int j = 0; j < nj; ++j) {
+                            int i = j * WAVE + lane;
+                            if (i < n)
+                                step[i] = 0.0;
+                        }
+                        q_model = grad_mag == 0.0 ? 0.0 : __builtin_nan("");
+                        break;
+                    }
+                    double rooted = P.tol_scale_root == 0.5 ? __builtin_sqrt(grad_mag)
+                                                            : pow(grad_mag, P.tol_scale_root);
+                    tolerance = fmin(P.tol_max, (P.tol_scale * grad_mag) * fmin(1.0, rooted));
+                    state     = CG;
+                    vin       = d;
+                }
+                // the one Hessian-vector product site: work = H(xbar) * vin
+                pb.hess_prod(X_(prox), vin, work);
+                ++st.n_hess_psi_prod;
+                if (state == KTERM) {
+                    for (int j = 0; j < nj; ++j) {
+                        int i = j * WAVE + lane;
+                        if (i < n && ((mask >> j) & 1u))
+                            rJ[i] = rJ[i] + P.hessian_vec_factor * work[i];
+                    }
+                    state = CGSTART;
+                    continue;
+                }
+                if (state == CG) {
+                    for (int j = 0; j < nj; ++j) {
+                        int i = j * WAVE + lane;
+                        if (i < n)
+                            Bd[i] = (mask >> j) & 1u ? work[i] : 0.0;
+                    }
+                    ++cg_its;
+                    double dBd = pb.dot(d, Bd);
+                    bool to_boundary = false, neg_curv = dBd <= 0.0;
+                    double alpha = 0;
+                    if (!neg_curv) {
+                        alpha = r_sq / dBd;
+                        for (int j = 0; j < nj; ++j) {
+                            int i = j * WAVE + lane;
+                            if (i < n)
+                                step[i] = z[i] + alpha * d[i];
+                        }
+                        to_boundary = __builtin_sqrt(pb.dot(step, step)) >= radius;
+                    }
+                    if (neg_curv || to_boundary) {
+                        // ||z + t d|| = radius
+                        double zz = pb.dot(z, z), zd = pb.dot(z, d), dd = pb.dot(d, d);
+                        double qa_ = dd, qb_ = 2.0 * zd, qc_ = zz - radius * radius;
+                        double sqd = __builtin_sqrt(qb_ * qb_ - (4.0 * qa_) * qc_);
+                        double aux = qb_ + copysign(sqd, qb_);
+                        double t1 = (-aux) / (2.0 * qa_), t2 = (-(2.0 * qc_)) / aux;
+                        double ta = fmin(t1, t2), tb = fmax(t1, t2);
+                        if (neg_curv) {
+                            for (int j = 0; j < nj; ++j) {
+                                int i = j * WAVE + lane;
+                                if (i < n) {
+                                    double zi = z[i], di = d[i];
+                                    r[i] = zi + ta * di;
+                                    d[i] = zi + tb * di;
+                                }
+                            }
+                            state = EVAL_A;
+                            vin   = r;
+                        } else {
+                            for (int j = 0; j < nj; ++j) {
+                                int i = j * WAVE + lane;
+                                if (i < n)
+                                    step[i] = z[i] + tb * d[i];
+                            }
+                            state = EVAL_STEP;
+                            vin   = step;
+                        }
+                        continue;
+                    }
+                    for (int j = 0; j < nj; ++j) {
+                        int i = j * WAVE + lane;
+                        if (i < n)
+                            r[i] = r[i] + alpha * Bd[i];
+                    }
+                    double r_next_sq = pb.dot(r, r);
+                    if (__builtin_sqrt(r_next_sq) < tolerance || cg_i > cg_max) {
+                        state = EVAL_STEP;
+                        vin   = step;
+                        continue;
+                    }
+                    double beta = r_next_sq / r_sq;
+                    r_sq        = r_next_sq;
+                    for (int j = 0; j < nj; ++j) {
+                        int i = j * WAVE + lane;
+                        if (i < n) {
+                            d[i] = (-r[i]) + beta * d[i];
+                            z[i] = step[i];
+                        }
+                    }
+                    ++cg_i;
+                    vin = d;
+                    continue;
+                }
+                // model value m(p) = p'g + 1/2 p'Hp of the vector just multiplied
+                double mval = pb.dot(vin, rJ) + 0.5 * pb.dot_masked(vin, work, mask);
+                if (state == EVAL_A) {
+                    qa    = mval;
+                    state = EVAL_B;
+                    vin   = d;
+                    continue;
+                }
+                if (state == EVAL_B) {
+                    bool a_best = qa < mval;
+                    const double *best = a_best ? r : d;
+                    for (int j = 0; j < nj; ++j) {
+                        int i = j * WAVE + lane;
+                        if (i < n)
+                            step[i] = best[i];
+                    }
+                    q_model = a_best ? qa : mval;
+                    break;
+                }
+                q_model = mval; // EVAL_STEP
+                break;
+            }
+            st.cg_iterations += cg_its;
+            // full step: Newton part on J, prox step on the active set
+            bool fin = true;
+            for (int j = 0; j < nj; ++j) {
+                int i = j * WAVE + lane;
+                if (i < n) {
+                    double qi = (mask >> j) & 1u ? step[i] : P_(prox)[i];
+                    q[i]      = qi;
+                    fin       = fin && is_finite(qi);
+                }
+            }
+            bool q_finite = __builtin_amdgcn_readfirstlane(__all(fin ? 1 : 0)) != 0;
+            if (q_finite && q_model < 0) {
+                for (int j = 0; j < nj; ++j) {
+                    int i = j * WAVE + lane;
+                    if (i < n)
+                        X_(cand)[i] = X_(prox)[i] + q[i];
+                }
+                cand.psi_x = pb.psi_grad(X_(cand), G_(cand));
+                ++st.n_psi_grad_psi;
+                cand.gamma = prox.gamma;
+                cand.L     = prox.L;
+                pb.prox_grad_step(cand.gamma, X_(cand), G_(cand), XH_(cand), P_(cand), cand.pTp,
+                                  cand.gradTp);
+                ++st.n_prox_grad_step;
+                double phi_k = prox.fbe(), phi_n = cand.fbe();
+                double tr_eps = (1.0 + fabs(phi_k)) * P.TR_tolerance_factor;
+                rho    = ((phi_k - phi_n) + tr_eps) / (-q_model);
+                accept = rho >= P.ratio_threshold_acceptable;
+                double qn = __builtin_sqrt(pb.dot(q, q));
+                double nr = rho >= P.ratio_threshold_good ? fmax(P.radius_factor_good * qn, radius)
+                            : rho >= P.ratio_threshold_acceptable ? radius * P.radius_factor_acceptable
+                                                                  : P.radius_factor_rejected * qn;
+                if (rho != rho)
+                    nr = P.radius_factor_rejected * qn;
+                radius = fmax(nr, P.min_radius);
+            }
+        }
+        if (trace && k < a.trace_cap && lane == 0) {
+            double *o = a.trace + ((size_t)inst * a.trace_cap + k) * TRACE_COLS;
+            o[0] = eps_k; o[1] = curr.psi_x; o[2] = __builtin_sqrt(curr.pTp); o[3] = curr.gamma;
+            o[4] = radius; o[5] = rho; o[6] = q_model; o[7] = curr.fbe(); o[8] = nJ; o[9] = cg_its;
+            o[10] = accept ? 1.0 : 0.0;
+        }
+        if (accept) {
+            which = 1;
+            ++st.accepted;
+        } else {
+            which = 2;
+            ++st.rejected;
+        }
+    }
+
+    // ---- results ----
+    if ((status == Converged || status == Interrupted || P.always_overwrite_results) && is_finite(curr.L)) {
+        for (int j = 0; j < nj; ++j) {
+            int i = j * WAVE + lane;
+            if (i < n)
+                a.u[(size_t)inst * n + i] = XH_(curr)[i];
+        }
+    }
+    if (lane == 0) {
+        st.status       = status;
+        st.iterations   = k;
+        st.eps          = eps_k;
+        st.final_gamma  = curr.gamma;
+        st.final_psi    = curr.psi_xh;
+        st.final_fbe    = curr.fbe();
+        st.final_radius = radius;
+        st.elapsed_s    = (double)(wall_clock64() - t_start) * 1e-8;
+        a.stats[inst]   = st;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Stand-alone problem-function kernels (parity tests of rows a7-a9, a13; same device code)
+// ---------------------------------------------------------------------------------------
+enum EvalMode : int32_t { EVAL_PSI = 0, EVAL_PSI_GRAD = 1, EVAL_HESS_PROD = 2, EVAL_PROX = 3 };
+
+struct EvalArgs {
+    int32_t B, N, n, npad, nj, mode;
+    const double *x0; ///< [B][nx]
+    const double *u;  ///< [B][n]
+    const double *v;  ///< [B][n]  (HESS_PROD: direction; PROX: gradient)
+    double *out_s;    ///< [B][4]  psi | (pTp, gradTp, eps_unit, nJ)
+    double *out_v;    ///< [B][n]  grad | Hv | xhat
+    double *out_v2;   ///< [B][n]  PROX: p
+    double *ws;       ///< [B][2][(N+1)][64]
+    double gamma;
+};
+
+template <class M>
+__global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, inst = blockIdx.x;
+    if (inst >= a.B)
+        return;
+    typename M::Lane L(lane);
+    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, 0.0, nullptr, nullptr};
+    pb.x0 = lane < M::nx ? a.x0[(size_t)inst * M::nx + lane] : 0.0;
+    pb.X  = a.ws + (size_t)inst * 2 * (a.N + 1) * WAVE;
+    pb.Xt = pb.X + (size_t)(a.N + 1) * WAVE;
+    double *u = pb.vec(0), *v = pb.vec(1), *o = pb.vec(2), *o2 = pb.vec(3);
+    for (int i = lane; i < 4 * a.npad; i += WAVE)
+        lds[i] = 0.0;
+    wave_sync();
+    for (int i = lane; i < a.n; i += WAVE) {
+        u[i] = a.u[(size_t)inst * a.n + i];
+        if (a.v)
+            v[i] = a.v[(size_t)inst * a.n + i];
+    }
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (a.mode == EVAL_PSI) {
+        s0 = pb.template psi_forward<false>(u);
+    } else if (a.mode == EVAL_PSI_GRAD) {
+        s0 = pb.psi_grad(u, o);
+    } else if (a.mode == EVAL_HESS_PROD) {
+        pb.hess_prod(u, v, o);
+    } else {
+        pb.prox_grad_step(a.gamma, u, v, o, o2, s0, s1);
+        s2 = pb.proj_grad_unit_norm(u, v);
+        int nJ;
+        pb.inactive_mask(a.gamma, u, v, nJ);
+        s3 = nJ;
+    }
+    for (int i = lane; i < a.n; i += WAVE) {
+        if (a.out_v)
+            a.out_v[(size_t)inst * a.n + i] = o[i];
+        if (a.out_v2)
+            a.out_v2[(size_t)inst * a.n + i] = o2[i];
+    }
+    if (lane == 0 && a.out_s) {
+        double *os = a.out_s + (size_t)inst * 4;
+        os[0] = s0; os[1] = s1; os[2] = s2; os[3] = s3;
+    }
+}
+
+/// Plant step x+ = f_d(x, u) for a batch (formulation.hpp:258-261).
+template <class M>
+__global__ __launch_bounds__(WAVE) void pantr_simulate_kernel(int B, const double *x, const double *u,
+                                                              double *xn) {
+    const int lane = threadIdx.x, inst = blockIdx.x;
+    if (inst >= B)
+        return;
+    typename M::Lane L(lane);
+    double s  = lane < M::nx ? x[(size_t)inst * M::nx + lane] : 0.0;
+    double uc = u[(size_t)inst * M::nu + L.uidx];
+    double r  = M::rk4(L, s, uc);
+    if (lane < M::nx)
+        xn[(size_t)inst * M::nx + lane] = r;
+}
+
+} // namespace pantr

@@ -1,0 +1,94 @@
+// Wavefront-level arithmetic for gfx950 (CDNA4): one 64-lane wavefront cooperates on one
+// MPC instance.  Cross-lane data movement is ds_bpermute (LDS crossbar, no LDS memory);
+// reductions are xor-butterflies so that every lane ends with the same bits.
+//
+// Built with -ffp-contract=off: the order of operations written here is the order that
+// runs.  DESIGN.md ("Arithmetic specification") states that order.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pantr {
+
+constexpr int WAVE = 64;
+
+// ---- first-order dual number (value, tangent) -------------------------------------------
+struct dual {
+    double v, t;
+};
+__device__ __forceinline__ dual operator+(dual a, dual b) { return {a.v + b.v, a.t + b.t}; }
+__device__ __forceinline__ dual operator-(dual a, dual b) { return {a.v - b.v, a.t - b.t}; }
+__device__ __forceinline__ dual operator*(dual a, dual b) {
+    return {a.v * b.v, (a.v * b.t) + (a.t * b.v)};
+}
+__device__ __forceinline__ dual operator*(double c, dual a) { return {c * a.v, c * a.t}; }
+__device__ __forceinline__ dual operator+(dual a, double c) { return {a.v + c, a.t}; }
+__device__ __forceinline__ dual operator-(dual a, double c) { return {a.v - c, a.t}; }
+__device__ __forceinline__ dual operator-(double c, dual a) { return {c - a.v, 0.0 - a.t}; }
+__device__ __forceinline__ dual operator/(dual a, dual b) {
+    return {a.v / b.v, ((a.t * b.v) - (a.v * b.t)) / (b.v * b.v)};
+}
+__device__ __forceinline__ dual operator/(double c, dual b) {
+    return {c / b.v, (-(c * b.t)) / (b.v * b.v)};
+}
+__device__ __forceinline__ dual wsqrt(dual a) {
+    double r = __builtin_sqrt(a.v);
+    return {r, (a.t * 0.5) / r};
+}
+__device__ __forceinline__ double wsqrt(double a) { return __builtin_sqrt(a); }
+
+template <class T>
+__device__ __forceinline__ T make_const(double c);
+template <>
+__device__ __forceinline__ double make_const<double>(double c) { return c; }
+template <>
+__device__ __forceinline__ dual make_const<dual>(double c) { return {c, 0.0}; }
+
+__device__ __forceinline__ double select(bool c, double a, double b) { return c ? a : b; }
+__device__ __forceinline__ dual select(bool c, dual a, dual b) {
+    return {c ? a.v : b.v, c ? a.t : b.t};
+}
+
+// ---- cross-lane ----------------------------------------------------------------------------
+/// Value of `v` held by lane `src` (src taken modulo 64 by the hardware).
+__device__ __forceinline__ double lane_read(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo     = __builtin_amdgcn_ds_bpermute(src << 2, lo);
+    hi     = __builtin_amdgcn_ds_bpermute(src << 2, hi);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ dual lane_read(dual v, int src) {
+    return {lane_read(v.v, src), lane_read(v.t, src)};
+}
+
+/// 64-lane butterfly all-reduce: masks 32, 16, 8, 4, 2, 1; a + partner at every level, so
+/// all lanes finish with bit-identical sums.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v = v + lane_read(v, (int)(threadIdx.x & 63) ^ m);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v = fmax(v, lane_read(v, (int)(threadIdx.x & 63) ^ m));
+    return v;
+}
+
+/// Order this wavefront's LDS/global accesses: what any lane wrote before is visible to every
+/// lane after (the workgroup is a single wavefront, so no s_barrier is involved).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+/// Move a wave-uniform double into scalar registers (lets the compiler branch on SCC).
+__device__ __forceinline__ double uniform(double v) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+} // namespace pantr

@@ -1,0 +1,341 @@
+// Solver option structs and the "prefix.key=value" parser.
+//
+// Mirrors the part of alpaqa's option surface the reference exercises:
+//   alpaqa::params::set_params(obj, prefix, opts)  drivers/mpc-driver.cpp:54,61,62,113
+//   PANTRParams / NewtonTRDirectionParams / SteihaugCGParams / ALMParams
+//       values set in new-benchmarks-paper/dodo.py:12-33,98-105 and
+//       benchmarks-paper/Makefile:218-224; driver defaults mpc-driver.cpp:51-53,109-111
+// Field names and defaults follow upstream alpaqa (develop, mid-2023); the structs are plain
+// data so they can cross the C ABI by value.
+#pragma once
+#include <cerrno>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <string_view>
+
+namespace pantr::host {
+
+inline constexpr double kEps = std::numeric_limits<double>::epsilon();
+inline constexpr double kNaN = std::numeric_limits<double>::quiet_NaN();
+inline constexpr double kInf = std::numeric_limits<double>::infinity();
+
+/// alpaqa::PANOCStopCrit
+enum class PANOCStopCrit : int32_t {
+    ApproxKKT = 0, ApproxKKT2, ProjGradNorm, ProjGradNorm2, ProjGradUnitNorm, ProjGradUnitNorm2,
+    FPRNorm, FPRNorm2, Ipopt, LBFGSBpp,
+};
+inline const char *enum_name(PANOCStopCrit s) {
+    static const char *names[] = {"ApproxKKT", "ApproxKKT2", "ProjGradNorm", "ProjGradNorm2",
+                                  "ProjGradUnitNorm", "ProjGradUnitNorm2", "FPRNorm", "FPRNorm2",
+                                  "Ipopt", "LBFGSBpp"};
+    return names[static_cast<int>(s)];
+}
+
+/// alpaqa::SolverStatus (printed at mpc-driver.cpp:218)
+enum class SolverStatus : int32_t {
+    Busy = 0, Converged, MaxTime, MaxIter, NotFinite, NoProgress, Interrupted, Exception,
+};
+inline const char *enum_name(SolverStatus s) {
+    static const char *names[] = {"Busy", "Converged", "MaxTime", "MaxIter", "NotFinite",
+                                  "NoProgress", "Interrupted", "Exception"};
+    int i = static_cast<int>(s);
+    return i >= 0 && i < 8 ? names[i] : "<unknown>";
+}
+
+struct LipschitzEstimateParams {
+    double L_0 = 0, epsilon = 1e-6, delta = 1e-12, Lgamma_factor = 0.95;
+};
+
+struct PANTRParams {
+    LipschitzEstimateParams Lipschitz;
+    int32_t max_iter      = 100;
+    double max_time       = 300; ///< seconds (alpaqa: 5 min)
+    double L_min = 1e-5, L_max = 1e20;
+    PANOCStopCrit stop_crit = PANOCStopCrit::ApproxKKT;
+    int32_t max_no_progress = 10;
+    int32_t print_interval = 0, print_precision = 6;
+    double quadratic_upperbound_tolerance_factor = 10 * kEps;
+    double TR_tolerance_factor                   = 10 * kEps;
+    double ratio_threshold_acceptable = 0.2, ratio_threshold_good = 0.8;
+    double radius_factor_rejected = 0.35, radius_factor_acceptable = 0.999, radius_factor_good = 2.5;
+    double initial_radius = kNaN, min_radius = 100 * kEps;
+    bool compute_ratio_using_new_stepsize               = false;
+    bool update_direction_on_prox_step                  = true;
+    bool recompute_last_prox_step_after_direction_reset = false;
+    bool disable_acceleration                           = false;
+    bool ratio_approx_fbe_quadratic_model               = true;
+};
+
+struct NewtonTRDirectionParams {
+    double hessian_vec_factor   = 0.5;
+    bool finite_diff            = false;
+    double finite_diff_stepsize = 1.4901161193847656e-08; // sqrt(eps)
+};
+
+struct SteihaugCGParams {
+    double tol_scale = 1, tol_scale_root = 0.5, tol_max = kInf, max_iter_factor = 1;
+};
+
+struct ALMParams {
+    double tolerance = 1e-5, dual_tolerance = 1e-5;
+    double penalty_update_factor = 10, initial_penalty = 1, initial_penalty_factor = 20;
+    double initial_tolerance = 1, tolerance_update_factor = 1e-1;
+    double rel_penalty_increase_threshold = 0.1;
+    double max_multiplier = 1e9, max_penalty = 1e9, min_penalty = 1e-9;
+    int32_t max_iter = 100;
+    double max_time  = 300; ///< seconds
+    int32_t print_interval = 0, print_precision = 6;
+    bool single_penalty_factor = false;
+};
+
+/// Everything one solver instance is configured by.
+struct SolverOptions {
+    PANTRParams solver;
+    NewtonTRDirectionParams dir;
+    SteihaugCGParams accel;
+    ALMParams alm;
+    /// make_inner_solver / make_solver defaults of the reference driver
+    /// (mpc-driver.cpp:51-53 and :109-111), applied before the CLI options.
+    static SolverOptions driver_defaults() {
+        SolverOptions o;
+        o.solver.max_iter       = 50'000;
+        o.solver.print_interval = 0;
+        o.solver.stop_crit      = PANOCStopCrit::FPRNorm;
+        o.alm.max_iter          = 200;
+        o.alm.tolerance         = 1e-8;
+        o.alm.dual_tolerance    = 1e-8;
+        o.alm.print_interval    = 0;
+        return o;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// value parsers
+// ---------------------------------------------------------------------------------------
+inline bool parse_double(std::string_view s, double &out) {
+    std::string tmp(s);
+    if (tmp.empty())
+        return false;
+    char *end = nullptr;
+    errno     = 0;
+    double v  = std::strtod(tmp.c_str(), &end);
+    if (end == tmp.c_str() || *end != '\0')
+        return false;
+    out = v;
+    return true;
+}
+inline bool parse_int(std::string_view s, int32_t &out) {
+    std::string tmp(s);
+    if (tmp.empty())
+        return false;
+    char *end   = nullptr;
+    long long v = std::strtoll(tmp.c_str(), &end, 10);
+    if (end == tmp.c_str() || *end != '\0') {
+        // accept integral floating notation such as 5e4
+        double d;
+        if (!parse_double(s, d) || d != std::floor(d))
+            return false;
+        v = static_cast<long long>(d);
+    }
+    if (v < std::numeric_limits<int32_t>::min() || v > std::numeric_limits<int32_t>::max())
+        return false;
+    out = static_cast<int32_t>(v);
+    return true;
+}
+inline bool parse_bool(std::string_view s, bool &out) {
+    if (s == "true" || s == "1" || s == "True") {
+        out = true;
+        return true;
+    }
+    if (s == "false" || s == "0" || s == "False") {
+        out = false;
+        return true;
+    }
+    return false;
+}
+/// "30s", "500ms", "2min", "1h", "250us", "10ns"; a bare number is seconds.
+inline bool parse_duration(std::string_view s, double &seconds) {
+    static const struct {
+        const char *suffix;
+        double scale;
+    } units[] = {{"ns", 1e-9}, {"us", 1e-6}, {"µs", 1e-6}, {"ms", 1e-3}, {"min", 60}, {"h", 3600}, {"s", 1}};
+    for (const auto &u : units) {
+        size_t len = std::strlen(u.suffix);
+        if (s.size() > len && s.substr(s.size() - len) == u.suffix) {
+            double v;
+            if (!parse_double(s.substr(0, s.size() - len), v))
+                return false;
+            seconds = v * u.scale;
+            return true;
+        }
+    }
+    return parse_double(s, seconds);
+}
+inline bool parse_stop_crit(std::string_view s, PANOCStopCrit &out) {
+    for (int i = 0; i <= static_cast<int>(PANOCStopCrit::LBFGSBpp); ++i)
+        if (s == enum_name(static_cast<PANOCStopCrit>(i))) {
+            out = static_cast<PANOCStopCrit>(i);
+            return true;
+        }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------
+// key table
+// ---------------------------------------------------------------------------------------
+enum class FieldType { Double, Int, Bool, Duration, StopCrit };
+struct FieldRef {
+    FieldType type;
+    void *ptr;
+};
+
+/// Resolve "prefix.key" to a field; returns false if the prefix is ours but the key is not.
+/// `known_prefix` tells the caller whether the string was addressed to one of our structs.
+inline bool find_field(SolverOptions &o, std::string_view full_key, FieldRef &ref, bool &known_prefix) {
+    auto dot = full_key.find('.');
+    known_prefix = false;
+    if (dot == std::string_view::npos)
+        return false;
+    std::string_view prefix = full_key.substr(0, dot), key = full_key.substr(dot + 1);
+#define PANTR_FIELD(name, T, member)                                                               \
+    if (key == name) {                                                                             \
+        ref = {FieldType::T, &(member)};                                                           \
+        return true;                                                                               \
+    }
+    if (prefix == "solver") {
+        known_prefix = true;
+        auto &s = o.solver;
+        PANTR_FIELD("Lipschitz.L_0", Double, s.Lipschitz.L_0)
+        PANTR_FIELD("Lipschitz.ε", Double, s.Lipschitz.epsilon)
+        PANTR_FIELD("Lipschitz.epsilon", Double, s.Lipschitz.epsilon)
+        PANTR_FIELD("Lipschitz.δ", Double, s.Lipschitz.delta)
+        PANTR_FIELD("Lipschitz.delta", Double, s.Lipschitz.delta)
+        PANTR_FIELD("Lipschitz.Lγ_factor", Double, s.Lipschitz.Lgamma_factor)
+        PANTR_FIELD("Lipschitz.Lgamma_factor", Double, s.Lipschitz.Lgamma_factor)
+        PANTR_FIELD("max_iter", Int, s.max_iter)
+        PANTR_FIELD("max_time", Duration, s.max_time)
+        PANTR_FIELD("L_min", Double, s.L_min)
+        PANTR_FIELD("L_max", Double, s.L_max)
+        PANTR_FIELD("stop_crit", StopCrit, s.stop_crit)
+        PANTR_FIELD("max_no_progress", Int, s.max_no_progress)
+        PANTR_FIELD("print_interval", Int, s.print_interval)
+        PANTR_FIELD("print_precision", Int, s.print_precision)
+        PANTR_FIELD("quadratic_upperbound_tolerance_factor", Double, s.quadratic_upperbound_tolerance_factor)
+        PANTR_FIELD("TR_tolerance_factor", Double, s.TR_tolerance_factor)
+        PANTR_FIELD("ratio_threshold_acceptable", Double, s.ratio_threshold_acceptable)
+        PANTR_FIELD("ratio_threshold_good", Double, s.ratio_threshold_good)
+        PANTR_FIELD("radius_factor_rejected", Double, s.radius_factor_rejected)
+        PANTR_FIELD("radius_factor_acceptable", Double, s.radius_factor_acceptable)
+        PANTR_FIELD("radius_factor_good", Double, s.radius_factor_good)
+        PANTR_FIELD("initial_radius", Double, s.initial_radius)
+        PANTR_FIELD("min_radius", Double, s.min_radius)
+        PANTR_FIELD("compute_ratio_using_new_stepsize", Bool, s.compute_ratio_using_new_stepsize)
+        PANTR_FIELD("update_direction_on_prox_step", Bool, s.update_direction_on_prox_step)
+        PANTR_FIELD("recompute_last_prox_step_after_direction_reset", Bool,
+                    s.recompute_last_prox_step_after_direction_reset)
+        PANTR_FIELD("disable_acceleration", Bool, s.disable_acceleration)
+        PANTR_FIELD("ratio_approx_fbe_quadratic_model", Bool, s.ratio_approx_fbe_quadratic_model)
+        return false;
+    }
+    if (prefix == "dir") {
+        known_prefix = true;
+        auto &d = o.dir;
+        PANTR_FIELD("hessian_vec_factor", Double, d.hessian_vec_factor)
+        PANTR_FIELD("finite_diff", Bool, d.finite_diff)
+        PANTR_FIELD("finite_diff_stepsize", Double, d.finite_diff_stepsize)
+        return false;
+    }
+    if (prefix == "accel") {
+        known_prefix = true;
+        auto &c = o.accel;
+        PANTR_FIELD("tol_scale", Double, c.tol_scale)
+        PANTR_FIELD("tol_scale_root", Double, c.tol_scale_root)
+        PANTR_FIELD("tol_max", Double, c.tol_max)
+        PANTR_FIELD("max_iter_factor", Double, c.max_iter_factor)
+        return false;
+    }
+    if (prefix == "alm") {
+        known_prefix = true;
+        auto &m = o.alm;
+        PANTR_FIELD("tolerance", Double, m.tolerance)
+        PANTR_FIELD("dual_tolerance", Double, m.dual_tolerance)
+        PANTR_FIELD("penalty_update_factor", Double, m.penalty_update_factor)
+        PANTR_FIELD("initial_penalty", Double, m.initial_penalty)
+        PANTR_FIELD("initial_penalty_factor", Double, m.initial_penalty_factor)
+        PANTR_FIELD("initial_tolerance", Double, m.initial_tolerance)
+        PANTR_FIELD("tolerance_update_factor", Double, m.tolerance_update_factor)
+        PANTR_FIELD("rel_penalty_increase_threshold", Double, m.rel_penalty_increase_threshold)
+        PANTR_FIELD("max_multiplier", Double, m.max_multiplier)
+        PANTR_FIELD("max_penalty", Double, m.max_penalty)
+        PANTR_FIELD("min_penalty", Double, m.min_penalty)
+        PANTR_FIELD("max_iter", Int, m.max_iter)
+        PANTR_FIELD("max_time", Duration, m.max_time)
+        PANTR_FIELD("print_interval", Int, m.print_interval)
+        PANTR_FIELD("print_precision", Int, m.print_precision)
+        PANTR_FIELD("single_penalty_factor", Bool, m.single_penalty_factor)
+        return false;
+    }
+#undef PANTR_FIELD
+    return false;
+}
+
+enum class SetResult { Ok, Ignored, UnknownKey, BadValue, Malformed };
+
+/// Apply one "prefix.key=value" option.  Options for other objects are ignored, as
+/// alpaqa::params::set_params ignores keys whose prefix is not the one it was given.
+inline SetResult set_option(SolverOptions &o, std::string_view kv, std::string &err) {
+    auto eq = kv.find('=');
+    if (eq == std::string_view::npos) {
+        auto dot = kv.find('.');
+        std::string_view prefix = dot == std::string_view::npos ? kv : kv.substr(0, dot);
+        if (prefix == "solver" || prefix == "dir" || prefix == "accel" || prefix == "alm") {
+            err = "Option '" + std::string(kv) + "' is missing '=value'";
+            return SetResult::Malformed;
+        }
+        return SetResult::Ignored;
+    }
+    std::string_view key = kv.substr(0, eq), value = kv.substr(eq + 1);
+    FieldRef ref{};
+    bool known_prefix = false;
+    if (!find_field(o, key, ref, known_prefix)) {
+        if (!known_prefix)
+            return SetResult::Ignored;
+        err = "Invalid key '" + std::string(key) + "'";
+        return SetResult::UnknownKey;
+    }
+    bool ok = false;
+    switch (ref.type) {
+    case FieldType::Double: ok = parse_double(value, *static_cast<double *>(ref.ptr)); break;
+    case FieldType::Int: ok = parse_int(value, *static_cast<int32_t *>(ref.ptr)); break;
+    case FieldType::Bool: ok = parse_bool(value, *static_cast<bool *>(ref.ptr)); break;
+    case FieldType::Duration: ok = parse_duration(value, *static_cast<double *>(ref.ptr)); break;
+    case FieldType::StopCrit: ok = parse_stop_crit(value, *static_cast<PANOCStopCrit *>(ref.ptr)); break;
+    }
+    if (!ok) {
+        err = "Invalid value '" + std::string(value) + "' for '" + std::string(key) + "'";
+        return SetResult::BadValue;
+    }
+    return SetResult::Ok;
+}
+
+/// Read a field back as a double (enums/bools/ints converted); false if unknown.
+inline bool get_option(const SolverOptions &o, std::string_view key, double &out) {
+    FieldRef ref{};
+    bool known = false;
+    if (!find_field(const_cast<SolverOptions &>(o), key, ref, known))
+        return false;
+    switch (ref.type) {
+    case FieldType::Double:
+    case FieldType::Duration: out = *static_cast<double *>(ref.ptr); break;
+    case FieldType::Int: out = *static_cast<int32_t *>(ref.ptr); break;
+    case FieldType::Bool: out = *static_cast<bool *>(ref.ptr) ? 1 : 0; break;
+    case FieldType::StopCrit: out = static_cast<int>(*static_cast<PANOCStopCrit *>(ref.ptr)); break;
+    }
+    return true;
+}
+
+} // namespace pantr::host

@@ -1,0 +1,325 @@
+"""Python host binding (ctypes) of the MI355X-native batched PANTR solver.
+
+Thin mirror of include/pantr_mi355x.h; the compute lives in
+lib/libpantr_mi355x.so (hand-written HIP for gfx950).  There is no CPU fallback:
+if the library is missing, or no HIP device is present when a compute call is
+made, this module raises.
+
+The Python-level names follow the reference's driver surface:
+  PantrBatch.solve        <->  stats = solver(problem, u, y)       drivers/mpc-driver.cpp:217
+  PantrBatch.set_params   <->  alpaqa::params::set_params          drivers/mpc-driver.cpp:54,61,62,113
+  DODO_PANTR_OPTS         <->  SOLVER_OPT["pantr"]                 new-benchmarks-paper/dodo.py:12-33
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libpantr_mi355x.so")
+
+_dbl, _i32 = C.c_double, C.c_int32
+
+STATUS_NAMES = ("Busy", "Converged", "MaxTime", "MaxIter", "NotFinite", "NoProgress",
+                "Interrupted", "Exception")
+TRACE_COLS = ("eps", "psi", "pnorm", "gamma", "radius", "rho", "q_model", "fbe", "nJ",
+              "cg_its", "accepted")
+
+# new-benchmarks-paper/dodo.py:12-22 (OPT_ALM) + :25-33 (SOLVER_OPT["pantr"])
+DODO_PANTR_OPTS = (
+    "alm.max_iter=300", "alm.max_time=30s", "alm.initial_penalty=1e4",
+    "alm.penalty_update_factor=5", "alm.initial_tolerance=1e2",
+    "alm.tolerance_update_factor=0.1", "solver.stop_crit=ProjGradUnitNorm",
+    "alm.tolerance=1e-08", "alm.dual_tolerance=1e-08",
+    "solver.radius_factor_rejected=0.35", "solver.radius_factor_acceptable=0.99",
+    "solver.radius_factor_good=10", "solver.ratio_threshold_acceptable=0.3",
+    "solver.ratio_threshold_good=0.5", "dir.hessian_vec_factor=1", "accel.tol_scale=1e-2",
+)
+# new-benchmarks-paper/dodo.py:94-95
+DODO_HANGING_CHAIN_OPTS = ("num_dist=5", "u_dist=-1,1,1")
+
+
+class PantrStats(C.Structure):
+    """pantr_stats_t"""
+    _fields_ = [(k, _dbl) for k in ("eps", "final_gamma", "final_psi", "final_fbe",
+                                    "final_radius", "elapsed_s")] + \
+               [(k, _i32) for k in ("status", "iterations", "cg_iterations", "accepted",
+                                    "rejected", "qub_backtracks", "n_psi", "n_grad_psi",
+                                    "n_psi_grad_psi", "n_grad_L", "n_hess_psi_prod",
+                                    "n_prox_grad_step")]
+
+
+STATS_DTYPE = np.dtype([(k, np.float64) for k in ("eps", "final_gamma", "final_psi", "final_fbe",
+                                                  "final_radius", "elapsed_s")] +
+                       [(k, np.int32) for k in ("status", "iterations", "cg_iterations",
+                                                "accepted", "rejected", "qub_backtracks", "n_psi",
+                                                "n_grad_psi", "n_psi_grad_psi", "n_grad_L",
+                                                "n_hess_psi_prod", "n_prox_grad_step")])
+assert STATS_DTYPE.itemsize == C.sizeof(PantrStats)
+
+# every symbol include/pantr_mi355x.h declares
+EXPORTS = (
+    "pantr_params_create", "pantr_params_destroy", "pantr_params_set", "pantr_params_get",
+    "pantr_batch_create", "pantr_batch_destroy", "pantr_batch_dims", "pantr_batch_get_box_C",
+    "pantr_batch_get_initial_guess", "pantr_batch_get_initial_state", "pantr_batch_set_param",
+    "pantr_batch_get_param", "pantr_batch_solve", "pantr_batch_solve_device",
+    "pantr_batch_last_kernel_ms", "pantr_batch_set_launch_order", "pantr_batch_set_trace",
+    "pantr_batch_get_trace", "pantr_batch_eval_psi", "pantr_batch_eval_psi_grad_psi",
+    "pantr_batch_eval_hess_psi_prod", "pantr_batch_eval_prox_grad_step",
+    "pantr_batch_simulate_dynamics", "pantr_last_error", "pantr_version", "pantr_device_count",
+    "pantr_batch_footprint",
+)
+
+
+class PantrError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile lib/libpantr_mi355x.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", PKG_DIR] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP extension.  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `make -C {PKG_DIR}` (or "
+                              "__graft_entry__.build()); the PANTR solver has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, cp = C.c_void_p, C.c_char_p
+        pd = C.POINTER(_dbl)
+        L.pantr_last_error.restype = cp
+        L.pantr_version.restype = cp
+        L.pantr_params_create.argtypes = [C.POINTER(vp)]
+        L.pantr_params_destroy.argtypes = [vp]
+        L.pantr_params_destroy.restype = None
+        L.pantr_params_set.argtypes = [vp, cp]
+        L.pantr_params_get.argtypes = [vp, cp, pd]
+        L.pantr_batch_create.argtypes = [cp, _i32, _i32, _i32, C.POINTER(vp)]
+        L.pantr_batch_destroy.argtypes = [vp]
+        L.pantr_batch_destroy.restype = None
+        L.pantr_batch_dims.argtypes = [vp] + [C.POINTER(_i32)] * 6
+        L.pantr_batch_get_box_C.argtypes = [vp, vp, vp]
+        L.pantr_batch_get_initial_guess.argtypes = [vp, vp]
+        L.pantr_batch_get_initial_state.argtypes = [vp, vp]
+        L.pantr_batch_set_param.argtypes = [vp, cp]
+        L.pantr_batch_get_param.argtypes = [vp, cp, pd]
+        L.pantr_batch_solve.argtypes = [vp, _i32, vp, vp, vp, vp]
+        L.pantr_batch_solve_device.argtypes = [vp, _i32, vp, vp, vp, vp]
+        L.pantr_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.pantr_batch_set_launch_order.argtypes = [vp, _i32, vp]
+        L.pantr_batch_set_trace.argtypes = [vp, _i32, _i32]
+        L.pantr_batch_get_trace.argtypes = [vp, vp]
+        L.pantr_batch_eval_psi.argtypes = [vp, _i32, vp, vp, vp]
+        L.pantr_batch_eval_psi_grad_psi.argtypes = [vp, _i32, vp, vp, vp, vp]
+        L.pantr_batch_eval_hess_psi_prod.argtypes = [vp, _i32, vp, vp, vp, vp]
+        L.pantr_batch_eval_prox_grad_step.argtypes = [vp, _i32, _dbl, vp, vp, vp, vp, vp]
+        L.pantr_batch_simulate_dynamics.argtypes = [vp, _i32, vp, vp, vp]
+        L.pantr_batch_footprint.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise PantrError(rc, lib().pantr_last_error().decode())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+class PantrParams:
+    """Solver option set without a device (pantr_params_t)."""
+
+    def __init__(self, opts=()):
+        self._h = C.c_void_p()
+        _check(lib().pantr_params_create(C.byref(self._h)))
+        for o in opts:
+            self.set(o)
+
+    def set(self, kv):
+        _check(lib().pantr_params_set(self._h, kv.encode()))
+
+    def get(self, key):
+        v = _dbl()
+        _check(lib().pantr_params_get(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().pantr_params_destroy(self._h)
+            self._h = None
+
+
+class PantrBatch:
+    """A problem (name, horizon) with device resources for up to max_instances solves."""
+
+    def __init__(self, problem="hanging_chain", horizon=60, max_instances=1, device=0, opts=()):
+        self._h = C.c_void_p()
+        _check(lib().pantr_batch_create(problem.encode(), horizon, max_instances, device,
+                                        C.byref(self._h)))
+        d = [_i32() for _ in range(6)]
+        _check(lib().pantr_batch_dims(self._h, *[C.byref(x) for x in d]))
+        self.n, self.m, self.nx, self.nu, self.nc, self.nc_N = [x.value for x in d]
+        self.horizon = horizon
+        self.max_instances = max_instances
+        self.set_params(opts)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pantr_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- options -------------------------------------------------------------------------
+    def set_params(self, opts):
+        for o in opts:
+            _check(lib().pantr_batch_set_param(self._h, o.encode()))
+
+    def get_param(self, key):
+        v = _dbl()
+        _check(lib().pantr_batch_get_param(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    # ---- problem data --------------------------------------------------------------------
+    def box_C(self):
+        lb, ub = np.zeros(self.n), np.zeros(self.n)
+        _check(lib().pantr_batch_get_box_C(self._h, _ptr(lb), _ptr(ub)))
+        return lb, ub
+
+    def initial_guess(self):
+        u = np.zeros(self.n)
+        _check(lib().pantr_batch_get_initial_guess(self._h, _ptr(u)))
+        return u
+
+    def initial_state(self):
+        x = np.zeros(self.nx)
+        _check(lib().pantr_batch_get_initial_state(self._h, _ptr(x)))
+        return x
+
+    def footprint(self):
+        a, b = C.c_int64(), C.c_int64()
+        _check(lib().pantr_batch_footprint(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # ---- hot path ------------------------------------------------------------------------
+    def solve(self, x0, u0):
+        """Solve B instances.  x0: (B, nx), u0: (B, n).  Returns (u, stats recarray)."""
+        x0 = _f64(x0)
+        B = x0.shape[0]
+        x0 = _f64(x0, (B, self.nx))
+        u = np.array(u0, dtype=np.float64, order="C", copy=True)
+        if u.shape != (B, self.n):
+            raise ValueError(f"expected u0 shape {(B, self.n)}, got {u.shape}")
+        stats = np.zeros(B, dtype=STATS_DTYPE)
+        _check(lib().pantr_batch_solve(self._h, B, _ptr(x0), _ptr(u), None, _ptr(stats)))
+        return u, stats
+
+    def solve_device(self, B, d_x0, d_u, d_stats, stream=None):
+        """Device-pointer solve (ints = device addresses), asynchronous on `stream`."""
+        _check(lib().pantr_batch_solve_device(self._h, B, C.c_void_p(d_x0), C.c_void_p(d_u),
+                                              C.c_void_p(d_stats), C.c_void_p(stream or 0)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _check(lib().pantr_batch_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def set_launch_order(self, order):
+        if order is None:
+            _check(lib().pantr_batch_set_launch_order(self._h, 0, None))
+            return
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        _check(lib().pantr_batch_set_launch_order(self._h, len(order), _ptr(order)))
+
+    def set_trace(self, instances, cap):
+        _check(lib().pantr_batch_set_trace(self._h, instances, cap))
+        self._trace_shape = (instances, cap, len(TRACE_COLS))
+
+    def get_trace(self):
+        out = np.zeros(self._trace_shape)
+        _check(lib().pantr_batch_get_trace(self._h, _ptr(out)))
+        return out
+
+    # ---- problem functions ---------------------------------------------------------------
+    def eval_psi(self, x0, u):
+        x0, u = _f64(x0), _f64(u)
+        B = x0.shape[0]
+        psi = np.zeros(B)
+        _check(lib().pantr_batch_eval_psi(self._h, B, _ptr(x0), _ptr(u), _ptr(psi)))
+        return psi
+
+    def eval_psi_grad_psi(self, x0, u):
+        x0, u = _f64(x0), _f64(u)
+        B = x0.shape[0]
+        psi, grad = np.zeros(B), np.zeros((B, self.n))
+        _check(lib().pantr_batch_eval_psi_grad_psi(self._h, B, _ptr(x0), _ptr(u), _ptr(psi),
+                                                   _ptr(grad)))
+        return psi, grad
+
+    def eval_hess_psi_prod(self, x0, u, v):
+        x0, u, v = _f64(x0), _f64(u), _f64(v)
+        B = x0.shape[0]
+        Hv = np.zeros((B, self.n))
+        _check(lib().pantr_batch_eval_hess_psi_prod(self._h, B, _ptr(x0), _ptr(u), _ptr(v), _ptr(Hv)))
+        return Hv
+
+    def eval_prox_grad_step(self, gamma, x, grad):
+        x, grad = _f64(x), _f64(grad)
+        B = x.shape[0]
+        xh, p, s = np.zeros((B, self.n)), np.zeros((B, self.n)), np.zeros((B, 4))
+        _check(lib().pantr_batch_eval_prox_grad_step(self._h, B, gamma, _ptr(x), _ptr(grad),
+                                                     _ptr(xh), _ptr(p), _ptr(s)))
+        return xh, p, s
+
+    def simulate_dynamics(self, x, u):
+        x, u = _f64(x), _f64(u)
+        B = x.shape[0]
+        xn = np.zeros((B, self.nx))
+        _check(lib().pantr_batch_simulate_dynamics(self._h, B, _ptr(x), _ptr(u), _ptr(xn)))
+        return xn
+
+
+def device_count():
+    return lib().pantr_device_count()
+
+
+def version():
+    return lib().pantr_version().decode()
+
+
+def algorithmic_bytes(stats, N, nx, nu, m=0):
+    """trajectory-streaming byte model, summed over the records.
+
+    B_alg = 8 [ n_psi (n + nx + N nx + 3m) + n_grad (2n + nx + 2 N nx + 4m)
+              + n_Hv (3n + nx + 4 N nx + 4m) + n_cg 17 n + n_it 15 n ]
+    with n_grad = #psi_grad_psi + #grad_psi + #grad_L.
+    """
+    n = nu * N
+    s = stats
+    n_psi = s["n_psi"].astype(np.int64).sum()
+    n_grad = (s["n_psi_grad_psi"].astype(np.int64) + s["n_grad_psi"] + s["n_grad_L"]).sum()
+    n_hv = s["n_hess_psi_prod"].astype(np.int64).sum()
+    n_cg = s["cg_iterations"].astype(np.int64).sum()
+    n_it = s["iterations"].astype(np.int64).sum()
+    return 8 * (n_psi * (n + nx + N * nx + 3 * m) + n_grad * (2 * n + nx + 2 * N * nx + 4 * m) +
+                n_hv * (3 * n + nx + 4 * N * nx + 4 * m) + n_cg * 17 * n + n_it * 15 * n)

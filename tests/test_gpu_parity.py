@@ -1,0 +1,126 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Bar: exact equality of fp64 results (the kernels and the oracle follow one arithmetic
+specification), which is stricter than the 1e-10 relative tolerance the
+north star states; RTOL below is that stated tolerance and is what the asserts enforce
+where a comparison is not required to be exact.
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import pantr_amd as pa
+from common import NX, NU, disturbed_state, random_inputs, random_states
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10  # north star: fp64 iterates within 1e-10 relative of the CPU solver
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def rng():
+    return np.random.default_rng(20231003)
+
+
+@pytest.mark.parametrize("N", [1, 2, 7, 21, 22, 60])
+def test_psi_grad_hess_prod_match_oracle(rng, N):
+    B = 5
+    with_batch = pa.PantrBatch("hanging_chain", N, B)
+    x0, u, v = random_states(rng, B), random_inputs(rng, B, N), rng.standard_normal((B, NU * N))
+    psi = with_batch.eval_psi(x0, u)
+    psi2, grad = with_batch.eval_psi_grad_psi(x0, u)
+    Hv = with_batch.eval_hess_psi_prod(x0, u, v)
+    for b in range(B):
+        f_o, g_o = ob.psi_grad(N, x0[b], u[b])
+        Hv_o = ob.hess_prod(N, x0[b], u[b], v[b])
+        assert psi[b] == f_o and psi2[b] == f_o
+        assert rel(grad[b], g_o) <= RTOL and np.array_equal(grad[b], g_o)
+        assert rel(Hv[b], Hv_o) <= RTOL and np.array_equal(Hv[b], Hv_o)
+    with_batch.close()
+
+
+@pytest.mark.parametrize("N", [1, 22, 60])
+def test_prox_grad_step_matches_oracle(rng, N):
+    B = 4
+    batch = pa.PantrBatch("hanging_chain", N, B)
+    x = random_inputs(rng, B, N, -1.5, 1.5)          # some components outside the box
+    g = 30 * rng.standard_normal((B, NU * N))
+    for gamma in (1.0, 1e-3, 0.05):
+        xh, p, s = batch.eval_prox_grad_step(gamma, x, g)
+        for b in range(B):
+            xh_o, p_o, pTp, gTp = ob.prox_grad_step(N, gamma, x[b], g[b])
+            assert np.array_equal(xh[b], xh_o) and np.array_equal(p[b], p_o)
+            assert s[b, 0] == pTp and s[b, 1] == gTp
+            lb, ub = -1.0, 1.0
+            assert s[b, 2] == np.max(np.abs(np.clip(-g[b], lb - x[b], ub - x[b])))
+            xfw = x[b] - gamma * g[b]
+            assert s[b, 3] == np.sum((lb < xfw) & (xfw < ub))
+    batch.close()
+
+
+def test_simulate_dynamics_matches_oracle(rng):
+    B = 9
+    batch = pa.PantrBatch("hanging_chain", 3, B)
+    x, u = random_states(rng, B), rng.uniform(-1, 1, (B, NU))
+    xn = batch.simulate_dynamics(x, u)
+    for b in range(B):
+        assert np.array_equal(xn[b], ob.simulate(x[b], u[b]))
+    batch.close()
+
+
+def _solve_both(N, x0s, u0s, opts, trace_cap=400):
+    B = len(x0s)
+    batch = pa.PantrBatch("hanging_chain", N, B, opts=opts)
+    batch.set_trace(B, trace_cap)
+    u, st = batch.solve(x0s, u0s)
+    tr = batch.get_trace()
+    batch.close()
+    return u, st, tr
+
+
+@pytest.mark.parametrize("N", [5, 22, 60])
+def test_solve_iterates_match_oracle(rng, N):
+    """Whole solves: same iterates (per-iteration trace), same counters, same solution."""
+    B = 4
+    x0s = np.vstack([disturbed_state()[None, :], random_states(rng, B - 1, 0.02)])
+    u0s = np.vstack([np.zeros((1, NU * N)), random_inputs(rng, B - 1, N, -0.3, 0.3)])
+    u, st, tr = _solve_both(N, x0s, u0s, pa.DODO_PANTR_OPTS)
+    prm = ob.dodo_params()
+    for b in range(B):
+        u_o, st_o, tr_o = ob.solve(N, x0s[b], u0s[b], prm, trace_cap=400)
+        assert st["status"][b] == st_o["status"] == 1
+        for key in ("iterations", "cg_iterations", "accepted", "rejected", "qub_backtracks",
+                    "n_psi", "n_grad_psi", "n_psi_grad_psi", "n_grad_L", "n_hess_psi_prod",
+                    "n_prox_grad_step"):
+            assert st[key][b] == st_o[key], key
+        k = st_o["iterations"]
+        assert len(tr_o) == k
+        a, o = tr[b, :k], tr_o
+        fin = np.isfinite(o)
+        assert np.array_equal(np.isfinite(a), fin)
+        assert rel(a[fin], o[fin]) <= RTOL and np.array_equal(a[fin], o[fin])
+        assert rel(u[b], u_o) <= RTOL and np.array_equal(u[b], u_o)
+        assert st["eps"][b] == st_o["eps"] and st["eps"][b] <= 1e-8
+        assert st["final_psi"][b] == st_o["final_psi"]
+
+
+def test_solve_status_codes(rng):
+    """max_iter exhaustion gives MaxIter (negative runtime in the reference, mpc-driver.cpp:219-221)."""
+    N = 22
+    x0s, u0s = disturbed_state()[None, :], np.zeros((1, NU * N))
+    u, st, _ = _solve_both(N, x0s, u0s, pa.DODO_PANTR_OPTS + ("solver.max_iter=3",))
+    prm = ob.dodo_params(max_iter=3)
+    u_o, st_o, _ = ob.solve(N, x0s[0], u0s[0], prm)
+    assert st["status"][0] == st_o["status"] == 3 and st["iterations"][0] == 3
+    assert np.array_equal(u[0], u_o)  # always_overwrite_results in the m = 0 ALM shell
+
+
+def test_unsupported_option_fails_loudly():
+    batch = pa.PantrBatch("hanging_chain", 5, 1, opts=("dir.finite_diff=true",))
+    with pytest.raises(pa.PantrError):
+        batch.solve(np.zeros((1, NX)), np.zeros((1, 15)))
+    batch.close()
