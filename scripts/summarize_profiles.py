@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Copies the rocprofv3 summaries of scripts/profile.sh from gpurun_out/prof into profiles/
+(tracked) and writes profiles/<tag>_summary.json with per-launch numbers for the solve kernel.
+
+Units/corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB;
+on gfx950 FETCH_SIZE counts 64 B per 128-B read request, so it is doubled before use
+(an upper bound for this kernel's 8-B-per-lane row reads, which are uncalibrated).
+"""
+import csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+KERNEL = "pantr_solve_kernel"
+
+summary = {"tag": tag, "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+           "kernel": "pantr::pantr_solve_kernel<pantr::ChainModel>"}
+stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+for r in csv.DictReader(open(stats)):
+    if KERNEL in r["Name"]:
+        summary["kernel_trace"] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                                   "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
+                                   "percentage": float(r["Percentage"])}
+trace = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))[0]
+for r in csv.DictReader(open(trace)):
+    if KERNEL in r["Kernel_Name"]:
+        summary["dispatch"] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size",
+                                                  "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count",
+                                                  "SGPR_Count") if k in r}
+        break
+pmc = {}
+for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    files = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    agg = {}
+    for r in csv.DictReader(open(files[0])):
+        if KERNEL in r["Kernel_Name"]:
+            agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        pmc[k] = sum(v) / len(v)
+summary["pmc_per_launch"] = pmc
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    summary["hbm_traffic_bytes_per_launch"] = {
+        "read_corrected": 2 * pmc["FETCH_SIZE"] * 1024, "write": pmc["WRITE_SIZE"] * 1024,
+        "total": (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024,
+        "note": "KiB -> bytes; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request)"}
+json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
