@@ -74,6 +74,7 @@ def main():
 
     import torch
     import pantr_amd as pa
+    from pantr_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -120,10 +121,7 @@ def main():
         kernel_ms.append(batch.last_kernel_ms())  # HIP events on the launch stream
     barrier()
     elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, dev)  # MAX over ranks (identity at N = 1)
 
     stats = np.frombuffer(stats_t.cpu().numpy().tobytes(), dtype=pa.STATS_DTYPE)
     converged = int(np.sum(stats["status"] == 1))

@@ -1,0 +1,51 @@
+"""Worker of test_two_rank_sharded_batch_gloo: one rank of a 2-rank sharded batch on CPU.
+
+The device solve is replaced by the oracle here (a test may use it); what is exercised is the
+product's sharding code: the deterministic LPT partition, the row gather and the MAX reduction.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "pantr-cdc2023-experiments_amd"))
+import oracle_binding as ob  # noqa: E402
+from pantr_amd import sharding  # noqa: E402
+
+
+def main():
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    N, B = 6, 7
+    rng = np.random.default_rng(5)
+    x = ob.initial_state()
+    for _ in range(5):
+        x = ob.simulate(x, (-1.0, 1.0, 1.0))
+    x0 = x[None, :] + 0.02 * rng.standard_normal((B, x.size))
+    u0 = rng.uniform(-0.2, 0.2, (B, 3 * N))
+    u0[::2] = 0.0                                   # "cold" instances
+    costs = np.where(np.all(u0 == 0, axis=1), 2.0, 1.0)
+    idx = sharding.shard_indices(B, rank, world, costs)
+    t = time.perf_counter()
+    us, _ = ob.solve_batch(N, x0[idx], u0[idx]) if len(idx) else (np.zeros((0, 3 * N)), [])
+    elapsed = time.perf_counter() - t
+    gathered = sharding.gather_rows(us, idx, B)
+    tmax = sharding.max_over_ranks(elapsed)
+    times = [None] * world
+    dist.all_gather_object(times, elapsed)
+    idxs = [None] * world
+    dist.all_gather_object(idxs, idx)
+    if rank == 0:
+        serial, _ = ob.solve_batch(N, x0, u0)
+        np.savez(sys.argv[1], gathered=gathered, serial=serial, tmax=tmax, t0=times[0], t1=times[1],
+                 idx0=idxs[0], idx1=idxs[1], world=world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+"""CPU tests of the host logic: C-ABI surface, option parser, error behaviour, sharding.
+
+No compute call is made here (there is no GPU): the library must load, export every symbol
+include/pantr_mi355x.h declares, and refuse to solve without a device.
+"""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import pantr_amd as pa
+from pantr_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "pantr_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pantr_[a-z_A-Z0-9]+)\s*\(", hdr))
+    assert declared == set(pa.EXPORTS)
+    L = pa.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+    assert "gfx950" in pa.version()
+
+
+def test_stats_struct_layout():
+    hdr = open(os.path.join(ROOT, "include", "pantr_mi355x.h")).read()
+    body = re.search(r"typedef struct pantr_stats \{(.*?)\} pantr_stats_t;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            names += [x.strip() for x in decl.split(None, 1)[1].split(",")]
+    assert tuple(names) == pa.STATS_DTYPE.names
+    assert pa.STATS_DTYPE.itemsize == 6 * 8 + 12 * 4
+
+
+def test_driver_defaults_and_dodo_options():
+    """mpc-driver.cpp:51-53,109-111 defaults, then dodo.py:12-33 overrides."""
+    p = pa.PantrParams()
+    assert p.get("solver.max_iter") == 50000
+    assert p.get("solver.stop_crit") == 6          # FPRNorm
+    assert p.get("alm.max_iter") == 200 and p.get("alm.tolerance") == 1e-8
+    assert p.get("solver.radius_factor_good") == 2.5 and p.get("dir.hessian_vec_factor") == 0.5
+    assert np.isnan(p.get("solver.initial_radius"))
+    for o in pa.DODO_PANTR_OPTS:
+        p.set(o)
+    assert p.get("solver.stop_crit") == 4          # ProjGradUnitNorm
+    assert p.get("alm.max_time") == 30.0 and p.get("alm.max_iter") == 300
+    assert p.get("solver.radius_factor_good") == 10 and p.get("solver.ratio_threshold_good") == 0.5
+    assert p.get("accel.tol_scale") == 1e-2 and p.get("dir.hessian_vec_factor") == 1
+    assert p.get("alm.initial_penalty") == 1e4 and p.get("alm.penalty_update_factor") == 5
+
+
+def test_option_grammar():
+    p = pa.PantrParams()
+    p.set("solver.max_iter=250")                   # dodo.py:98-100
+    assert p.get("solver.max_iter") == 250
+    p.set("alm.max_time=500ms")
+    assert p.get("alm.max_time") == 0.5
+    p.set("solver.max_time=2min")
+    assert p.get("solver.max_time") == 120
+    p.set("solver.disable_acceleration=true")
+    assert p.get("solver.disable_acceleration") == 1
+    p.set("solver.Lipschitz.L_0=3.5")
+    assert p.get("solver.Lipschitz.L_0") == 3.5
+    # options addressed to other objects are ignored, as set_params(obj, prefix, opts) does
+    for foreign in ("num_dist=5", "u_dist=-1,1,1", "warm=true", "method=pantr",
+                    "results_name=mpc-x", "ipopt.tol=1e-8"):
+        p.set(foreign)
+    for bad in ("solver.no_such_key=1", "solver.max_iter=abc", "solver.stop_crit=Nope",
+                "alm.max_time=30parsecs", "accel.tol_scale", "dir.finite_diff=maybe"):
+        with pytest.raises(pa.PantrError) as e:
+            p.set(bad)
+        assert e.value.code == -1
+    with pytest.raises(pa.PantrError):
+        p.get("solver.no_such_key")
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product refuses to create a problem: there is no CPU path."""
+    if pa.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(pa.PantrError) as e:
+        pa.PantrBatch("hanging_chain", 60, 1)
+    assert e.value.code == -3 and "no CPU path" in str(e.value)
+
+
+def test_create_argument_errors():
+    with pytest.raises(pa.PantrError) as e:
+        pa.PantrBatch("no_such_problem", 10, 1)
+    assert e.value.code == -2
+    with pytest.raises(pa.PantrError) as e:
+        pa.PantrBatch("hanging_chain", 0, 1)
+    assert e.value.code == -1
+
+
+def test_product_does_not_import_the_oracle():
+    """Nothing under the package may reference oracle/ (SURVEY.md section 8c rule)."""
+    pkg = os.path.join(ROOT, "pantr-cdc2023-experiments_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_binding" not in text and "liboracle" not in text, f
+                assert not re.search(r'#include\s+"[^"]*oracle', text), f
+
+
+def test_algorithmic_bytes_formula():
+    """SURVEY.md section 8(d) worked numbers for hanging_chain N=60."""
+    st = np.zeros(1, dtype=pa.STATS_DTYPE)
+    st["n_psi"] = 1
+    assert pa.algorithmic_bytes(st, 60, 57, 3) == 8 * (180 + 57 + 60 * 57)          # 29.3 KB
+    st["n_psi"], st["n_grad_L"] = 0, 1
+    assert pa.algorithmic_bytes(st, 60, 57, 3) == 8 * (360 + 57 + 2 * 60 * 57)      # 58.1 KB
+    st["n_grad_L"], st["n_hess_psi_prod"] = 0, 1
+    assert pa.algorithmic_bytes(st, 60, 57, 3) == 8 * (540 + 57 + 4 * 60 * 57)      # 114.2 KB
+    st["n_hess_psi_prod"], st["cg_iterations"], st["iterations"] = 0, 1, 1
+    assert pa.algorithmic_bytes(st, 60, 57, 3) == 8 * (17 * 180 + 15 * 180)
+
+
+def test_lpt_partition_and_launch_order():
+    costs = np.array([5, 1, 1, 1, 4, 4, 1, 3.0])
+    shards = sharding.lpt_partition(costs, 2)
+    assert sorted(np.concatenate(shards).tolist()) == list(range(8))
+    loads = [costs[s].sum() for s in shards]
+    assert max(loads) - min(loads) <= 1.0
+    assert sharding.launch_order(costs).tolist() == [0, 4, 5, 7, 1, 2, 3, 6]
+    assert sharding.shard_indices(7, 1, 3).tolist() == [1, 4]
+    # empty shards are legal (more ranks than instances)
+    assert [len(s) for s in sharding.lpt_partition([1.0], 3)] == [1, 0, 0]
+
+
+def test_two_rank_sharded_batch_gloo(tmp_path):
+    """world_size 2 over gloo: shard, solve (oracle stands in for the device), gather, MAX."""
+    script = os.path.join(ROOT, "tests", "gloo_shard_worker.py")
+    port = 29500 + (os.getpid() % 2000)
+    out = tmp_path / "result.npz"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script, str(out)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = np.load(out)
+    assert np.array_equal(d["gathered"], d["serial"])      # sharded == unsharded, bit for bit
+    assert d["tmax"] >= max(d["t0"], d["t1"]) - 1e-12 and d["world"] == 2
+    assert sorted(np.concatenate([d["idx0"], d["idx1"]]).tolist()) == list(range(len(d["serial"])))

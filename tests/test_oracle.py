@@ -1,0 +1,242 @@
+"""CPU tests of the oracle: derivative checks, independent cross-checks, golden fixtures.
+
+The reference holds no golden vectors for the PANTR path (parity
+unpinned), so the oracle is pinned by (i) mathematical certificates that do not depend on
+the algorithm under test, (ii) SciPy's independent Steihaug-Toint implementation and an
+independently written numpy chain model, (iii) this project's own committed fixtures.
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy.optimize._trustregion_ncg import CGSteihaugSubproblem
+
+import oracle_binding as ob
+from common import NX, NU, disturbed_state, random_inputs, random_states
+
+
+# ---- independent numpy transcription of the model (hanging_chain.py:24-80 read as text) ------
+def numpy_fc(s, u, D=0.1, L=0.033, m=0.03, g=9.81):
+    x = s[:30].reshape(10, 3)
+    v = s[30:].reshape(9, 3)
+    dist = np.vstack([x[0:1], x[1:] - x[:-1]])
+    norm = np.sqrt((dist * dist).sum(axis=1))
+    F = dist * (D * (1 - L / norm))[:, None]
+    acc = (F[1:] - F[:-1]) / m + np.array([0, 0, -g])
+    return np.concatenate([v.ravel(), u, acc.ravel()])
+
+
+def numpy_rk4(s, u, Ts=0.1):
+    k1 = numpy_fc(s, u)
+    k2 = numpy_fc(s + Ts * k1 / 2, u)
+    k3 = numpy_fc(s + Ts * k2 / 2, u)
+    k4 = numpy_fc(s + Ts * k3, u)
+    return s + (Ts / 6) * (k1 + 2 * k2 + 2 * k3 + k4)
+
+
+def numpy_cost(N, x0, u, alpha=25, beta=1, gamma=0.01):
+    s, f = x0.copy(), 0.0
+    e = np.array([1.0, 0, 0])
+    for k in range(N):
+        uk = u[3 * k:3 * k + 3]
+        f += alpha * np.sum((s[27:30] - e) ** 2) + beta * np.sum(s[30:] ** 2) + gamma * np.sum(uk ** 2)
+        s = numpy_rk4(s, uk)
+    return f + alpha * np.sum((s[27:30] - e) ** 2) + beta * np.sum(s[30:] ** 2)
+
+
+@pytest.fixture(scope="module")
+def rng():
+    return np.random.default_rng(42)
+
+
+def test_initial_state_and_box():
+    x0 = ob.initial_state()
+    assert x0.shape == (NX,)
+    assert np.allclose(x0[0:30:3], np.arange(1, 11) / 10) and np.count_nonzero(x0) == 10
+    lb, ub = np.zeros(3), np.zeros(3)
+    ob.lib().oracle_chain_box(lb, ub)
+    assert np.all(lb == -1) and np.all(ub == 1)
+
+
+def test_dynamics_match_independent_numpy_model(rng):
+    for _ in range(5):
+        s = random_states(rng, 1)[0]
+        u = rng.uniform(-1, 1, 3)
+        assert np.allclose(ob.fc(s, u), numpy_fc(s, u), rtol=1e-13, atol=1e-13)
+        assert np.allclose(ob.simulate(s, u), numpy_rk4(s, u), rtol=1e-13, atol=1e-13)
+
+
+def test_rk4_has_order_four():
+    """Halving the step of the oracle's integrator cuts the error ~16x against a fine reference."""
+    s, u = disturbed_state(), np.array([0.3, -0.2, 0.1])
+
+    def integrate(n_sub):
+        x, h = s.copy(), 0.1 / n_sub
+        for _ in range(n_sub):
+            k1 = numpy_fc(x, u); k2 = numpy_fc(x + h * k1 / 2, u)
+            k3 = numpy_fc(x + h * k2 / 2, u); k4 = numpy_fc(x + h * k3, u)
+            x = x + (h / 6) * (k1 + 2 * k2 + 2 * k3 + k4)
+        return x
+    ref = integrate(64)
+    e1 = np.abs(ob.simulate(s, u) - ref).max()
+    e2 = np.abs(integrate(2) - ref).max()
+    assert 10 < e1 / e2 < 24
+
+
+@pytest.mark.parametrize("N", [1, 6, 25])
+def test_cost_and_gradient(rng, N):
+    x0, u = random_states(rng, 1)[0], random_inputs(rng, 1, N)[0]
+    f, g = ob.psi_grad(N, x0, u)
+    assert ob.psi(N, x0, u) == f
+    assert abs(f - numpy_cost(N, x0, u)) <= 1e-12 * abs(f)
+    h = 1e-6
+    gfd = np.array([(ob.psi(N, x0, u + h * e) - ob.psi(N, x0, u - h * e)) / (2 * h)
+                    for e in np.eye(NU * N)])
+    assert np.abs(g - gfd).max() <= 1e-6 * np.abs(g).max()
+
+
+@pytest.mark.parametrize("N", [3, 20])
+def test_hessian_vector_product(rng, N):
+    x0, u = random_states(rng, 1)[0], random_inputs(rng, 1, N)[0]
+    v, w = rng.standard_normal(NU * N), rng.standard_normal(NU * N)
+    Hv, Hw = ob.hess_prod(N, x0, u, v), ob.hess_prod(N, x0, u, w)
+    h = 1e-6
+    fd = (ob.psi_grad(N, x0, u + h * v)[1] - ob.psi_grad(N, x0, u - h * v)[1]) / (2 * h)
+    assert np.abs(Hv - fd).max() <= 1e-6 * np.abs(Hv).max()
+    assert abs(w @ Hv - v @ Hw) <= 1e-12 * abs(w @ Hv)          # symmetry
+    assert np.array_equal(ob.hess_prod(N, x0, u, np.zeros(NU * N)), np.zeros(NU * N))
+    assert np.allclose(ob.hess_prod(N, x0, u, 2.5 * v), 2.5 * Hv, rtol=1e-13)  # linearity
+
+
+def test_prox_grad_step_is_box_projection(rng):
+    N = 9
+    x, g = random_inputs(rng, 1, N, -1.5, 1.5)[0], 20 * rng.standard_normal(NU * N)
+    for gamma in (1.0, 0.01):
+        xh, p, pTp, gTp = ob.prox_grad_step(N, gamma, x, g)
+        assert np.allclose(xh, x + np.clip(-gamma * g, -1 - x, 1 - x), rtol=0, atol=0)
+        assert np.array_equal(xh, x + p)
+        assert np.isclose(pTp, p @ p, rtol=1e-14) and np.isclose(gTp, p @ g, rtol=1e-13)
+
+
+def test_wave_dot_order(rng):
+    """oracle_dot = per-lane strided partial sums + 64-lane butterfly (the wavefront order)."""
+    for n in (1, 63, 64, 65, 180, 360):
+        a, b = rng.standard_normal(n), rng.standard_normal(n)
+        part = np.zeros(64)
+        for l in range(64):
+            acc = 0.0
+            for i in range(l, n, 64):
+                acc = acc + a[i] * b[i]
+            part[l] = acc
+        for m in (32, 16, 8, 4, 2, 1):
+            part = part + part[np.arange(64) ^ m]
+        assert ob.lib().oracle_dot(a, b, n) == part[0]
+
+
+# ---- Steihaug-Toint CG against SciPy's independent implementation ----------------------------
+def scipy_steihaug(H, g, radius, tol_scale):
+    sub = CGSteihaugSubproblem(np.zeros(len(g)), lambda x: 0.0, lambda x: g, lambda x: H,
+                               lambda x, p: H @ p)
+    # SciPy hard-codes tolerance = min(0.5, sqrt(|g|)) |g|; reproduce the oracle's scale by
+    # scaling the problem is not possible, so compare in the regimes where the tolerance does
+    # not decide the exit (boundary exits), and where it does only for tol_scale = SciPy's.
+    return sub.solve(radius)
+
+
+@pytest.mark.parametrize("case", ["interior", "boundary", "negative_curvature"])
+def test_steihaug_matches_scipy(rng, case):
+    n = 24
+    A = rng.standard_normal((n, n))
+    if case == "negative_curvature":
+        H = A + A.T
+        radius = 1.5
+    else:
+        H = A @ A.T + 0.5 * np.eye(n)
+        radius = 100.0 if case == "interior" else 0.05
+    g = rng.standard_normal(n)
+    p_sp, hits = scipy_steihaug(H, g, radius, None)
+    # SciPy: tolerance = min(0.5, sqrt(gnorm)) * gnorm -> tol_scale 0.5 when sqrt(gnorm) >= 0.5...
+    gn = np.linalg.norm(g)
+    scale = min(0.5, np.sqrt(gn)) / min(1.0, np.sqrt(gn))
+    p_or, m_or, its = ob.steihaug_dense(H, g, radius, tol_scale=scale)
+    assert np.allclose(p_or, p_sp, rtol=1e-9, atol=1e-12)
+    assert np.isclose(m_or, g @ p_or + 0.5 * p_or @ H @ p_or, rtol=1e-12)
+    assert hits == (case != "interior")
+    if case != "interior":
+        assert np.isclose(np.linalg.norm(p_or), radius, rtol=1e-12)
+
+
+# ---- whole solves: optimality certificates (results.hpp:258-286 semantics) --------------------
+@pytest.mark.parametrize("N,warm", [(10, False), (30, False), (30, True)])
+def test_solve_reaches_kkt_point(N, warm):
+    x0 = disturbed_state()
+    u0 = np.zeros(NU * N)
+    u, st, tr = ob.solve(N, x0, u0, trace_cap=500)
+    assert ob.STATUS[st["status"]] == "Converged" and st["eps"] <= 1e-8
+    if warm:  # re-solve from the shifted solution: fewer iterations
+        x1 = ob.simulate(x0, u[:3])
+        u1, st1, _ = ob.solve(N, x1, np.concatenate([u[3:], u[-3:]]))
+        assert st1["status"] == 1 and st1["iterations"] < st["iterations"]
+        u, x0 = u1, x1
+    assert np.all(np.abs(u) <= 1.0)                                   # box feasibility
+    _, g = ob.psi_grad(N, x0, u)
+    stationarity = np.abs(np.clip(u - g, -1, 1) - u).max()            # || Pi_C(x - grad L) - x ||_inf
+    assert stationarity <= 1e-8
+    assert len(tr) == st["iterations"] and st["accepted"] + st["rejected"] == st["iterations"]
+    assert np.all(np.diff(tr[:, 7]) <= 1e-9 * np.abs(tr[:-1, 7]))     # FBE decreases monotonically
+
+
+def test_mpc_loop_semantics():
+    """mpc-driver.cpp:123-210: disturbance, untimed first solve, shift-by-nu warm start, simulate."""
+    N, num_sim = 8, 5
+    states, inputs, guesses, stats = ob.mpc(N, num_sim, warm=True)
+    x = ob.initial_state()
+    for _ in range(5):
+        x = ob.simulate(x, (-1.0, 1.0, 1.0))
+    u, _, _ = ob.solve(N, x, np.zeros(NU * N))
+    x = ob.simulate(x, u[:NU])
+    for i in range(num_sim):
+        assert np.array_equal(states[i], x)
+        u[:-NU] = u[NU:].copy()
+        assert np.array_equal(guesses[i], u)
+        u, st, _ = ob.solve(N, x, u)
+        assert np.array_equal(inputs[i], u) and st["status"] == stats[i]["status"] == 1
+        x = ob.simulate(x, u[:NU])
+    assert np.array_equal(states[num_sim], x)
+    _, _, g_cold, _ = ob.mpc(N, 2, warm=False)
+    assert np.all(g_cold == 0)
+
+
+# ---- committed fixtures ----------------------------------------------------------------------
+def test_golden_problem_functions(golden_dir):
+    d = np.load(os.path.join(golden_dir, "problem_functions_N7.npz"))
+    N = int(d["N"])
+    for i in range(len(d["u"])):
+        f, g = ob.psi_grad(N, d["x0"], d["u"][i])
+        assert f == d["psi"][i] and np.array_equal(g, d["grad"][i])
+        assert np.array_equal(ob.hess_prod(N, d["x0"], d["u"][i], d["v"][i]), d["Hv"][i])
+
+
+@pytest.mark.parametrize("N", [10, 20])
+def test_golden_closed_loop_cold(golden_dir, N):
+    d = np.load(os.path.join(golden_dir, f"mpc_hanging_chain_N{N}_cold8.npz"))
+    states, inputs, guesses, stats = ob.mpc(N, 8, warm=False)
+    assert np.array_equal(states[:-1], d["x0"]) and np.array_equal(inputs, d["sol"])
+    assert [s["iterations"] for s in stats] == list(d["iters"])
+    assert [s["n_hess_psi_prod"] for s in stats] == list(d["hv"])
+
+
+def test_golden_replay_fixture_is_a_pure_function_of_its_inputs(golden_dir):
+    """Replay batching: each recorded step re-solved in isolation reproduces the closed loop."""
+    d = np.load(os.path.join(golden_dir, "mpc_hanging_chain_N60_warm300.npz"))
+    assert d["x0"].shape == (300, NX) and d["guess"].shape == (300, 180)
+    assert np.all(d["status"] == 1) and np.all(d["eps"] <= 1e-8)
+    idx = [0, 137, 299]
+    us, stats = ob.solve_batch(60, d["x0"][idx], d["guess"][idx], nthreads=3)
+    for j, i in enumerate(idx):
+        assert np.array_equal(us[j], d["sol"][i]) and stats[j]["iterations"] == d["iters"][i]
+    # the warm start of step i+1 is the solution of step i shifted by nu
+    assert np.array_equal(d["guess"][1:, :-NU], d["sol"][:-1, NU:])
+    assert np.array_equal(d["guess"][1:, -NU:], d["sol"][:-1, -NU:])
+    # and the next state is the plant step of the first input block
+    assert np.array_equal(d["x0"][1], ob.simulate(d["x0"][0], d["sol"][0, :NU]))
