@@ -1,0 +1,384 @@
+// The slice of alpaqa's C++ surface that drivers/mpc-driver.cpp's "pantr" branch uses,
+// re-implemented over the C ABI of include/pantr_mi355x.h.  Same names, argument meaning and
+// error behaviour, so a driver written against alpaqa's types reads the same against these:
+//
+//   alpaqa::TypeErasedProblem<config_t>   get_n/get_m/get_box_C/eval_*   casadi-dll-wrapper.hpp:18, mpc-driver.cpp:131,140
+//   typename InnerSolver::Params, ::Direction, Direction::DirectionParams / AcceleratorParams
+//   InnerSolver{params, Direction{{.accelerator = ..., .direction = ...}}}  mpc-driver.cpp:50-69
+//   ALMSolver{alm_param, inner};  stats = solver(problem, u, y);  stats.status, stats.elapsed_time
+//                                                                          mpc-driver.cpp:104-115,217-221
+//   solver.get_name()                                                      mpc-driver.cpp:295-296
+//   alpaqa::params::set_params(x, "prefix", opts)                          mpc-driver.cpp:54
+//
+// Vectors are std::vector<double> / std::span<double> (no Eigen in this pipeline).  Errors
+// of the C ABI are turned back into the exception types the reference throws.
+#pragma once
+#include "../../include/pantr_mi355x.h"
+#include "params.hpp"
+
+#include <chrono>
+#include <memory>
+#include <ostream>
+#include <span>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <vector>
+
+namespace alpaqa {
+
+using real_t   = double;
+using length_t = std::ptrdiff_t;
+using index_t  = std::ptrdiff_t;
+using vec      = std::vector<real_t>;
+using rvec     = std::span<real_t>;
+using crvec    = std::span<const real_t>;
+struct DefaultConfig {};
+
+using pantr::host::ALMParams;
+using pantr::host::NewtonTRDirectionParams;
+using pantr::host::PANOCStopCrit;
+using pantr::host::PANTRParams;
+using pantr::host::SolverStatus;
+using pantr::host::SteihaugCGParams;
+using pantr::host::enum_name;
+
+/// Map a C-ABI error code to the exception the reference would have thrown.
+inline void check(int rc) {
+    if (rc == PANTR_OK)
+        return;
+    std::string msg = pantr_last_error();
+    switch (rc) {
+    case PANTR_ERR_INVALID_ARGUMENT: throw std::invalid_argument(msg);
+    case PANTR_ERR_OUT_OF_RANGE: throw std::out_of_range(msg);
+    default: throw std::runtime_error(msg);
+    }
+}
+
+struct Box {
+    vec lowerbound, upperbound;
+};
+
+/// alpaqa::EvalCounter fields the reference writes (drivers/results.hpp:63-87).
+struct EvalCounter {
+    unsigned proj_diff_g = 0, proj_multipliers = 0, prox_grad_step = 0, f = 0, grad_f = 0,
+             f_grad_f = 0, f_g = 0, grad_f_grad_g_prod = 0, g = 0, grad_g_prod = 0, grad_gi = 0,
+             grad_L = 0, hess_L_prod = 0, hess_L = 0, hess_psi_prod = 0, hess_psi = 0, psi = 0,
+             grad_psi = 0, psi_grad_psi = 0;
+    void reset() { *this = {}; }
+    void add(const pantr_stats_t &s) {
+        prox_grad_step += s.n_prox_grad_step;
+        grad_L += s.n_grad_L;
+        hess_psi_prod += s.n_hess_psi_prod;
+        psi += s.n_psi;
+        grad_psi += s.n_grad_psi;
+        psi_grad_psi += s.n_psi_grad_psi;
+    }
+};
+
+/// The problem as the solver sees it.  Owns a pantr_batch (device code + workspace) and the
+/// problem parameter (initial state) the driver writes through (mpc-driver.cpp:126).
+template <class Conf = DefaultConfig>
+class TypeErasedProblem {
+  public:
+    TypeErasedProblem(std::string_view name, length_t horizon, int max_instances = 1, int device = 0) {
+        pantr_batch_t *h = nullptr;
+        check(pantr_batch_create(std::string(name).c_str(), static_cast<int32_t>(horizon), max_instances,
+                                 device, &h));
+        handle.reset(h, pantr_batch_destroy);
+        int32_t n_, m_, nx_, nu_, nc_, ncN_;
+        check(pantr_batch_dims(h, &n_, &m_, &nx_, &nu_, &nc_, &ncN_));
+        n = n_; m = m_; nx = nx_; nu = nu_; nc = nc_; nc_N = ncN_;
+        param.resize(nx);
+        check(pantr_batch_get_initial_state(h, param.data()));
+        evaluations = std::make_shared<EvalCounter>();
+    }
+    length_t get_n() const { return n; }
+    length_t get_m() const { return m; }
+    Box get_box_C() const {
+        Box b{vec(n), vec(n)};
+        check(pantr_batch_get_box_C(handle.get(), b.lowerbound.data(), b.upperbound.data()));
+        return b;
+    }
+    vec get_initial_guess() const {
+        vec u(n);
+        check(pantr_batch_get_initial_guess(handle.get(), u.data()));
+        return u;
+    }
+    // problem functions (single instance, evaluated on the device)
+    real_t eval_psi(crvec x) const {
+        real_t v;
+        check(pantr_batch_eval_psi(handle.get(), 1, param.data(), x.data(), &v));
+        return v;
+    }
+    real_t eval_psi_grad_psi(crvec x, rvec grad) const {
+        real_t v;
+        check(pantr_batch_eval_psi_grad_psi(handle.get(), 1, param.data(), x.data(), &v, grad.data()));
+        return v;
+    }
+    void eval_grad_L(crvec x, crvec /*y*/, rvec grad, rvec /*work*/) const {
+        real_t v;
+        check(pantr_batch_eval_psi_grad_psi(handle.get(), 1, param.data(), x.data(), &v, grad.data()));
+    }
+    void eval_hess_psi_prod(crvec x, crvec v, rvec Hv) const {
+        check(pantr_batch_eval_hess_psi_prod(handle.get(), 1, param.data(), x.data(), v.data(), Hv.data()));
+    }
+    real_t eval_prox_grad_step(real_t gamma, crvec x, crvec grad, rvec xh, rvec p) const {
+        real_t s[4];
+        check(pantr_batch_eval_prox_grad_step(handle.get(), 1, gamma, x.data(), grad.data(), xh.data(),
+                                              p.data(), s));
+        return 0; // h(xhat) of a box
+    }
+    vec simulate(crvec x, crvec u) const {
+        vec xn(nx);
+        check(pantr_batch_simulate_dynamics(handle.get(), 1, x.data(), u.data(), xn.data()));
+        return xn;
+    }
+
+    pantr_batch_t *get() const { return handle.get(); }
+    length_t n = 0, m = 0, nx = 0, nu = 0, nc = 0, nc_N = 0;
+    vec param; ///< initial state: CasADiProblem::param in the reference (casadi-dll-wrapper.cpp:64)
+    std::shared_ptr<EvalCounter> evaluations;
+
+  private:
+    std::shared_ptr<pantr_batch_t> handle;
+};
+
+template <class Conf = DefaultConfig>
+struct NewtonTRDirection {
+    using DirectionParams   = NewtonTRDirectionParams;
+    using AcceleratorParams = SteihaugCGParams;
+    struct Params {
+        AcceleratorParams accelerator{};
+        DirectionParams direction{};
+    } params;
+    NewtonTRDirection() = default;
+    NewtonTRDirection(const Params &p) : params(p) {}
+    std::string get_name() const { return "NewtonTRDirection"; }
+};
+
+template <class DirectionT>
+class PANTRSolver {
+  public:
+    using Params    = PANTRParams;
+    using Direction = DirectionT;
+    PANTRSolver(const Params &p, Direction d = {}) : params(p), direction(std::move(d)) {}
+    std::string get_name() const { return "PANTRSolver<" + direction.get_name() + ">"; }
+    Params params;
+    Direction direction;
+};
+
+template <class InnerSolverT>
+class ALMSolver {
+  public:
+    using Params      = ALMParams;
+    using InnerSolver = InnerSolverT;
+    struct Stats {
+        SolverStatus status = SolverStatus::Busy;
+        std::chrono::nanoseconds elapsed_time{};
+        unsigned outer_iterations = 0;
+        real_t eps = 0, delta = 0;
+        pantr_stats_t inner{};
+    };
+    ALMSolver(const Params &p, InnerSolver inner) : params(p), inner_solver(std::move(inner)) {}
+    std::string get_name() const { return "ALMSolver<" + inner_solver.get_name() + ">"; }
+
+    /// stats = solver(problem, x, y)   (mpc-driver.cpp:217)
+    template <class Conf>
+    Stats operator()(TypeErasedProblem<Conf> &problem, rvec x, rvec y) {
+        if (static_cast<length_t>(x.size()) != problem.get_n())
+            throw std::invalid_argument("ALMSolver: x has the wrong dimension");
+        if (static_cast<length_t>(y.size()) != problem.get_m())
+            throw std::invalid_argument("ALMSolver: y has the wrong dimension");
+        push_options(problem.get());
+        pantr_stats_t s{};
+        check(pantr_batch_solve(problem.get(), 1, problem.param.data(), x.data(), y.data(), &s));
+        problem.evaluations->add(s);
+        return convert(s);
+    }
+
+    /// Batched form: B independent instances (x0s[B][nx], xs[B][n] in/out).
+    template <class Conf>
+    std::vector<Stats> solve_batch(TypeErasedProblem<Conf> &problem, length_t B, crvec x0s, rvec xs) {
+        push_options(problem.get());
+        std::vector<pantr_stats_t> s(B);
+        check(pantr_batch_solve(problem.get(), static_cast<int32_t>(B), x0s.data(), xs.data(), nullptr,
+                                s.data()));
+        std::vector<Stats> out;
+        for (auto &e : s) {
+            problem.evaluations->add(e);
+            out.push_back(convert(e));
+        }
+        return out;
+    }
+
+    Params params;
+    InnerSolver inner_solver;
+
+  private:
+    static Stats convert(const pantr_stats_t &s) {
+        Stats r;
+        r.status           = static_cast<SolverStatus>(s.status);
+        r.elapsed_time     = std::chrono::nanoseconds(static_cast<long long>(s.elapsed_s * 1e9));
+        r.outer_iterations = 1;
+        r.eps              = s.eps;
+        r.inner            = s;
+        return r;
+    }
+    /// Hand the typed parameter structs to the handle through the string interface of the ABI.
+    void push_options(pantr_batch_t *b) const {
+        pantr::host::SolverOptions o;
+        o.solver = inner_solver.params;
+        o.dir    = inner_solver.direction.params.direction;
+        o.accel  = inner_solver.direction.params.accelerator;
+        o.alm    = params;
+        auto set = [&](const char *key, double v) {
+            char buf[128];
+            std::snprintf(buf, sizeof buf, "%s=%.17g", key, v);
+            check(pantr_batch_set_param(b, buf));
+        };
+        auto setb = [&](const char *key, bool v) {
+            check(pantr_batch_set_param(b, (std::string(key) + (v ? "=true" : "=false")).c_str()));
+        };
+        const auto &s = o.solver;
+        set("solver.Lipschitz.L_0", s.Lipschitz.L_0);
+        set("solver.Lipschitz.epsilon", s.Lipschitz.epsilon);
+        set("solver.Lipschitz.delta", s.Lipschitz.delta);
+        set("solver.Lipschitz.Lgamma_factor", s.Lipschitz.Lgamma_factor);
+        set("solver.max_iter", s.max_iter);
+        set("solver.max_time", s.max_time);
+        set("solver.L_min", s.L_min);
+        set("solver.L_max", s.L_max);
+        check(pantr_batch_set_param(b, (std::string("solver.stop_crit=") + enum_name(s.stop_crit)).c_str()));
+        set("solver.max_no_progress", s.max_no_progress);
+        set("solver.quadratic_upperbound_tolerance_factor", s.quadratic_upperbound_tolerance_factor);
+        set("solver.TR_tolerance_factor", s.TR_tolerance_factor);
+        set("solver.ratio_threshold_acceptable", s.ratio_threshold_acceptable);
+        set("solver.ratio_threshold_good", s.ratio_threshold_good);
+        set("solver.radius_factor_rejected", s.radius_factor_rejected);
+        set("solver.radius_factor_acceptable", s.radius_factor_acceptable);
+        set("solver.radius_factor_good", s.radius_factor_good);
+        set("solver.initial_radius", s.initial_radius);
+        set("solver.min_radius", s.min_radius);
+        setb("solver.compute_ratio_using_new_stepsize", s.compute_ratio_using_new_stepsize);
+        setb("solver.disable_acceleration", s.disable_acceleration);
+        setb("solver.ratio_approx_fbe_quadratic_model", s.ratio_approx_fbe_quadratic_model);
+        set("dir.hessian_vec_factor", o.dir.hessian_vec_factor);
+        setb("dir.finite_diff", o.dir.finite_diff);
+        set("accel.tol_scale", o.accel.tol_scale);
+        set("accel.tol_scale_root", o.accel.tol_scale_root);
+        set("accel.tol_max", o.accel.tol_max);
+        set("accel.max_iter_factor", o.accel.max_iter_factor);
+        set("alm.tolerance", o.alm.tolerance);
+        set("alm.dual_tolerance", o.alm.dual_tolerance);
+        set("alm.max_iter", o.alm.max_iter);
+        set("alm.max_time", o.alm.max_time);
+        set("alm.initial_penalty", o.alm.initial_penalty);
+        set("alm.penalty_update_factor", o.alm.penalty_update_factor);
+        set("alm.initial_tolerance", o.alm.initial_tolerance);
+        set("alm.tolerance_update_factor", o.alm.tolerance_update_factor);
+    }
+};
+
+namespace params {
+
+namespace detail {
+/// Apply the options addressed to `prefix` to the member of SolverOptions named `canonical`
+/// (the caller may choose any prefix, mpc-driver.cpp:54 uses "solver", :61 "dir", ...).
+template <class T>
+void set_struct(T &p, T pantr::host::SolverOptions::*member, std::string_view canonical,
+                std::string_view prefix, std::span<const std::string_view> opts) {
+    pantr::host::SolverOptions o;
+    o.*member = p;
+    const std::string pfx = std::string(prefix) + ".";
+    for (std::string_view kv : opts) {
+        if (kv.substr(0, pfx.size()) != pfx)
+            continue; // addressed to another object
+        std::string rewritten = std::string(canonical) + "." + std::string(kv.substr(pfx.size()));
+        std::string err;
+        if (pantr::host::set_option(o, rewritten, err) != pantr::host::SetResult::Ok)
+            throw std::invalid_argument(err);
+    }
+    p = o.*member;
+}
+} // namespace detail
+
+/// set_params(struct, "prefix", opts): applies the "prefix.key=value" options to the struct.
+inline void set_params(PANTRParams &p, std::string_view prefix, std::span<const std::string_view> opts) {
+    detail::set_struct(p, &pantr::host::SolverOptions::solver, "solver", prefix, opts);
+}
+inline void set_params(NewtonTRDirectionParams &p, std::string_view prefix,
+                       std::span<const std::string_view> opts) {
+    detail::set_struct(p, &pantr::host::SolverOptions::dir, "dir", prefix, opts);
+}
+inline void set_params(SteihaugCGParams &p, std::string_view prefix, std::span<const std::string_view> opts) {
+    detail::set_struct(p, &pantr::host::SolverOptions::accel, "accel", prefix, opts);
+}
+inline void set_params(ALMParams &p, std::string_view prefix, std::span<const std::string_view> opts) {
+    detail::set_struct(p, &pantr::host::SolverOptions::alm, "alm", prefix, opts);
+}
+
+/// Scalars, strings and vectors the driver itself reads ("num_sim=60", "u_dist=-1,1,1", ...):
+/// the key is the whole prefix (mpc-driver.cpp:144-157,316,360).
+inline std::string_view find_value(std::string_view key, std::span<const std::string_view> opts, bool &found) {
+    found = false;
+    std::string_view val;
+    for (auto kv : opts) {
+        auto eq = kv.find('=');
+        if (eq != std::string_view::npos && kv.substr(0, eq) == key) {
+            val   = kv.substr(eq + 1);
+            found = true; // last one wins (dodo.py appends overrides, :101-105)
+        }
+    }
+    return val;
+}
+inline void set_params(length_t &v, std::string_view key, std::span<const std::string_view> opts) {
+    bool found;
+    auto s = find_value(key, opts, found);
+    if (!found)
+        return;
+    int32_t i;
+    if (!pantr::host::parse_int(s, i))
+        throw std::invalid_argument("Invalid value '" + std::string(s) + "' for '" + std::string(key) + "'");
+    v = i;
+}
+inline void set_params(bool &v, std::string_view key, std::span<const std::string_view> opts) {
+    bool found;
+    auto s = find_value(key, opts, found);
+    if (found && !pantr::host::parse_bool(s, v))
+        throw std::invalid_argument("Invalid value '" + std::string(s) + "' for '" + std::string(key) + "'");
+}
+inline void set_params(std::string &v, std::string_view key, std::span<const std::string_view> opts) {
+    bool found;
+    auto s = find_value(key, opts, found);
+    if (found)
+        v = std::string(s);
+}
+inline void set_params(std::string_view &v, std::string_view key, std::span<const std::string_view> opts) {
+    bool found;
+    auto s = find_value(key, opts, found);
+    if (found)
+        v = s;
+}
+/// Comma-separated vector; must keep its size (mpc-driver.cpp:144-146 checks it afterwards).
+inline void set_params(vec &v, std::string_view key, std::span<const std::string_view> opts) {
+    bool found;
+    auto s = find_value(key, opts, found);
+    if (!found)
+        return;
+    vec out;
+    while (true) {
+        auto comma = s.find(',');
+        double d;
+        if (!pantr::host::parse_double(s.substr(0, comma), d))
+            throw std::invalid_argument("Invalid value in '" + std::string(key) + "'");
+        out.push_back(d);
+        if (comma == std::string_view::npos)
+            break;
+        s = s.substr(comma + 1);
+    }
+    v = out;
+}
+
+} // namespace params
+} // namespace alpaqa

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <ostream>
 #include <string>
 #include <string_view>
 
@@ -45,6 +46,9 @@ inline const char *enum_name(SolverStatus s) {
     int i = static_cast<int>(s);
     return i >= 0 && i < 8 ? names[i] : "<unknown>";
 }
+
+inline std::ostream &operator<<(std::ostream &os, SolverStatus s) { return os << enum_name(s); }
+inline std::ostream &operator<<(std::ostream &os, PANOCStopCrit s) { return os << enum_name(s); }
 
 struct LipschitzEstimateParams {
     double L_0 = 0, epsilon = 1e-6, delta = 1e-12, Lgamma_factor = 0.95;

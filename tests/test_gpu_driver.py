@@ -1,0 +1,66 @@
+"""GPU test of the C++ host side: the benchmark-mpc-driver CLI clone and its results file.
+
+The results module is loaded the way new-benchmarks-paper/benchmark_util.py:4-9 loads it and
+compared with the oracle's closed loop (drivers/mpc-driver.cpp:123-210).
+"""
+import importlib.util
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import pantr_amd as pa
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "pantr-cdc2023-experiments_amd", "bin", "benchmark-mpc-driver")
+
+
+def load_results(path, name):
+    spec = importlib.util.spec_from_file_location("", os.path.join(path, f"{name}.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.results
+
+
+@pytest.mark.parametrize("warm", [True, False])
+def test_driver_closed_loop_matches_oracle(tmp_path, warm):
+    N, num_sim = 20, 12
+    name = f"mpc-hanging_chain-{N},{num_sim}-{'warm' if warm else 'cold'}-pantr"
+    opts = list(pa.DODO_PANTR_OPTS) + list(pa.DODO_HANGING_CHAIN_OPTS)
+    cmd = [DRIVER, "hanging_chain", str(N), "ss2p", "method=pantr", f"num_sim={num_sim}",
+           f"results_name={name}", f"warm={'true' if warm else 'false'}", "replay=true"] + opts
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stderr.count("Converged") == num_sim + 1          # status line per solve (:218)
+    assert "identical to the closed loop" in r.stdout
+    res = load_results(str(tmp_path), name)
+    states, inputs, guesses, stats = ob.mpc(N, num_sim, warm)
+    assert res["states"].shape == (57, num_sim + 1) and res["inputs"].shape == (3 * N, num_sim)
+    assert np.array_equal(res["states"].T, states) and np.array_equal(res["inputs"].T, inputs)
+    assert np.all(res["runtimes"] > 0) and len(res["runtimes"]) == num_sim
+    ev = res["evaluations"]
+    assert ev["hess_ψ_prod"] == sum(s["n_hess_psi_prod"] for s in stats)
+    assert ev["ψ"] == sum(s["n_psi"] for s in stats)
+    assert ev["ψ_grad_ψ"] == sum(s["n_psi_grad_psi"] for s in stats)
+    assert ev["grad_L"] == sum(s["n_grad_L"] for s in stats)
+    assert res["problem"] == "hanging_chain" and res["nvar"] == 3 * N and res["ncon"] == 0
+    assert res["horizon"] == N and res["formulation"] == "ss2p" and res["second_order"] is False
+    assert res["solver"].startswith("ALMSolver<PANTRSolver<") and "method=pantr" in res["opts"]
+
+
+def test_driver_errors(tmp_path):
+    r = subprocess.run([DRIVER, "hanging_chain", "10", "ss2p", "method=nope"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "Unknown solver 'nope'" in r.stderr
+    r = subprocess.run([DRIVER, "no_such_problem", "10", "ss2p", "method=pantr"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "unknown problem" in r.stderr
+    r = subprocess.run([DRIVER, "hanging_chain", "10", "ss2p", "method=pantr", "solver.bogus=1"],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode != 0 and "Invalid key" in r.stderr
+    r = subprocess.run([DRIVER, "hanging_chain", "10", "ss2p", "method=pantr", "u_dist=1,2"],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode != 0 and "Invalid u_dist size" in r.stderr
