@@ -79,15 +79,18 @@ inline Dual operator*(double c, Dual a) { return {c * a.v, c * a.t}; }
 inline Dual operator+(Dual a, double c) { return {a.v + c, a.t}; }
 inline Dual operator-(Dual a, double c) { return {a.v - c, a.t}; }
 inline Dual operator-(double c, Dual a) { return {c - a.v, 0.0 - a.t}; }
-/// a / b: tangent ((a.t*b.v) - (a.v*b.t)) / (b.v*b.v)
-inline Dual operator/(Dual a, Dual b) {
-    return {a.v / b.v, ((a.t * b.v) - (a.v * b.t)) / (b.v * b.v)};
+/// c / b = q with tangent b.t * k, k = (-q) / b.v  (every division acts on primal values only,
+/// so a kernel may record q and k once and replay tangents without dividing)
+inline Dual operator/(double c, Dual b) {
+    double q = c / b.v;
+    double k = (-q) / b.v;
+    return {q, b.t * k};
 }
-/// c / b: tangent (-(c*b.t)) / (b.v*b.v)
-inline Dual operator/(double c, Dual b) { return {c / b.v, (-(c * b.t)) / (b.v * b.v)}; }
+/// sqrt(a) = r with tangent a.t * h, h = 0.5 / r
 inline Dual sqrt(Dual a) {
     double r = std::sqrt(a.v);
-    return {r, (a.t * 0.5) / r};
+    double h = 0.5 / r;
+    return {r, a.t * h};
 }
 inline double sqrt(double a) { return std::sqrt(a); }
 inline double value(double a) { return a; }
@@ -267,6 +270,237 @@ struct Chain {
         }
     }
 
+    // ---- tape: record primal substage quantities once, replay tangents without dividing -----
+    // (the kernels' Hessian-vector path; must equal the dual-number sweep bit for bit)
+    struct TapeSub {
+        double d[NP][DIM], c[NP], h[NP], kq[NP], n2[NP], r[NP]; // springs
+        double lF[NP][DIM], dt[NP], w[NP], kw[NP], t[NP];       // adjoint
+    };
+    struct TapeStage {
+        TapeSub sub[4];
+    };
+    struct SpringsTan {
+        double d[NP][DIM], n2[NP], r[NP], c[NP];
+    };
+
+    static void tape_springs(const Springs<double> &sp, TapeSub &ts) {
+        for (int p = 0; p < NP; ++p) {
+            for (int c = 0; c < DIM; ++c)
+                ts.d[p][c] = sp.d[p][c];
+            double q = Lspring / sp.r[p];
+            ts.c[p]  = sp.c[p];
+            ts.h[p]  = 0.5 / sp.r[p];
+            ts.kq[p] = (-q) / sp.r[p];
+            ts.n2[p] = sp.n2[p];
+            ts.r[p]  = sp.r[p];
+        }
+    }
+
+    /// fc_adj on doubles that also fills the adjoint part of the tape.
+    static void fc_adj_record(const Springs<double> &sp, const double *kbar, double *abar, TapeSub &ts) {
+        tape_springs(sp, ts);
+        double ld[NP][DIM];
+        for (int p = 0; p < NP; ++p) {
+            double lF[DIM], pr[DIM];
+            for (int c = 0; c < DIM; ++c) {
+                if (p == 0)
+                    lF[c] = inv_m * (0.0 - kbar[VOFF + DIM * p + c]);
+                else if (p == NP - 1)
+                    lF[c] = inv_m * (kbar[VOFF + DIM * (p - 1) + c] - 0.0);
+                else
+                    lF[c] = inv_m * (kbar[VOFF + DIM * (p - 1) + c] - kbar[VOFF + DIM * p + c]);
+                pr[c]       = sp.d[p][c] * lF[c];
+                ts.lF[p][c] = lF[c];
+            }
+            double dt  = (pr[0] + pr[1]) + pr[2];
+            double n2r = sp.n2[p] * sp.r[p];
+            double w   = DL / n2r;
+            double t   = dt * w;
+            ts.dt[p] = dt;
+            ts.w[p]  = w;
+            ts.kw[p] = (-w) / n2r;
+            ts.t[p]  = t;
+            for (int c = 0; c < DIM; ++c)
+                ld[p][c] = (sp.c[p] * lF[c]) + (t * sp.d[p][c]);
+        }
+        for (int p = 0; p < NP; ++p)
+            for (int c = 0; c < DIM; ++c)
+                abar[DIM * p + c] = p == NP - 1 ? ld[p][c] : ld[p][c] - ld[p + 1][c];
+        for (int l = 0; l < DIM * NB; ++l)
+            abar[VOFF + l] = kbar[l];
+    }
+
+    /// rk4_adj on doubles, recording the stage's tape.
+    static void rk4_adj_record(const double *s, const double *u, const double *mu, double *sbar,
+                               double *ubar, TapeStage &tp) {
+        double k[nx], w[nx];
+        Springs<double> sp1, sp2, sp3, sp4;
+        fc(s, u, k, sp1);
+        for (int l = 0; l < nx; ++l)
+            w[l] = s[l] + 0.5 * (Ts * k[l]);
+        fc(w, u, k, sp2);
+        for (int l = 0; l < nx; ++l)
+            w[l] = s[l] + 0.5 * (Ts * k[l]);
+        fc(w, u, k, sp3);
+        for (int l = 0; l < nx; ++l)
+            w[l] = s[l] + Ts * k[l];
+        springs(w, sp4);
+        double kb1[nx], kb2[nx], kb3[nx], kb4[nx], a[nx];
+        for (int l = 0; l < nx; ++l) {
+            double sg = c6 * mu[l];
+            kb1[l] = sg;
+            kb2[l] = 2.0 * sg;
+            kb3[l] = 2.0 * sg;
+            kb4[l] = sg;
+            sbar[l] = mu[l];
+        }
+        fc_adj_record(sp4, kb4, a, tp.sub[3]);
+        for (int l = 0; l < nx; ++l) {
+            sbar[l] = sbar[l] + a[l];
+            kb3[l]  = kb3[l] + Ts * a[l];
+        }
+        fc_adj_record(sp3, kb3, a, tp.sub[2]);
+        for (int l = 0; l < nx; ++l) {
+            sbar[l] = sbar[l] + a[l];
+            kb2[l]  = kb2[l] + 0.5 * (Ts * a[l]);
+        }
+        fc_adj_record(sp2, kb2, a, tp.sub[1]);
+        for (int l = 0; l < nx; ++l) {
+            sbar[l] = sbar[l] + a[l];
+            kb1[l]  = kb1[l] + 0.5 * (Ts * a[l]);
+        }
+        fc_adj_record(sp1, kb1, a, tp.sub[0]);
+        for (int l = 0; l < nx; ++l)
+            sbar[l] = sbar[l] + a[l];
+        for (int c = 0; c < DIM; ++c) {
+            int l   = DIM * NB + c;
+            ubar[c] = ((kb4[l] + kb3[l]) + kb2[l]) + kb1[l];
+        }
+    }
+
+    static void springs_tan(const TapeSub &g, const double *s_t, SpringsTan &st) {
+        for (int p = 0; p < NP; ++p) {
+            double sq[DIM];
+            for (int c = 0; c < DIM; ++c) {
+                st.d[p][c] = p == 0 ? s_t[c] : s_t[DIM * p + c] - s_t[DIM * (p - 1) + c];
+                sq[c]      = (g.d[p][c] * st.d[p][c]) + (st.d[p][c] * g.d[p][c]);
+            }
+            st.n2[p]    = (sq[0] + sq[1]) + sq[2];
+            st.r[p]     = st.n2[p] * g.h[p];
+            double q_t  = st.r[p] * g.kq[p];
+            double om_t = 0.0 - q_t;
+            st.c[p]     = Dspring * om_t;
+        }
+    }
+    static void fc_tan(const TapeSub &g, const double *s_t, const double *u_t, double *ds_t, SpringsTan &st) {
+        springs_tan(g, s_t, st);
+        double F[NP][DIM];
+        for (int p = 0; p < NP; ++p)
+            for (int c = 0; c < DIM; ++c)
+                F[p][c] = (g.d[p][c] * st.c[p]) + (st.d[p][c] * g.c[p]);
+        for (int l = 0; l < DIM * NB; ++l)
+            ds_t[l] = s_t[VOFF + l];
+        for (int c = 0; c < DIM; ++c)
+            ds_t[DIM * NB + c] = u_t[c];
+        for (int i = 0; i < NB; ++i)
+            for (int c = 0; c < DIM; ++c)
+                ds_t[VOFF + DIM * i + c] = inv_m * (F[i + 1][c] - F[i][c]);
+    }
+    static void fc_adj_tan(const TapeSub &g, const SpringsTan &st, const double *kbar_t, double *abar_t) {
+        double ld[NP][DIM];
+        for (int p = 0; p < NP; ++p) {
+            double lF[DIM], pr[DIM];
+            for (int c = 0; c < DIM; ++c) {
+                double A = p == 0 ? 0.0 : kbar_t[VOFF + DIM * (p - 1) + c];
+                double B = p == NP - 1 ? 0.0 : kbar_t[VOFF + DIM * p + c];
+                lF[c]    = inv_m * (A - B);
+                pr[c]    = (g.d[p][c] * lF[c]) + (st.d[p][c] * g.lF[p][c]);
+            }
+            double dt  = (pr[0] + pr[1]) + pr[2];
+            double n2r = (g.n2[p] * st.r[p]) + (st.n2[p] * g.r[p]);
+            double w   = n2r * g.kw[p];
+            double t   = (g.dt[p] * w) + (dt * g.w[p]);
+            for (int c = 0; c < DIM; ++c)
+                ld[p][c] = ((g.c[p] * lF[c]) + (st.c[p] * g.lF[p][c])) +
+                           ((g.t[p] * st.d[p][c]) + (t * g.d[p][c]));
+        }
+        for (int p = 0; p < NP; ++p)
+            for (int c = 0; c < DIM; ++c)
+                abar_t[DIM * p + c] = p == NP - 1 ? ld[p][c] : ld[p][c] - ld[p + 1][c];
+        for (int l = 0; l < DIM * NB; ++l)
+            abar_t[VOFF + l] = kbar_t[l];
+    }
+    static void rk4_tan(const TapeStage &tp, const double *s_t, const double *u_t, double *xn_t) {
+        double k1[nx], k2[nx], k3[nx], k4[nx], w[nx];
+        SpringsTan st;
+        fc_tan(tp.sub[0], s_t, u_t, k1, st);
+        for (int l = 0; l < nx; ++l)
+            w[l] = s_t[l] + 0.5 * (Ts * k1[l]);
+        fc_tan(tp.sub[1], w, u_t, k2, st);
+        for (int l = 0; l < nx; ++l)
+            w[l] = s_t[l] + 0.5 * (Ts * k2[l]);
+        fc_tan(tp.sub[2], w, u_t, k3, st);
+        for (int l = 0; l < nx; ++l)
+            w[l] = s_t[l] + Ts * k3[l];
+        fc_tan(tp.sub[3], w, u_t, k4, st);
+        for (int l = 0; l < nx; ++l)
+            xn_t[l] = s_t[l] + c6 * (((k1[l] + 2.0 * k2[l]) + 2.0 * k3[l]) + k4[l]);
+    }
+    static void rk4_adj_tan(const TapeStage &tp, const double *s_t, const double *u_t, const double *mu_t,
+                            double *sbar_t, double *ubar_t) {
+        double k[nx], w[nx];
+        SpringsTan st1, st2, st3, st4;
+        fc_tan(tp.sub[0], s_t, u_t, k, st1);
+        for (int l = 0; l < nx; ++l)
+            w[l] = s_t[l] + 0.5 * (Ts * k[l]);
+        fc_tan(tp.sub[1], w, u_t, k, st2);
+        for (int l = 0; l < nx; ++l)
+            w[l] = s_t[l] + 0.5 * (Ts * k[l]);
+        fc_tan(tp.sub[2], w, u_t, k, st3);
+        for (int l = 0; l < nx; ++l)
+            w[l] = s_t[l] + Ts * k[l];
+        springs_tan(tp.sub[3], w, st4);
+        double kb1[nx], kb2[nx], kb3[nx], kb4[nx], a[nx];
+        for (int l = 0; l < nx; ++l) {
+            double sg = c6 * mu_t[l];
+            kb1[l] = sg;
+            kb2[l] = 2.0 * sg;
+            kb3[l] = 2.0 * sg;
+            kb4[l] = sg;
+            sbar_t[l] = mu_t[l];
+        }
+        fc_adj_tan(tp.sub[3], st4, kb4, a);
+        for (int l = 0; l < nx; ++l) {
+            sbar_t[l] = sbar_t[l] + a[l];
+            kb3[l]    = kb3[l] + Ts * a[l];
+        }
+        fc_adj_tan(tp.sub[2], st3, kb3, a);
+        for (int l = 0; l < nx; ++l) {
+            sbar_t[l] = sbar_t[l] + a[l];
+            kb2[l]    = kb2[l] + 0.5 * (Ts * a[l]);
+        }
+        fc_adj_tan(tp.sub[1], st2, kb2, a);
+        for (int l = 0; l < nx; ++l) {
+            sbar_t[l] = sbar_t[l] + a[l];
+            kb1[l]    = kb1[l] + 0.5 * (Ts * a[l]);
+        }
+        fc_adj_tan(tp.sub[0], st1, kb1, a);
+        for (int l = 0; l < nx; ++l)
+            sbar_t[l] = sbar_t[l] + a[l];
+        for (int c = 0; c < DIM; ++c) {
+            int l     = DIM * NB + c;
+            ubar_t[c] = ((kb4[l] + kb3[l]) + kb2[l]) + kb1[l];
+        }
+    }
+    static void cost_grad_x_add_tan(const double *s_t, double *lam_t) {
+        for (int c = 0; c < DIM; ++c) {
+            int l    = DIM * NB + c;
+            lam_t[l] = lam_t[l] + c2a * s_t[l];
+        }
+        for (int l = VOFF; l < nx; ++l)
+            lam_t[l] = lam_t[l] + c2b * s_t[l];
+    }
+
     /// Per-lane cost contribution of one stage (hanging_chain.cpp:127-131):
     /// lanes 27..29: alpha (x_end - ref)^2 then + gamma u^2; lanes 30..56: beta v^2.
     template <class T>
@@ -394,6 +628,39 @@ struct SingleShooting {
                 Hv[nu * k + c] = (ubar[c] + Model::c2g * ud[c]).t;
             std::copy(sbar, sbar + nx, lam);
             Model::cost_grad_x_add(sk, lam);
+        }
+    }
+
+    /// The kernels' Hessian-vector path: record the tape at u (one gradient sweep), replay
+    /// tangents over it.  Must equal eval_hess_psi_prod bit for bit.
+    void eval_hess_psi_prod_tape(const double *u, const double *v, double *Hv) const {
+        std::vector<double> X((N + 1) * nx), grad(n());
+        eval_f_impl(u, X.data());
+        std::vector<typename Model::TapeStage> tape(N);
+        double lam[nx] = {}, sbar[nx], ubar[nu];
+        Model::cost_grad_x_add(X.data() + N * nx, lam);
+        for (int k = N - 1; k >= 0; --k) {
+            const double *s = X.data() + k * nx;
+            Model::rk4_adj_record(s, u + nu * k, lam, sbar, ubar, tape[k]);
+            std::copy(sbar, sbar + nx, lam);
+            Model::cost_grad_x_add(s, lam);
+        }
+        std::vector<double> Xt((N + 1) * nx);
+        double s_t[nx] = {}, xn_t[nx];
+        for (int k = 0; k < N; ++k) {
+            std::copy(s_t, s_t + nx, Xt.data() + k * nx);
+            Model::rk4_tan(tape[k], s_t, v + nu * k, xn_t);
+            std::copy(xn_t, xn_t + nx, s_t);
+        }
+        double lam_t[nx] = {}, sbar_t[nx], ubar_t[nu];
+        Model::cost_grad_x_add_tan(s_t, lam_t);
+        for (int k = N - 1; k >= 0; --k) {
+            const double *sk_t = Xt.data() + k * nx;
+            Model::rk4_adj_tan(tape[k], sk_t, v + nu * k, lam_t, sbar_t, ubar_t);
+            for (int c = 0; c < nu; ++c)
+                Hv[nu * k + c] = ubar_t[c] + Model::c2g * v[nu * k + c];
+            std::copy(sbar_t, sbar_t + nx, lam_t);
+            Model::cost_grad_x_add_tan(sk_t, lam_t);
         }
     }
 

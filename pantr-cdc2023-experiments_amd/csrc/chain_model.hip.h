@@ -91,22 +91,182 @@ struct ChainModel {
         return select(L.l < U_LANE, vel, select(L.isE, uc, select(L.isV, a, zero)));
     }
 
+    /// Intermediates of the f_c adjoint that the tape path records.
+    template <class T>
+    struct AdjAux {
+        T lF, dt, n2r, w, t;
+    };
+
     /// Adjoint of f_c: kbar = adjoint of ds, returns adjoint of s (adjoint of u = kbar on 27..29).
     template <class T>
-    __device__ static __forceinline__ T fc_adj(const Lane &L, const Springs<T> &sp, T kbar) {
+    __device__ static __forceinline__ T fc_adj(const Lane &L, const Springs<T> &sp, T kbar, AdjAux<T> &ax) {
         const T zero = make_const<T>(0.0);
-        T A  = select(L.isX && !L.first, lane_read(kbar, L.l + (VOFF - DIM)), zero);
-        T B  = select(L.isX && !L.last, lane_read(kbar, L.l + VOFF), zero);
-        T lF = inv_m * (A - B);
-        T pr = sp.d * lF;
-        T dt = (lane_read(pr, L.tri) + lane_read(pr, L.tri + 1)) + lane_read(pr, L.tri + 2);
-        T w  = DL / (sp.n2 * sp.r);
-        T t  = dt * w;
-        T ld = (sp.c * lF) + (t * sp.d);
-        T ldn = lane_read(ld, L.l + DIM);
-        T ax  = select(L.last, ld, ld - ldn);
-        T av  = lane_read(kbar, L.l - VOFF);
-        return select(L.isX, ax, select(L.isV, av, zero));
+        T A   = select(L.isX && !L.first, lane_read(kbar, L.l + (VOFF - DIM)), zero);
+        T B   = select(L.isX && !L.last, lane_read(kbar, L.l + VOFF), zero);
+        ax.lF = inv_m * (A - B);
+        T pr  = sp.d * ax.lF;
+        ax.dt = (lane_read(pr, L.tri) + lane_read(pr, L.tri + 1)) + lane_read(pr, L.tri + 2);
+        ax.n2r = sp.n2 * sp.r;
+        ax.w   = DL / ax.n2r;
+        ax.t   = ax.dt * ax.w;
+        T ld   = (sp.c * ax.lF) + (ax.t * sp.d);
+        T ldn  = lane_read(ld, L.l + DIM);
+        T axx  = select(L.last, ld, ld - ldn);
+        T av   = lane_read(kbar, L.l - VOFF);
+        return select(L.isX, axx, select(L.isV, av, zero));
+    }
+
+    // ---- the tape: primal quantities of one RK4 substage, recorded once per PANTR iteration ----
+    // Three groups of four doubles per lane (lanes 0..31; only the 30 position lanes matter):
+    //   G0 = {d, c, h, kq}      d = dist_vect, c = D(1 - L/r), h = 0.5/r, kq = (-(L/r))/r
+    //   G1 = {n2, r, lF, dt}    squared length, length, adjoint force, d.lF
+    //   G2 = {w, kw, t, -}      w = DL/(n2 r), kw = (-w)/(n2 r), t = dt w
+    // Row layout in HBM: tape[((k*4 + j)*3 + g)*32 + lane] as double4 (32 B per lane, 1 KiB per
+    // group row, one coalesced access per wavefront).
+    static constexpr int TAPE_GROUPS      = 3;
+    static constexpr int TAPE_LANES       = 32;
+    static constexpr int TAPE_D4_PER_STAGE = 4 * TAPE_GROUPS * TAPE_LANES; // double4 elements
+
+    struct TapeFwd { // what the tangent forward sweep needs of one substage
+        double d, c, h, kq;
+    };
+    struct TapeRev { // what the tangent adjoint sweep needs of one substage
+        double d, c, h, kq, n2, r, lF, dt, w, kw, t;
+    };
+    struct SpringsTan {
+        double d, n2, r, c; // tangents of the spring quantities
+    };
+
+    __device__ static __forceinline__ void tape_store(const Lane &L, double4 *stage, int j,
+                                                      const Springs<double> &sp, const AdjAux<double> &ax) {
+        if (L.l < TAPE_LANES) {
+            double q  = Lspring / sp.r; // the same quotient springs() forms
+            double h  = 0.5 / sp.r;
+            double kq = (-q) / sp.r;
+            double kw = (-ax.w) / ax.n2r;
+            double4 *p = stage + (j * TAPE_GROUPS) * TAPE_LANES + L.l;
+            p[0]              = make_double4(sp.d, sp.c, h, kq);
+            p[TAPE_LANES]     = make_double4(sp.n2, sp.r, ax.lF, ax.dt);
+            p[2 * TAPE_LANES] = make_double4(ax.w, kw, ax.t, 0.0);
+        }
+    }
+    __device__ static __forceinline__ void tape_load_fwd(const Lane &L, const double4 *stage, TapeFwd (&g)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double4 a = make_double4(0, 0, 0, 0);
+            if (L.l < TAPE_LANES)
+                a = stage[(j * TAPE_GROUPS) * TAPE_LANES + L.l];
+            g[j] = {a.x, a.y, a.z, a.w};
+        }
+    }
+    __device__ static __forceinline__ void tape_load_rev(const Lane &L, const double4 *stage, TapeRev (&g)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double4 a = make_double4(0, 0, 0, 0), b = a, c = a;
+            if (L.l < TAPE_LANES) {
+                const double4 *p = stage + (j * TAPE_GROUPS) * TAPE_LANES + L.l;
+                a = p[0];
+                b = p[TAPE_LANES];
+                c = p[2 * TAPE_LANES];
+            }
+            g[j] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z};
+        }
+    }
+
+    /// Tangent of springs(): the .t parts of the dual evaluation, primal values from the tape.
+    template <class G>
+    __device__ static __forceinline__ void springs_tan(const Lane &L, const G &g, double s_t, SpringsTan &st) {
+        double sprev = lane_read(s_t, L.l - DIM);
+        st.d         = L.first ? s_t : s_t - sprev;
+        double sq    = (g.d * st.d) + (st.d * g.d);
+        st.n2        = (lane_read(sq, L.tri) + lane_read(sq, L.tri + 1)) + lane_read(sq, L.tri + 2);
+        st.r         = st.n2 * g.h;
+        double q_t   = st.r * g.kq;
+        double om_t  = 0.0 - q_t;
+        st.c         = Dspring * om_t;
+    }
+
+    /// Tangent of f_c.
+    template <class G>
+    __device__ static __forceinline__ double fc_tan(const Lane &L, const G &g, double s_t, double uc_t,
+                                                    SpringsTan &st) {
+        springs_tan(L, g, s_t, st);
+        double F   = (g.d * st.c) + (st.d * g.c);
+        double Fhi = lane_read(F, L.l - (VOFF - DIM));
+        double Flo = lane_read(F, L.l - VOFF);
+        double a   = inv_m * (Fhi - Flo);
+        double vel = lane_read(s_t, L.l + VOFF);
+        return L.l < U_LANE ? vel : (L.isE ? uc_t : (L.isV ? a : 0.0));
+    }
+
+    /// Tangent of the f_c adjoint.
+    __device__ static __forceinline__ double fc_adj_tan(const Lane &L, const TapeRev &g, const SpringsTan &st,
+                                                        double kbar_t) {
+        // cross-lane reads run with every lane active (a masked-off source lane reads as 0),
+        // so they are hoisted out of the selects
+        double Ar  = lane_read(kbar_t, L.l + (VOFF - DIM));
+        double Br  = lane_read(kbar_t, L.l + VOFF);
+        double A   = L.first ? 0.0 : Ar;
+        double B   = L.last ? 0.0 : Br;
+        double lF  = inv_m * (A - B);
+        double pr  = (g.d * lF) + (st.d * g.lF);
+        double dt  = (lane_read(pr, L.tri) + lane_read(pr, L.tri + 1)) + lane_read(pr, L.tri + 2);
+        double n2r = (g.n2 * st.r) + (st.n2 * g.r);
+        double w   = n2r * g.kw;
+        double t   = (g.dt * w) + (dt * g.w);
+        double ld  = ((g.c * lF) + (st.c * g.lF)) + ((g.t * st.d) + (t * g.d));
+        double ldn = lane_read(ld, L.l + DIM);
+        double axx = L.last ? ld : ld - ldn;
+        double av  = lane_read(kbar_t, L.l - VOFF);
+        return L.isX ? axx : (L.isV ? av : 0.0);
+    }
+
+    /// Tangent of one RK4 step.
+    __device__ static __forceinline__ double rk4_tan(const Lane &L, const TapeFwd (&g)[4], double s_t, double uc_t) {
+        SpringsTan st;
+        double k1 = fc_tan(L, g[0], s_t, uc_t, st);
+        double w  = s_t + 0.5 * (Ts * k1);
+        double k2 = fc_tan(L, g[1], w, uc_t, st);
+        w         = s_t + 0.5 * (Ts * k2);
+        double k3 = fc_tan(L, g[2], w, uc_t, st);
+        w         = s_t + Ts * k3;
+        double k4 = fc_tan(L, g[3], w, uc_t, st);
+        return s_t + c6 * (((k1 + 2.0 * k2) + 2.0 * k3) + k4);
+    }
+
+    /// Tangent of the RK4 adjoint (second-order adjoint): mu_t = tangent of the incoming adjoint.
+    __device__ static __forceinline__ void rk4_adj_tan(const Lane &L, const TapeRev (&g)[4], double s_t,
+                                                       double uc_t, double mu_t, double &sbar_t,
+                                                       double &ubar_t) {
+        SpringsTan st1, st2, st3, st4;
+        double k = fc_tan(L, g[0], s_t, uc_t, st1);
+        double w = s_t + 0.5 * (Ts * k);
+        k        = fc_tan(L, g[1], w, uc_t, st2);
+        w        = s_t + 0.5 * (Ts * k);
+        k        = fc_tan(L, g[2], w, uc_t, st3);
+        w        = s_t + Ts * k;
+        springs_tan(L, g[3], w, st4);
+
+        double sg  = c6 * mu_t;
+        double kb1 = sg, kb2 = 2.0 * sg, kb3 = 2.0 * sg, kb4 = sg;
+        sbar_t     = mu_t;
+        double a   = fc_adj_tan(L, g[3], st4, kb4);
+        sbar_t     = sbar_t + a;
+        kb3        = kb3 + Ts * a;
+        a          = fc_adj_tan(L, g[2], st3, kb3);
+        sbar_t     = sbar_t + a;
+        kb2        = kb2 + 0.5 * (Ts * a);
+        a          = fc_adj_tan(L, g[1], st2, kb2);
+        sbar_t     = sbar_t + a;
+        kb1        = kb1 + 0.5 * (Ts * a);
+        a          = fc_adj_tan(L, g[0], st1, kb1);
+        sbar_t     = sbar_t + a;
+        ubar_t     = ((kb4 + kb3) + kb2) + kb1;
+    }
+
+    /// Tangent of cost_grad_x_add: lam_t + d2(l)/dx2 s_t.
+    __device__ static __forceinline__ double cost_grad_x_add_tan(const Lane &L, double s_t, double lam_t) {
+        return L.isE ? lam_t + c2a * s_t : (L.isV ? lam_t + c2b * s_t : lam_t);
     }
 
     /// One RK4 step of the plant (formulation.hpp:21-28).
@@ -125,9 +285,12 @@ struct ChainModel {
 
     /// Adjoint of one RK4 step.  mu = adjoint of x_next.  sbar = adjoint of s,
     /// ubar = adjoint of u through the dynamics (valid on lanes 27..29).
+    /// With `tape_stage` != nullptr (T = double only) the substage quantities are recorded.
     template <class T>
-    __device__ static __forceinline__ void rk4_adj(const Lane &L, T s, T uc, T mu, T &sbar, T &ubar) {
+    __device__ static __forceinline__ void rk4_adj(const Lane &L, T s, T uc, T mu, T &sbar, T &ubar,
+                                                   double4 *tape_stage = nullptr) {
         Springs<T> sp1, sp2, sp3, sp4;
+        AdjAux<T> ax;
         T k = fc(L, s, uc, sp1);
         T w = s + 0.5 * (Ts * k);
         k   = fc(L, w, uc, sp2);
@@ -139,19 +302,30 @@ struct ChainModel {
         T sg  = c6 * mu;
         T kb1 = sg, kb2 = 2.0 * sg, kb3 = 2.0 * sg, kb4 = sg;
         sbar  = mu;
-        T a   = fc_adj(L, sp4, kb4);
+        T a   = fc_adj(L, sp4, kb4, ax);
+        record(L, tape_stage, 3, sp4, ax);
         sbar  = sbar + a;
         kb3   = kb3 + Ts * a;
-        a     = fc_adj(L, sp3, kb3);
+        a     = fc_adj(L, sp3, kb3, ax);
+        record(L, tape_stage, 2, sp3, ax);
         sbar  = sbar + a;
         kb2   = kb2 + 0.5 * (Ts * a);
-        a     = fc_adj(L, sp2, kb2);
+        a     = fc_adj(L, sp2, kb2, ax);
+        record(L, tape_stage, 1, sp2, ax);
         sbar  = sbar + a;
         kb1   = kb1 + 0.5 * (Ts * a);
-        a     = fc_adj(L, sp1, kb1);
+        a     = fc_adj(L, sp1, kb1, ax);
+        record(L, tape_stage, 0, sp1, ax);
         sbar  = sbar + a;
         ubar  = ((kb4 + kb3) + kb2) + kb1;
     }
+    __device__ static __forceinline__ void record(const Lane &L, double4 *stage, int j,
+                                                  const Springs<double> &sp, const AdjAux<double> &ax) {
+        if (stage)
+            tape_store(L, stage, j, sp, ax);
+    }
+    __device__ static __forceinline__ void record(const Lane &, double4 *, int, const Springs<dual> &,
+                                                  const AdjAux<dual> &) {}
 
     /// Per-lane running cost: lanes 27..29 add alpha (x_end - ref)^2 then gamma u^2,
     /// lanes 30..56 add beta v^2  (hanging_chain.cpp:127-131).

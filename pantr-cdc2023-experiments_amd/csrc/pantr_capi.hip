@@ -249,7 +249,7 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
     if (b->nj > 32)
         return fail(PANTR_ERR_OUT_OF_RANGE, "horizon too long: n = nu*N must be <= 2048");
     b->maxB            = max_instances;
-    b->ws_per_instance = (size_t)2 * (b->N + 1) * WAVE;
+    b->ws_per_instance = WaveProblem<ChainModel>::workspace_doubles(b->N);
     b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double);
     if (b->lds_bytes > 160 * 1024)
         return fail(PANTR_ERR_OUT_OF_RANGE, "decision vectors do not fit the 160 KiB LDS");
@@ -469,6 +469,24 @@ int pantr_batch_eval_psi_grad_psi(pantr_batch_t *b, int32_t B, const double *x0,
 
 int pantr_batch_eval_hess_psi_prod(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
                                    const double *v, double *Hv) {
+    if (!x0 || !u || !v || !Hv)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    // the solver's own path: record the tape at u, then replay it for v
+    return run_eval(b, B, EVAL_HESS_PROD_TAPE, 0, x0, u, v, nullptr, Hv, nullptr);
+}
+
+extern "C" int pantr_debug_tape(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
+                                const double *v, double *Hv, double *scal) {
+    return run_eval(b, B, 99, 0, x0, u, v, scal, Hv, nullptr);
+}
+
+extern "C" int pantr_debug_read_ws(pantr_batch_t *b, double *out, int64_t count) {
+    HIP_TRY(hipMemcpy(out, b->d_ws, count * sizeof(double), hipMemcpyDeviceToHost));
+    return PANTR_OK;
+}
+
+int pantr_batch_eval_hess_psi_prod_dual(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
+                                        const double *v, double *Hv) {
     if (!x0 || !u || !v || !Hv)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
     return run_eval(b, B, EVAL_HESS_PROD, 0, x0, u, v, nullptr, Hv, nullptr);

@@ -60,7 +60,7 @@ struct SolveArgs {
     int32_t trace_cap, trace_instances, pad0;
     const double *x0;      ///< [B][nx] initial states (the problem parameter)
     double *u;             ///< [B][n]  in: initial guess, out: solution
-    double *ws;            ///< [B][2][(N+1)][64] trajectory workspace
+    double *ws;            ///< [B][WaveProblem::workspace_doubles(N)] trajectories + tape
     DeviceStats *stats;    ///< [B]
     double *trace;         ///< [trace_instances][trace_cap][TRACE_COLS] or nullptr
     const int32_t *order;  ///< optional launch order (instance index per workgroup) or nullptr
@@ -79,8 +79,19 @@ struct WaveProblem {
     double x0;  ///< this lane's initial-state component
     double *X;  ///< global: primal trajectory rows, X[k*64 + lane]
     double *Xt; ///< global: tangent trajectory rows
+    double4 *tape; ///< global: recorded primal substage quantities, M::TAPE_D4_PER_STAGE per stage
 
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
+
+    /// Doubles of HBM workspace one instance needs: X and Xt rows plus the tape.
+    __host__ __device__ static size_t workspace_doubles(int N) {
+        return (size_t)2 * (N + 1) * WAVE + (size_t)N * M::TAPE_D4_PER_STAGE * 4;
+    }
+    __device__ __forceinline__ void bind_workspace(double *ws, int inst) {
+        X    = ws + (size_t)inst * workspace_doubles(N);
+        Xt   = X + (size_t)(N + 1) * WAVE;
+        tape = reinterpret_cast<double4 *>(Xt + (size_t)(N + 1) * WAVE);
+    }
 
     /// psi(u) = sum_k l(x_k,u_k) + l_N(x_N); optionally stores the trajectory.
     template <bool STORE>
@@ -101,6 +112,8 @@ struct WaveProblem {
     }
 
     /// psi and grad psi (forward sweep, then adjoint sweep over the stored trajectory).
+    /// RECORD: the adjoint sweep also writes the tape the Hessian-vector products replay.
+    template <bool RECORD = false>
     __device__ __forceinline__ double psi_grad(const double *u, double *grad) const {
         double psi = psi_forward<true>(u);
         wave_sync(); // the sweep below re-reads rows this wavefront has just written
@@ -110,7 +123,7 @@ struct WaveProblem {
             double s_prev = k > 0 ? X[(k - 1) * WAVE + L.l] : 0.0; // one stage ahead
             double uc     = u[M::nu * k + L.uidx];
             double sbar, ubar;
-            M::rk4_adj(L, s, uc, lam, sbar, ubar);
+            M::rk4_adj(L, s, uc, lam, sbar, ubar, RECORD ? tape + (size_t)k * M::TAPE_D4_PER_STAGE : nullptr);
             if (L.isE)
                 grad[M::nu * k + L.uidx] = ubar + M::c2g * uc;
             lam = M::cost_grad_x_add(L, s, sbar);
@@ -146,6 +159,51 @@ struct WaveProblem {
                 Hv[M::nu * k + L.uidx] = (ubar + M::c2g * uc).t;
             lam = M::cost_grad_x_add(L, s, sbar);
             s   = s_prev;
+        }
+        wave_sync();
+    }
+
+    /// Hv at the point the tape was recorded at: tangent-only forward sweep and second-order
+    /// adjoint sweep, every primal quantity streamed from the tape (no sqrt, no division).
+    /// Bit-identical to hess_prod() at the same point.
+    __device__ __forceinline__ void hess_prod_tape(const double *v, double *Hv) const {
+        wave_sync();
+        {
+            double s_t = 0.0;
+            typename M::TapeFwd cur[4], nxt[4];
+            M::tape_load_fwd(L, tape, nxt);
+            for (int k = 0; k < N; ++k) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    cur[j] = nxt[j];
+                if (k + 1 < N) // one stage ahead
+                    M::tape_load_fwd(L, tape + (size_t)(k + 1) * M::TAPE_D4_PER_STAGE, nxt);
+                double uc_t       = v[M::nu * k + L.uidx];
+                Xt[k * WAVE + L.l] = s_t;
+                s_t               = M::rk4_tan(L, cur, s_t, uc_t);
+            }
+            Xt[N * WAVE + L.l] = s_t;
+            wave_sync();
+            double lam_t = M::cost_grad_x_add_tan(L, s_t, 0.0);
+            typename M::TapeRev rc[4], rn[4];
+            M::tape_load_rev(L, tape + (size_t)(N - 1) * M::TAPE_D4_PER_STAGE, rn);
+            double s_n = Xt[(N - 1) * WAVE + L.l];
+            for (int k = N - 1; k >= 0; --k) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    rc[j] = rn[j];
+                s_t = s_n;
+                if (k > 0) { // one stage ahead
+                    M::tape_load_rev(L, tape + (size_t)(k - 1) * M::TAPE_D4_PER_STAGE, rn);
+                    s_n = Xt[(k - 1) * WAVE + L.l];
+                }
+                double uc_t = v[M::nu * k + L.uidx];
+                double sbar_t, ubar_t;
+                M::rk4_adj_tan(L, rc, s_t, uc_t, lam_t, sbar_t, ubar_t);
+                if (L.isE)
+                    Hv[M::nu * k + L.uidx] = ubar_t + M::c2g * uc_t;
+                lam_t = M::cost_grad_x_add_tan(L, s_t, sbar_t);
+            }
         }
         wave_sync();
     }
@@ -271,10 +329,9 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
     const KernelParams &P   = a.prm;
     typename M::Lane L(lane);
 
-    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, 0.0, nullptr, nullptr};
+    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, 0.0, nullptr, nullptr, nullptr};
     pb.x0 = lane < M::nx ? a.x0[(size_t)inst * M::nx + lane] : 0.0;
-    pb.X  = a.ws + (size_t)inst * 2 * (a.N + 1) * WAVE;
-    pb.Xt = pb.X + (size_t)(a.N + 1) * WAVE;
+    pb.bind_workspace(a.ws, inst);
     const int n = a.n, nj = a.nj;
 
     // vector slots
@@ -411,7 +468,7 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
                 X_(prox)[i] = XH_(curr)[i];
         }
         prox.psi_x = curr.psi_xh;
-        pb.psi_grad(X_(prox), G_(prox));
+        pb.template psi_grad<true>(X_(prox), G_(prox)); // records the tape at xbar
         ++st.n_grad_L;
         prox.gamma = curr.gamma;
         prox.L     = curr.L;
@@ -470,8 +527,8 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
                     state     = CG;
                     vin       = d;
                 }
-                // the one Hessian-vector product site: work = H(xbar) * vin
-                pb.hess_prod(X_(prox), vin, work);
+                // the one Hessian-vector product site: work = H(xbar) * vin (tape replay)
+                pb.hess_prod_tape(vin, work);
                 ++st.n_hess_psi_prod;
                 if (state == KTERM) {
                     for (int j = 0; j < nj; ++j) {
@@ -654,7 +711,8 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
 // ---------------------------------------------------------------------------------------
 // Stand-alone problem-function kernels (parity tests of rows a7-a9, a13; same device code)
 // ---------------------------------------------------------------------------------------
-enum EvalMode : int32_t { EVAL_PSI = 0, EVAL_PSI_GRAD = 1, EVAL_HESS_PROD = 2, EVAL_PROX = 3 };
+enum EvalMode : int32_t { EVAL_PSI = 0, EVAL_PSI_GRAD = 1, EVAL_HESS_PROD = 2, EVAL_PROX = 3,
+                          EVAL_HESS_PROD_TAPE = 4 };
 
 struct EvalArgs {
     int32_t B, N, n, npad, nj, mode;
@@ -664,7 +722,7 @@ struct EvalArgs {
     double *out_s;    ///< [B][4]  psi | (pTp, gradTp, eps_unit, nJ)
     double *out_v;    ///< [B][n]  grad | Hv | xhat
     double *out_v2;   ///< [B][n]  PROX: p
-    double *ws;       ///< [B][2][(N+1)][64]
+    double *ws;       ///< [B][WaveProblem::workspace_doubles(N)]
     double gamma;
 };
 
@@ -675,10 +733,9 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
     if (inst >= a.B)
         return;
     typename M::Lane L(lane);
-    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, 0.0, nullptr, nullptr};
+    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, 0.0, nullptr, nullptr, nullptr};
     pb.x0 = lane < M::nx ? a.x0[(size_t)inst * M::nx + lane] : 0.0;
-    pb.X  = a.ws + (size_t)inst * 2 * (a.N + 1) * WAVE;
-    pb.Xt = pb.X + (size_t)(a.N + 1) * WAVE;
+    pb.bind_workspace(a.ws, inst);
     double *u = pb.vec(0), *v = pb.vec(1), *o = pb.vec(2), *o2 = pb.vec(3);
     for (int i = lane; i < 4 * a.npad; i += WAVE)
         lds[i] = 0.0;
@@ -694,7 +751,19 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
     } else if (a.mode == EVAL_PSI_GRAD) {
         s0 = pb.psi_grad(u, o);
     } else if (a.mode == EVAL_HESS_PROD) {
+        pb.hess_prod(u, v, o); // dual-number path (validation)
+    } else if (a.mode == EVAL_HESS_PROD_TAPE) {
+        s0 = pb.template psi_grad<true>(u, o2); // record at u, then replay (the solver's path)
+        pb.hess_prod_tape(v, o);
+    } else if (a.mode == 99) { // debug: tangent trajectory of both paths
         pb.hess_prod(u, v, o);
+        double xt_d[8];
+        for (int k = 0; k < 8 && k <= a.N; ++k) xt_d[k] = pb.Xt[k * WAVE + lane];
+        pb.template psi_grad<true>(u, o2);
+        pb.hess_prod_tape(v, o);
+        double m = 0;
+        for (int k = 0; k < 8 && k <= a.N; ++k) m = fmax(m, fabs(xt_d[k] - pb.Xt[k * WAVE + lane]));
+        s1 = uniform(wave_max(lane < 57 ? m : 0.0));
     } else {
         pb.prox_grad_step(a.gamma, u, v, o, o2, s0, s1);
         s2 = pb.proj_grad_unit_norm(u, v);

@@ -24,15 +24,18 @@ __device__ __forceinline__ dual operator*(double c, dual a) { return {c * a.v, c
 __device__ __forceinline__ dual operator+(dual a, double c) { return {a.v + c, a.t}; }
 __device__ __forceinline__ dual operator-(dual a, double c) { return {a.v - c, a.t}; }
 __device__ __forceinline__ dual operator-(double c, dual a) { return {c - a.v, 0.0 - a.t}; }
-__device__ __forceinline__ dual operator/(dual a, dual b) {
-    return {a.v / b.v, ((a.t * b.v) - (a.v * b.t)) / (b.v * b.v)};
-}
+/// c / b = q with tangent b.t * k, k = (-q) / b.v: divisions act on primal values only, which
+/// is what lets the tape path record (q, k) once and replay tangents without dividing.
 __device__ __forceinline__ dual operator/(double c, dual b) {
-    return {c / b.v, (-(c * b.t)) / (b.v * b.v)};
+    double q = c / b.v;
+    double k = (-q) / b.v;
+    return {q, b.t * k};
 }
+/// sqrt(a) = r with tangent a.t * h, h = 0.5 / r
 __device__ __forceinline__ dual wsqrt(dual a) {
     double r = __builtin_sqrt(a.v);
-    return {r, (a.t * 0.5) / r};
+    double h = 0.5 / r;
+    return {r, a.t * h};
 }
 __device__ __forceinline__ double wsqrt(double a) { return __builtin_sqrt(a); }
 

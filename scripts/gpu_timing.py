@@ -12,7 +12,7 @@ B = len(x0)
 N = 60
 for name, xs, us in (("warm300", x0, guess), ("cold300", x0, np.zeros_like(guess)),
                      ("both600", np.vstack([x0, x0]), np.vstack([guess, np.zeros_like(guess)]))):
-    batch = pa.PantrBatch("hanging_chain", N, len(xs), opts=pa.DODO_PANTR_OPTS)
+    batch = pa.PantrBatch("hanging_chain", N, len(xs), opts=pa.DODO_PANTR_OPTS + ("alm.max_time=3s",))
     for rep in range(2):
         t = time.time(); u, st = batch.solve(xs, us); wall = time.time() - t
         ms = batch.last_kernel_ms()

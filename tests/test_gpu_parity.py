@@ -33,7 +33,9 @@ def test_psi_grad_hess_prod_match_oracle(rng, N):
     x0, u, v = random_states(rng, B), random_inputs(rng, B, N), rng.standard_normal((B, NU * N))
     psi = with_batch.eval_psi(x0, u)
     psi2, grad = with_batch.eval_psi_grad_psi(x0, u)
-    Hv = with_batch.eval_hess_psi_prod(x0, u, v)
+    Hv = with_batch.eval_hess_psi_prod(x0, u, v)                  # tape record + replay
+    Hv_dual = with_batch.eval_hess_psi_prod(x0, u, v, dual=True)   # dual-number sweep
+    assert np.array_equal(Hv, Hv_dual)
     for b in range(B):
         f_o, g_o = ob.psi_grad(N, x0[b], u[b])
         Hv_o = ob.hess_prod(N, x0[b], u[b], v[b])
