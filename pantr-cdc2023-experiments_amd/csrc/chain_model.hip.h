@@ -150,27 +150,31 @@ struct ChainModel {
             p[2 * TAPE_LANES] = make_double4(ax.w, kw, ax.t, 0.0);
         }
     }
-    __device__ static __forceinline__ void tape_load_fwd(const Lane &L, const double4 *stage, TapeFwd (&g)[4]) {
+    static constexpr int TAPE_STAGE_BYTES = TAPE_D4_PER_STAGE * 32; // 12 KiB
+    static constexpr int TAPE_ROW_BYTES   = TAPE_LANES * 32;        // 1 KiB
+
+    /// Start the LDS-DMA of one stage's tape rows into `buf` (12 KiB of LDS): all 12 rows for
+    /// the adjoint sweep, only the four G0 rows for the forward sweep.  One instruction per row.
+    template <bool ALL_GROUPS>
+    __device__ static __forceinline__ void tape_prefetch(const Lane &L, const double4 *stage, char *buf) {
+        const char *src = reinterpret_cast<const char *>(stage) + L.l * 16;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            double4 a = make_double4(0, 0, 0, 0);
-            if (L.l < TAPE_LANES)
-                a = stage[(j * TAPE_GROUPS) * TAPE_LANES + L.l];
-            g[j] = {a.x, a.y, a.z, a.w};
-        }
-    }
-    __device__ static __forceinline__ void tape_load_rev(const Lane &L, const double4 *stage, TapeRev (&g)[4]) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            double4 a = make_double4(0, 0, 0, 0), b = a, c = a;
-            if (L.l < TAPE_LANES) {
-                const double4 *p = stage + (j * TAPE_GROUPS) * TAPE_LANES + L.l;
-                a = p[0];
-                b = p[TAPE_LANES];
-                c = p[2 * TAPE_LANES];
+            for (int g = 0; g < (ALL_GROUPS ? TAPE_GROUPS : 1); ++g) {
+                int row = j * TAPE_GROUPS + g;
+                lds_dma_row(src + row * TAPE_ROW_BYTES, buf + row * TAPE_ROW_BYTES);
             }
-            g[j] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z};
-        }
+    }
+    __device__ static __forceinline__ TapeFwd tape_fwd(const Lane &L, const char *buf, int j) {
+        const double4 *p = reinterpret_cast<const double4 *>(buf) + (j * TAPE_GROUPS) * TAPE_LANES + (L.l & 31);
+        double4 a = p[0];
+        return {a.x, a.y, a.z, a.w};
+    }
+    __device__ static __forceinline__ TapeRev tape_rev(const Lane &L, const char *buf, int j) {
+        const double4 *p = reinterpret_cast<const double4 *>(buf) + (j * TAPE_GROUPS) * TAPE_LANES + (L.l & 31);
+        double4 a = p[0], b = p[TAPE_LANES], c = p[2 * TAPE_LANES];
+        return {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z};
     }
 
     /// Tangent of springs(): the .t parts of the dual evaluation, primal values from the tape.
@@ -221,45 +225,45 @@ struct ChainModel {
         return L.isX ? axx : (L.isV ? av : 0.0);
     }
 
-    /// Tangent of one RK4 step.
-    __device__ static __forceinline__ double rk4_tan(const Lane &L, const TapeFwd (&g)[4], double s_t, double uc_t) {
+    /// Tangent of one RK4 step; the stage's tape rows are in LDS at `buf`.
+    __device__ static __forceinline__ double rk4_tan(const Lane &L, const char *buf, double s_t, double uc_t) {
         SpringsTan st;
-        double k1 = fc_tan(L, g[0], s_t, uc_t, st);
+        double k1 = fc_tan(L, tape_fwd(L, buf, 0), s_t, uc_t, st);
         double w  = s_t + 0.5 * (Ts * k1);
-        double k2 = fc_tan(L, g[1], w, uc_t, st);
+        double k2 = fc_tan(L, tape_fwd(L, buf, 1), w, uc_t, st);
         w         = s_t + 0.5 * (Ts * k2);
-        double k3 = fc_tan(L, g[2], w, uc_t, st);
+        double k3 = fc_tan(L, tape_fwd(L, buf, 2), w, uc_t, st);
         w         = s_t + Ts * k3;
-        double k4 = fc_tan(L, g[3], w, uc_t, st);
+        double k4 = fc_tan(L, tape_fwd(L, buf, 3), w, uc_t, st);
         return s_t + c6 * (((k1 + 2.0 * k2) + 2.0 * k3) + k4);
     }
 
     /// Tangent of the RK4 adjoint (second-order adjoint): mu_t = tangent of the incoming adjoint.
-    __device__ static __forceinline__ void rk4_adj_tan(const Lane &L, const TapeRev (&g)[4], double s_t,
+    __device__ static __forceinline__ void rk4_adj_tan(const Lane &L, const char *buf, double s_t,
                                                        double uc_t, double mu_t, double &sbar_t,
                                                        double &ubar_t) {
         SpringsTan st1, st2, st3, st4;
-        double k = fc_tan(L, g[0], s_t, uc_t, st1);
+        double k = fc_tan(L, tape_fwd(L, buf, 0), s_t, uc_t, st1);
         double w = s_t + 0.5 * (Ts * k);
-        k        = fc_tan(L, g[1], w, uc_t, st2);
+        k        = fc_tan(L, tape_fwd(L, buf, 1), w, uc_t, st2);
         w        = s_t + 0.5 * (Ts * k);
-        k        = fc_tan(L, g[2], w, uc_t, st3);
+        k        = fc_tan(L, tape_fwd(L, buf, 2), w, uc_t, st3);
         w        = s_t + Ts * k;
-        springs_tan(L, g[3], w, st4);
+        springs_tan(L, tape_fwd(L, buf, 3), w, st4);
 
         double sg  = c6 * mu_t;
         double kb1 = sg, kb2 = 2.0 * sg, kb3 = 2.0 * sg, kb4 = sg;
         sbar_t     = mu_t;
-        double a   = fc_adj_tan(L, g[3], st4, kb4);
+        double a   = fc_adj_tan(L, tape_rev(L, buf, 3), st4, kb4);
         sbar_t     = sbar_t + a;
         kb3        = kb3 + Ts * a;
-        a          = fc_adj_tan(L, g[2], st3, kb3);
+        a          = fc_adj_tan(L, tape_rev(L, buf, 2), st3, kb3);
         sbar_t     = sbar_t + a;
         kb2        = kb2 + 0.5 * (Ts * a);
-        a          = fc_adj_tan(L, g[1], st2, kb2);
+        a          = fc_adj_tan(L, tape_rev(L, buf, 1), st2, kb2);
         sbar_t     = sbar_t + a;
         kb1        = kb1 + 0.5 * (Ts * a);
-        a          = fc_adj_tan(L, g[0], st1, kb1);
+        a          = fc_adj_tan(L, tape_rev(L, buf, 0), st1, kb1);
         sbar_t     = sbar_t + a;
         ubar_t     = ((kb4 + kb3) + kb2) + kb1;
     }

@@ -22,6 +22,7 @@ static_assert(sizeof(pantr_stats_t) == sizeof(DeviceStats), "stats layout mismat
 namespace {
 
 thread_local std::string g_last_error;
+int g_eval_reps = 1; ///< development aid: repeat count of the timed op in pantr_eval_kernel
 
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
@@ -169,9 +170,11 @@ int run_eval(pantr_batch *b, int32_t B, int mode, double gamma, const double *x0
         HIP_TRY(hipMemcpy(b->d_v, v, nb, hipMemcpyHostToDevice));
     EvalArgs a{};
     a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj; a.mode = mode;
+    a.reps = g_eval_reps;
     a.x0 = b->d_x0; a.u = b->d_u; a.v = v ? b->d_v : nullptr;
     a.out_s = b->d_s; a.out_v = b->d_o1; a.out_v2 = b->d_o2; a.ws = b->d_ws; a.gamma = gamma;
-    hipLaunchKernelGGL(pantr_eval_kernel<ChainModel>, dim3(B), dim3(WAVE), 4 * b->npad * sizeof(double), 0, a);
+    hipLaunchKernelGGL(pantr_eval_kernel<ChainModel>, dim3(B), dim3(WAVE),
+                       4 * b->npad * sizeof(double) + WaveProblem<ChainModel>::tape_lds_bytes(), 0, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     std::vector<double> s((size_t)B * 4);
@@ -250,7 +253,7 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
         return fail(PANTR_ERR_OUT_OF_RANGE, "horizon too long: n = nu*N must be <= 2048");
     b->maxB            = max_instances;
     b->ws_per_instance = WaveProblem<ChainModel>::workspace_doubles(b->N);
-    b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double);
+    b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double) + WaveProblem<ChainModel>::tape_lds_bytes();
     if (b->lds_bytes > 160 * 1024)
         return fail(PANTR_ERR_OUT_OF_RANGE, "decision vectors do not fit the 160 KiB LDS");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_solve_kernel<ChainModel>),
@@ -475,6 +478,7 @@ int pantr_batch_eval_hess_psi_prod(pantr_batch_t *b, int32_t B, const double *x0
     return run_eval(b, B, EVAL_HESS_PROD_TAPE, 0, x0, u, v, nullptr, Hv, nullptr);
 }
 
+extern "C" void pantr_debug_set_eval_reps(int r) { g_eval_reps = r; }
 extern "C" int pantr_debug_tape(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
                                 const double *v, double *Hv, double *scal) {
     return run_eval(b, B, 99, 0, x0, u, v, scal, Hv, nullptr);

@@ -80,9 +80,12 @@ struct WaveProblem {
     double *X;  ///< global: primal trajectory rows, X[k*64 + lane]
     double *Xt; ///< global: tangent trajectory rows
     double4 *tape; ///< global: recorded primal substage quantities, M::TAPE_D4_PER_STAGE per stage
+    char *tape_lds; ///< LDS: two stage-sized landing buffers for the tape's LDS-DMA
 
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
 
+    /// Bytes of LDS behind the decision vectors: two landing buffers for the tape's LDS-DMA.
+    __host__ __device__ static size_t tape_lds_bytes() { return 2 * (size_t)M::TAPE_STAGE_BYTES; }
     /// Doubles of HBM workspace one instance needs: X and Xt rows plus the tape.
     __host__ __device__ static size_t workspace_doubles(int N) {
         return (size_t)2 * (N + 1) * WAVE + (size_t)N * M::TAPE_D4_PER_STAGE * 4;
@@ -168,42 +171,37 @@ struct WaveProblem {
     /// Bit-identical to hess_prod() at the same point.
     __device__ __forceinline__ void hess_prod_tape(const double *v, double *Hv) const {
         wave_sync();
-        {
-            double s_t = 0.0;
-            typename M::TapeFwd cur[4], nxt[4];
-            M::tape_load_fwd(L, tape, nxt);
-            for (int k = 0; k < N; ++k) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    cur[j] = nxt[j];
-                if (k + 1 < N) // one stage ahead
-                    M::tape_load_fwd(L, tape + (size_t)(k + 1) * M::TAPE_D4_PER_STAGE, nxt);
-                double uc_t       = v[M::nu * k + L.uidx];
-                Xt[k * WAVE + L.l] = s_t;
-                s_t               = M::rk4_tan(L, cur, s_t, uc_t);
+        char *buf[2] = {tape_lds, tape_lds + M::TAPE_STAGE_BYTES};
+        // ---- forward tangent sweep: stage k+1's G0 rows stream into LDS while stage k runs ----
+        double s_t = 0.0;
+        M::template tape_prefetch<false>(L, tape, buf[0]);
+        for (int k = 0; k < N; ++k) {
+            wait_vmem(); // stage k's rows have landed
+            if (k + 1 < N)
+                M::template tape_prefetch<false>(L, tape + (size_t)(k + 1) * M::TAPE_D4_PER_STAGE, buf[(k + 1) & 1]);
+            double uc_t        = v[M::nu * k + L.uidx];
+            Xt[k * WAVE + L.l] = s_t;
+            s_t                = M::rk4_tan(L, buf[k & 1], s_t, uc_t);
+        }
+        Xt[N * WAVE + L.l] = s_t;
+        wave_sync();
+        // ---- second-order adjoint sweep ----
+        double lam_t = M::cost_grad_x_add_tan(L, s_t, 0.0);
+        M::template tape_prefetch<true>(L, tape + (size_t)(N - 1) * M::TAPE_D4_PER_STAGE, buf[(N - 1) & 1]);
+        double s_n = Xt[(N - 1) * WAVE + L.l];
+        for (int k = N - 1; k >= 0; --k) {
+            wait_vmem(); // stage k's rows and Xt row have landed
+            s_t = s_n;
+            if (k > 0) { // one stage ahead
+                M::template tape_prefetch<true>(L, tape + (size_t)(k - 1) * M::TAPE_D4_PER_STAGE, buf[(k - 1) & 1]);
+                s_n = Xt[(k - 1) * WAVE + L.l];
             }
-            Xt[N * WAVE + L.l] = s_t;
-            wave_sync();
-            double lam_t = M::cost_grad_x_add_tan(L, s_t, 0.0);
-            typename M::TapeRev rc[4], rn[4];
-            M::tape_load_rev(L, tape + (size_t)(N - 1) * M::TAPE_D4_PER_STAGE, rn);
-            double s_n = Xt[(N - 1) * WAVE + L.l];
-            for (int k = N - 1; k >= 0; --k) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    rc[j] = rn[j];
-                s_t = s_n;
-                if (k > 0) { // one stage ahead
-                    M::tape_load_rev(L, tape + (size_t)(k - 1) * M::TAPE_D4_PER_STAGE, rn);
-                    s_n = Xt[(k - 1) * WAVE + L.l];
-                }
-                double uc_t = v[M::nu * k + L.uidx];
-                double sbar_t, ubar_t;
-                M::rk4_adj_tan(L, rc, s_t, uc_t, lam_t, sbar_t, ubar_t);
-                if (L.isE)
-                    Hv[M::nu * k + L.uidx] = ubar_t + M::c2g * uc_t;
-                lam_t = M::cost_grad_x_add_tan(L, s_t, sbar_t);
-            }
+            double uc_t = v[M::nu * k + L.uidx];
+            double sbar_t, ubar_t;
+            M::rk4_adj_tan(L, buf[k & 1], s_t, uc_t, lam_t, sbar_t, ubar_t);
+            if (L.isE)
+                Hv[M::nu * k + L.uidx] = ubar_t + M::c2g * uc_t;
+            lam_t = M::cost_grad_x_add_tan(L, s_t, sbar_t);
         }
         wave_sync();
     }
@@ -329,9 +327,10 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
     const KernelParams &P   = a.prm;
     typename M::Lane L(lane);
 
-    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, 0.0, nullptr, nullptr, nullptr};
+    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, 0.0, nullptr, nullptr, nullptr, nullptr};
     pb.x0 = lane < M::nx ? a.x0[(size_t)inst * M::nx + lane] : 0.0;
     pb.bind_workspace(a.ws, inst);
+    pb.tape_lds = reinterpret_cast<char *>(lds + NUM_VEC * a.npad);
     const int n = a.n, nj = a.nj;
 
     // vector slots
@@ -715,7 +714,7 @@ enum EvalMode : int32_t { EVAL_PSI = 0, EVAL_PSI_GRAD = 1, EVAL_HESS_PROD = 2, E
                           EVAL_HESS_PROD_TAPE = 4 };
 
 struct EvalArgs {
-    int32_t B, N, n, npad, nj, mode;
+    int32_t B, N, n, npad, nj, mode, reps, pad0;
     const double *x0; ///< [B][nx]
     const double *u;  ///< [B][n]
     const double *v;  ///< [B][n]  (HESS_PROD: direction; PROX: gradient)
@@ -733,9 +732,10 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
     if (inst >= a.B)
         return;
     typename M::Lane L(lane);
-    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, 0.0, nullptr, nullptr, nullptr};
+    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, 0.0, nullptr, nullptr, nullptr, nullptr};
     pb.x0 = lane < M::nx ? a.x0[(size_t)inst * M::nx + lane] : 0.0;
     pb.bind_workspace(a.ws, inst);
+    pb.tape_lds = reinterpret_cast<char *>(lds + 4 * a.npad);
     double *u = pb.vec(0), *v = pb.vec(1), *o = pb.vec(2), *o2 = pb.vec(3);
     for (int i = lane; i < 4 * a.npad; i += WAVE)
         lds[i] = 0.0;
@@ -754,7 +754,8 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
         pb.hess_prod(u, v, o); // dual-number path (validation)
     } else if (a.mode == EVAL_HESS_PROD_TAPE) {
         s0 = pb.template psi_grad<true>(u, o2); // record at u, then replay (the solver's path)
-        pb.hess_prod_tape(v, o);
+        for (int r = 0; r < (a.reps > 0 ? a.reps : 1); ++r)
+            pb.hess_prod_tape(v, o);
     } else if (a.mode == 99) { // debug: tangent trajectory of both paths
         pb.hess_prod(u, v, o);
         double xt_d[8];

@@ -54,6 +54,9 @@ __device__ __forceinline__ dual select(bool c, dual a, dual b) {
 // ---- cross-lane ----------------------------------------------------------------------------
 /// Value of `v` held by lane `src` (src taken modulo 64 by the hardware).
 __device__ __forceinline__ double lane_read(double v, int src) {
+#ifdef PANTR_TIMING_NO_SHUFFLE // timing-only build: results are wrong
+    return v + (double)src;
+#endif
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo     = __builtin_amdgcn_ds_bpermute(src << 2, lo);
     hi     = __builtin_amdgcn_ds_bpermute(src << 2, hi);
@@ -84,6 +87,21 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+/// LDS-DMA (gfx950 global_load_lds_dwordx4): every lane fetches 16 bytes from its own global
+/// address and the wavefront's 1 KiB lands contiguously at the wave-uniform LDS address
+/// `lds_row` (+ lane*16), without passing through VGPRs.  Completion is tracked by vmcnt.
+__device__ __forceinline__ void lds_dma_row(const void *gsrc_lane, void *lds_row) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)gsrc_lane,
+        (__attribute__((address_space(3))) void *)lds_row, 16, 0, 0);
+}
+/// Wait until this wavefront's outstanding global loads/stores and LDS-DMA have completed.
+__device__ __forceinline__ void wait_vmem() {
+#ifndef PANTR_TIMING_NO_VMWAIT // timing-only build without it: results are wrong
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
 /// Move a wave-uniform double into scalar registers (lets the compiler branch on SCC).

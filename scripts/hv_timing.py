@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Times the tape-replay Hessian-vector product in isolation (development aid)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pantr-cdc2023-experiments_amd"))
+import pantr_amd as pa
+d = np.load(os.path.join(ROOT, "tests/golden/mpc_hanging_chain_N60_warm300.npz"))
+x0 = np.vstack([d["x0"], d["x0"]]); u = np.vstack([d["sol"], d["guess"]])
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+x0, u = x0[:B], u[:B]
+v = np.random.default_rng(0).standard_normal(u.shape)
+L = pa.lib()
+b = pa.PantrBatch("hanging_chain", 60, B)
+res = {}
+for reps in (1, 101):
+    L.pantr_debug_set_eval_reps(reps)
+    b.eval_hess_psi_prod(x0, u, v)
+    t = time.perf_counter(); Hv = b.eval_hess_psi_prod(x0, u, v); res[reps] = time.perf_counter() - t
+print(f"B={B}: Hv (tape replay) = {(res[101]-res[1])/100*1e6:.1f} us per product per wave "
+      f"({60*(res[101]-res[1])/100/60*1e9/60:.0f} ns/stage)")
