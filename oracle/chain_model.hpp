@@ -501,8 +501,8 @@ struct Chain {
             lam_t[l] = lam_t[l] + c2b * s_t[l];
     }
 
-    /// Per-lane cost contribution of one stage (hanging_chain.cpp:127-131):
-    /// lanes 27..29: alpha (x_end - ref)^2 then + gamma u^2; lanes 30..56: beta v^2.
+    /// Per-component cost contribution of one stage (hanging_chain.cpp:127-131): components
+    /// 27..29 (end point): alpha (x_end - ref)^2 then + gamma u^2; components 30..56: beta v^2.
     template <class T>
     static void cost_accumulate(const T *s, const T *u /*nullptr for l_N*/, T *acc /*[64]*/) {
         for (int c = 0; c < DIM; ++c) {
@@ -514,6 +514,22 @@ struct Chain {
         }
         for (int l = VOFF; l < nx; ++l)
             acc[l] = acc[l] + beta * (s[l] * s[l]);
+    }
+
+    /// Total of the per-component running sums: per chain point
+    /// ((((x0 + x1) + x2) + v0) + v1) + v2, then the 64-lane butterfly over the points
+    /// (the kernels hold one point per lane).
+    static double cost_total(const double *acc /*[64], indexed like the state vector*/) {
+        double part[64] = {};
+        for (int p = 0; p < NP; ++p) {
+            double ax[DIM], av[DIM];
+            for (int c = 0; c < DIM; ++c) {
+                ax[c] = acc[DIM * p + c];
+                av[c] = p < NB ? acc[VOFF + DIM * p + c] : 0.0;
+            }
+            part[p] = ((((ax[0] + ax[1]) + ax[2]) + av[0]) + av[1]) + av[2];
+        }
+        return wave_sum(part);
     }
 
     /// Gradient of the stage/terminal cost w.r.t. the state, added to lam.
@@ -561,7 +577,7 @@ struct SingleShooting {
         if (X)
             std::copy(s, s + nx, X + N * nx);
         Model::template cost_accumulate<double>(s, nullptr, acc);
-        return wave_sum(acc);
+        return Model::cost_total(acc);
     }
 
     double eval_psi(const double *u) const {

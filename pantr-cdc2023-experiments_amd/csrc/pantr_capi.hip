@@ -479,15 +479,6 @@ int pantr_batch_eval_hess_psi_prod(pantr_batch_t *b, int32_t B, const double *x0
 }
 
 extern "C" void pantr_debug_set_eval_reps(int r) { g_eval_reps = r; }
-extern "C" int pantr_debug_tape(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
-                                const double *v, double *Hv, double *scal) {
-    return run_eval(b, B, 99, 0, x0, u, v, scal, Hv, nullptr);
-}
-
-extern "C" int pantr_debug_read_ws(pantr_batch_t *b, double *out, int64_t count) {
-    HIP_TRY(hipMemcpy(out, b->d_ws, count * sizeof(double), hipMemcpyDeviceToHost));
-    return PANTR_OK;
-}
 
 int pantr_batch_eval_hess_psi_prod_dual(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
                                         const double *v, double *Hv) {

@@ -73,45 +73,49 @@ struct SolveArgs {
 template <class M>
 struct WaveProblem {
     using Lane = typename M::Lane;
+    template <class T>
+    using State = typename M::template State<T>;
     const Lane &L;
     double *lds; ///< base of this wavefront's vectors
     int N, n, npad, nj;
-    double x0;  ///< this lane's initial-state component
-    double *X;  ///< global: primal trajectory rows, X[k*64 + lane]
-    double *Xt; ///< global: tangent trajectory rows
-    double4 *tape; ///< global: recorded primal substage quantities, M::TAPE_D4_PER_STAGE per stage
-    char *tape_lds; ///< LDS: two stage-sized landing buffers for the tape's LDS-DMA
+    State<double> x0; ///< this lane's share of the initial state
+    double *X;        ///< global: primal trajectory rows, M::TRAJ_DOUBLES per stage
+    double *Xt;       ///< global: tangent trajectory rows
+    double4 *tape;    ///< global: recorded primal substage quantities, M::TAPE_D4_PER_STAGE per stage
+    double4 *st;      ///< global: tangent spring quantities of the current Hv, M::ST_D4_PER_STAGE per stage
+    char *tape_lds;   ///< LDS: two stage-sized landing buffers for the tape's LDS-DMA
 
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
 
     /// Bytes of LDS behind the decision vectors: two landing buffers for the tape's LDS-DMA.
-    __host__ __device__ static size_t tape_lds_bytes() { return 2 * (size_t)M::TAPE_STAGE_BYTES; }
-    /// Doubles of HBM workspace one instance needs: X and Xt rows plus the tape.
+    __host__ __device__ static size_t tape_lds_bytes() { return 2 * (size_t)M::LDS_STAGE_BYTES; }
+    /// Doubles of HBM workspace one instance needs: X and Xt rows, the tape, the tangent tape.
     __host__ __device__ static size_t workspace_doubles(int N) {
-        return (size_t)2 * (N + 1) * WAVE + (size_t)N * M::TAPE_D4_PER_STAGE * 4;
+        return (size_t)2 * (N + 1) * M::TRAJ_DOUBLES + (size_t)N * (M::TAPE_D4_PER_STAGE + M::ST_D4_PER_STAGE) * 4;
     }
     __device__ __forceinline__ void bind_workspace(double *ws, int inst) {
         X    = ws + (size_t)inst * workspace_doubles(N);
-        Xt   = X + (size_t)(N + 1) * WAVE;
-        tape = reinterpret_cast<double4 *>(Xt + (size_t)(N + 1) * WAVE);
+        Xt   = X + (size_t)(N + 1) * M::TRAJ_DOUBLES;
+        tape = reinterpret_cast<double4 *>(Xt + (size_t)(N + 1) * M::TRAJ_DOUBLES);
+        st   = tape + (size_t)N * M::TAPE_D4_PER_STAGE;
     }
 
     /// psi(u) = sum_k l(x_k,u_k) + l_N(x_N); optionally stores the trajectory.
     template <bool STORE>
     __device__ __forceinline__ double psi_forward(const double *u) const {
         wave_sync(); // u was written by its owner lanes
-        double s = x0, acc = 0.0;
+        State<double> s = x0, acc = M::template zero_state<double>();
         for (int k = 0; k < N; ++k) {
-            double uc = u[M::nu * k + L.uidx];
+            auto in = M::load_input(u + M::nu * k);
             if (STORE)
-                X[k * WAVE + L.l] = s;
-            acc = M::cost_accumulate(L, s, uc, true, acc);
-            s   = M::rk4(L, s, uc);
+                M::traj_store(L, X + (size_t)k * M::TRAJ_DOUBLES, s);
+            M::cost_accumulate(L, s, in, true, acc);
+            s = M::rk4(L, s, in);
         }
         if (STORE)
-            X[N * WAVE + L.l] = s;
-        acc = M::cost_accumulate(L, s, 0.0, false, acc);
-        return uniform(wave_sum(acc));
+            M::traj_store(L, X + (size_t)N * M::TRAJ_DOUBLES, s);
+        M::cost_accumulate(L, s, typename M::template Input<double>{}, false, acc);
+        return M::cost_total(L, acc);
     }
 
     /// psi and grad psi (forward sweep, then adjoint sweep over the stored trajectory).
@@ -120,88 +124,134 @@ struct WaveProblem {
     __device__ __forceinline__ double psi_grad(const double *u, double *grad) const {
         double psi = psi_forward<true>(u);
         wave_sync(); // the sweep below re-reads rows this wavefront has just written
-        double lam = M::cost_grad_x_add(L, X[N * WAVE + L.l], 0.0);
-        double s   = X[(N - 1) * WAVE + L.l];
+        State<double> lam = M::template zero_state<double>();
+        M::cost_grad_x_add(L, M::traj_load(L, X + (size_t)N * M::TRAJ_DOUBLES), lam);
+        State<double> s = M::traj_load(L, X + (size_t)(N - 1) * M::TRAJ_DOUBLES);
         for (int k = N - 1; k >= 0; --k) {
-            double s_prev = k > 0 ? X[(k - 1) * WAVE + L.l] : 0.0; // one stage ahead
-            double uc     = u[M::nu * k + L.uidx];
-            double sbar, ubar;
-            M::rk4_adj(L, s, uc, lam, sbar, ubar, RECORD ? tape + (size_t)k * M::TAPE_D4_PER_STAGE : nullptr);
-            if (L.isE)
-                grad[M::nu * k + L.uidx] = ubar + M::c2g * uc;
-            lam = M::cost_grad_x_add(L, s, sbar);
-            s   = s_prev;
+            State<double> s_prev = s;
+            if (k > 0) // one stage ahead
+                s_prev = M::traj_load(L, X + (size_t)(k - 1) * M::TRAJ_DOUBLES);
+            auto in = M::load_input(u + M::nu * k);
+            State<double> sbar;
+            double ubar[M::nu];
+            M::rk4_adj(L, s, in, lam, sbar, ubar, RECORD ? tape + (size_t)k * M::TAPE_D4_PER_STAGE : nullptr);
+            double g[M::nu];
+#pragma unroll
+            for (int c = 0; c < M::nu; ++c)
+                g[c] = ubar[c] + M::c2g * in.u[c];
+            M::store_input_grad(L, grad + M::nu * k, g);
+            lam = sbar;
+            M::cost_grad_x_add(L, s, lam);
+            s = s_prev;
         }
-        wave_sync(); // grad was written by lanes 27..29
+        wave_sync(); // grad was written by the owner of the input adjoint
         return psi;
     }
 
-    /// Hv = d/du (grad psi(u)^T v), forward-over-reverse on dual numbers.
+    /// Hv = d/du (grad psi(u)^T v), forward-over-reverse on dual numbers (validation path: every
+    /// primal quantity is recomputed; the solver uses hess_prod_tape).
     __device__ __forceinline__ void hess_prod(const double *u, const double *v, double *Hv) const {
         wave_sync();
-        dual s = {x0, 0.0};
-        for (int k = 0; k < N; ++k) {
-            dual uc             = {u[M::nu * k + L.uidx], v[M::nu * k + L.uidx]};
-            X[k * WAVE + L.l]   = s.v;
-            Xt[k * WAVE + L.l]  = s.t;
-            s                   = M::rk4(L, s, uc);
+        State<dual> s;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            s.x[c] = {x0.x[c], 0.0};
+            s.v[c] = {x0.v[c], 0.0};
         }
-        X[N * WAVE + L.l]  = s.v;
-        Xt[N * WAVE + L.l] = s.t;
+        auto split_store = [&](int k, const State<dual> &sd) {
+            State<double> pv, pt;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pv.x[c] = sd.x[c].v; pv.v[c] = sd.v[c].v;
+                pt.x[c] = sd.x[c].t; pt.v[c] = sd.v[c].t;
+            }
+            M::traj_store(L, X + (size_t)k * M::TRAJ_DOUBLES, pv);
+            M::traj_store(L, Xt + (size_t)k * M::TRAJ_DOUBLES, pt);
+        };
+        auto joint_load = [&](int k) {
+            State<double> pv = M::traj_load(L, X + (size_t)k * M::TRAJ_DOUBLES);
+            State<double> pt = M::traj_load(L, Xt + (size_t)k * M::TRAJ_DOUBLES);
+            State<dual> sd;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                sd.x[c] = {pv.x[c], pt.x[c]};
+                sd.v[c] = {pv.v[c], pt.v[c]};
+            }
+            return sd;
+        };
+        for (int k = 0; k < N; ++k) {
+            auto in = M::load_input(u + M::nu * k, v + M::nu * k);
+            split_store(k, s);
+            s = M::rk4(L, s, in);
+        }
+        split_store(N, s);
         wave_sync();
-        dual lam = M::cost_grad_x_add(L, s, dual{0.0, 0.0});
-        s        = {X[(N - 1) * WAVE + L.l], Xt[(N - 1) * WAVE + L.l]};
+        State<dual> lam = M::template zero_state<dual>();
+        M::cost_grad_x_add(L, s, lam);
+        s = joint_load(N - 1);
         for (int k = N - 1; k >= 0; --k) {
-            dual s_prev = {0.0, 0.0};
+            State<dual> s_prev = s;
             if (k > 0)
-                s_prev = {X[(k - 1) * WAVE + L.l], Xt[(k - 1) * WAVE + L.l]};
-            dual uc = {u[M::nu * k + L.uidx], v[M::nu * k + L.uidx]};
-            dual sbar, ubar;
-            M::rk4_adj(L, s, uc, lam, sbar, ubar);
-            if (L.isE)
-                Hv[M::nu * k + L.uidx] = (ubar + M::c2g * uc).t;
-            lam = M::cost_grad_x_add(L, s, sbar);
-            s   = s_prev;
+                s_prev = joint_load(k - 1);
+            auto in = M::load_input(u + M::nu * k, v + M::nu * k);
+            State<dual> sbar;
+            dual ubar[M::nu];
+            M::rk4_adj(L, s, in, lam, sbar, ubar);
+            double g[M::nu];
+#pragma unroll
+            for (int c = 0; c < M::nu; ++c)
+                g[c] = (ubar[c] + M::c2g * in.u[c]).t;
+            M::store_input_grad(L, Hv + M::nu * k, g);
+            lam = sbar;
+            M::cost_grad_x_add(L, s, lam);
+            s = s_prev;
         }
         wave_sync();
     }
 
     /// Hv at the point the tape was recorded at: tangent-only forward sweep and second-order
-    /// adjoint sweep, every primal quantity streamed from the tape (no sqrt, no division).
-    /// Bit-identical to hess_prod() at the same point.
+    /// adjoint sweep, every primal quantity streamed from the tape (no sqrt, no division; the
+    /// adjoint sweep also streams the forward sweep's tangent spring quantities instead of
+    /// recomputing them).  Bit-identical to hess_prod() at the same point.
     __device__ __forceinline__ void hess_prod_tape(const double *v, double *Hv) const {
         wave_sync();
-        char *buf[2] = {tape_lds, tape_lds + M::TAPE_STAGE_BYTES};
-        // ---- forward tangent sweep: stage k+1's G0 rows stream into LDS while stage k runs ----
-        double s_t = 0.0;
-        M::template tape_prefetch<false>(L, tape, buf[0]);
+        char *buf[2] = {tape_lds, tape_lds + M::LDS_STAGE_BYTES};
+        // ---- forward tangent sweep: stage k+1's rows stream into LDS while stage k runs ----
+        State<double> s_t = M::template zero_state<double>();
+        M::prefetch_fwd(L, tape, buf[0]);
         for (int k = 0; k < N; ++k) {
             wait_vmem(); // stage k's rows have landed
             if (k + 1 < N)
-                M::template tape_prefetch<false>(L, tape + (size_t)(k + 1) * M::TAPE_D4_PER_STAGE, buf[(k + 1) & 1]);
-            double uc_t        = v[M::nu * k + L.uidx];
-            Xt[k * WAVE + L.l] = s_t;
-            s_t                = M::rk4_tan(L, buf[k & 1], s_t, uc_t);
+                M::prefetch_fwd(L, tape + (size_t)(k + 1) * M::TAPE_D4_PER_STAGE, buf[(k + 1) & 1]);
+            auto in_t = M::load_input(v + M::nu * k);
+            M::traj_store(L, Xt + (size_t)k * M::TRAJ_DOUBLES, s_t);
+            s_t = M::rk4_tan(L, buf[k & 1], s_t, in_t, st + (size_t)k * M::ST_D4_PER_STAGE);
         }
-        Xt[N * WAVE + L.l] = s_t;
         wave_sync();
         // ---- second-order adjoint sweep ----
-        double lam_t = M::cost_grad_x_add_tan(L, s_t, 0.0);
-        M::template tape_prefetch<true>(L, tape + (size_t)(N - 1) * M::TAPE_D4_PER_STAGE, buf[(N - 1) & 1]);
-        double s_n = Xt[(N - 1) * WAVE + L.l];
+        State<double> lam_t = M::template zero_state<double>();
+        M::cost_grad_x_add_tan(L, s_t, lam_t);
+        M::prefetch_rev(L, tape + (size_t)(N - 1) * M::TAPE_D4_PER_STAGE, st + (size_t)(N - 1) * M::ST_D4_PER_STAGE,
+                        buf[(N - 1) & 1]);
+        State<double> s_n = M::traj_load(L, Xt + (size_t)(N - 1) * M::TRAJ_DOUBLES);
         for (int k = N - 1; k >= 0; --k) {
             wait_vmem(); // stage k's rows and Xt row have landed
             s_t = s_n;
             if (k > 0) { // one stage ahead
-                M::template tape_prefetch<true>(L, tape + (size_t)(k - 1) * M::TAPE_D4_PER_STAGE, buf[(k - 1) & 1]);
-                s_n = Xt[(k - 1) * WAVE + L.l];
+                M::prefetch_rev(L, tape + (size_t)(k - 1) * M::TAPE_D4_PER_STAGE,
+                                st + (size_t)(k - 1) * M::ST_D4_PER_STAGE, buf[(k - 1) & 1]);
+                s_n = M::traj_load(L, Xt + (size_t)(k - 1) * M::TRAJ_DOUBLES);
             }
-            double uc_t = v[M::nu * k + L.uidx];
-            double sbar_t, ubar_t;
-            M::rk4_adj_tan(L, buf[k & 1], s_t, uc_t, lam_t, sbar_t, ubar_t);
-            if (L.isE)
-                Hv[M::nu * k + L.uidx] = ubar_t + M::c2g * uc_t;
-            lam_t = M::cost_grad_x_add_tan(L, s_t, sbar_t);
+            auto in_t = M::load_input(v + M::nu * k);
+            State<double> sbar_t;
+            double ubar_t[M::nu], g[M::nu];
+            M::rk4_adj_tan(L, buf[k & 1], lam_t, sbar_t, ubar_t);
+#pragma unroll
+            for (int c = 0; c < M::nu; ++c)
+                g[c] = ubar_t[c] + M::c2g * in_t.u[c];
+            M::store_input_grad(L, Hv + M::nu * k, g);
+            lam_t = sbar_t;
+            M::cost_grad_x_add_tan(L, s_t, lam_t);
         }
         wave_sync();
     }
@@ -327,8 +377,8 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
     const KernelParams &P   = a.prm;
     typename M::Lane L(lane);
 
-    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, 0.0, nullptr, nullptr, nullptr, nullptr};
-    pb.x0 = lane < M::nx ? a.x0[(size_t)inst * M::nx + lane] : 0.0;
+    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, nullptr};
+    pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
     pb.tape_lds = reinterpret_cast<char *>(lds + NUM_VEC * a.npad);
     const int n = a.n, nj = a.nj;
@@ -732,8 +782,8 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
     if (inst >= a.B)
         return;
     typename M::Lane L(lane);
-    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, 0.0, nullptr, nullptr, nullptr, nullptr};
-    pb.x0 = lane < M::nx ? a.x0[(size_t)inst * M::nx + lane] : 0.0;
+    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, nullptr};
+    pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
     pb.tape_lds = reinterpret_cast<char *>(lds + 4 * a.npad);
     double *u = pb.vec(0), *v = pb.vec(1), *o = pb.vec(2), *o2 = pb.vec(3);
@@ -756,15 +806,6 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
         s0 = pb.template psi_grad<true>(u, o2); // record at u, then replay (the solver's path)
         for (int r = 0; r < (a.reps > 0 ? a.reps : 1); ++r)
             pb.hess_prod_tape(v, o);
-    } else if (a.mode == 99) { // debug: tangent trajectory of both paths
-        pb.hess_prod(u, v, o);
-        double xt_d[8];
-        for (int k = 0; k < 8 && k <= a.N; ++k) xt_d[k] = pb.Xt[k * WAVE + lane];
-        pb.template psi_grad<true>(u, o2);
-        pb.hess_prod_tape(v, o);
-        double m = 0;
-        for (int k = 0; k < 8 && k <= a.N; ++k) m = fmax(m, fabs(xt_d[k] - pb.Xt[k * WAVE + lane]));
-        s1 = uniform(wave_max(lane < 57 ? m : 0.0));
     } else {
         pb.prox_grad_step(a.gamma, u, v, o, o2, s0, s1);
         s2 = pb.proj_grad_unit_norm(u, v);
@@ -792,11 +833,10 @@ __global__ __launch_bounds__(WAVE) void pantr_simulate_kernel(int B, const doubl
     if (inst >= B)
         return;
     typename M::Lane L(lane);
-    double s  = lane < M::nx ? x[(size_t)inst * M::nx + lane] : 0.0;
-    double uc = u[(size_t)inst * M::nu + L.uidx];
-    double r  = M::rk4(L, s, uc);
-    if (lane < M::nx)
-        xn[(size_t)inst * M::nx + lane] = r;
+    auto s  = M::load_x0(L, x + (size_t)inst * M::nx);
+    auto in = M::load_input(u + (size_t)inst * M::nu);
+    auto r  = M::rk4(L, s, in);
+    M::store_x(L, xn + (size_t)inst * M::nx, r);
 }
 
 } // namespace pantr

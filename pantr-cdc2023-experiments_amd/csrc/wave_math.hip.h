@@ -66,6 +66,20 @@ __device__ __forceinline__ dual lane_read(dual v, int src) {
     return {lane_read(v.v, src), lane_read(v.t, src)};
 }
 
+// DPP row shifts (VALU-speed cross-lane moves inside a 16-lane row; a lane whose source falls
+// outside the row reads 0).  row_from_prev: lane i gets lane i-1; row_from_next: lane i gets i+1.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo     = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi     = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_from_prev(double v) { return dpp_move<0x111>(v); } // row_shr:1
+__device__ __forceinline__ double row_from_next(double v) { return dpp_move<0x101>(v); } // row_shl:1
+__device__ __forceinline__ dual row_from_prev(dual v) { return {row_from_prev(v.v), row_from_prev(v.t)}; }
+__device__ __forceinline__ dual row_from_next(dual v) { return {row_from_next(v.v), row_from_next(v.t)}; }
+
 /// 64-lane butterfly all-reduce: masks 32, 16, 8, 4, 2, 1; a + partner at every level, so
 /// all lanes finish with bit-identical sums.
 __device__ __forceinline__ double wave_sum(double v) {
