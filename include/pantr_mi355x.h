@@ -128,10 +128,6 @@ int pantr_batch_eval_psi_grad_psi(pantr_batch_t *b, int32_t B, const double *x0,
                                   double *psi, double *grad);
 int pantr_batch_eval_hess_psi_prod(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
                                    const double *v, double *Hv);
-/* Same product through the dual-number sweep that recomputes every primal quantity (the
- * validation twin of the tape replay above; results are bit-identical). */
-int pantr_batch_eval_hess_psi_prod_dual(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
-                                        const double *v, double *Hv);
 /* scalars[B][4] = { p'p, grad'p, ||Pi_C(x-grad)-x||_inf, |J(gamma)| } */
 int pantr_batch_eval_prox_grad_step(pantr_batch_t *b, int32_t B, double gamma, const double *x,
                                     const double *grad, double *xhat, double *p, double *scalars);

@@ -270,35 +270,25 @@ struct Chain {
         }
     }
 
-    // ---- tape: record primal substage quantities once, replay tangents without dividing -----
-    // (the kernels' Hessian-vector path; must equal the dual-number sweep bit for bit)
+    // ---- tape: second-order information of one RK4 substage --------------------------------
+    // The Hessian-vector product the solver uses.  One gradient-like sweep at the current point
+    // records, per substage and per spring, the 3x3 matrices
+    //   K = dF/dd = c I + w d d^T                    (w = DL / r^3)
+    //   M = d(K lF)/dd = w [ lF d^T + d lF^T + (d.lF) (I - (3/n2) d d^T) ]
+    // (lF = adjoint force of the gradient sweep).  A product H v is then two linear sweeps over
+    // the tape: tangent forward  F_t = K d_t,  second-order adjoint  ld_t = K lF_t + M d_t.
+    // Association order and the explicit fma calls below are the specification the kernels
+    // follow bit for bit; eval_hess_psi_prod_dual (dual numbers) is the independent check.
+    static constexpr double hTs = 0.5 * Ts;
     struct TapeSub {
-        double d[NP][DIM], c[NP], h[NP], kq[NP], n2[NP], r[NP]; // springs
-        double lF[NP][DIM], dt[NP], w[NP], kw[NP], t[NP];       // adjoint
+        double K[NP][DIM][DIM], M[NP][DIM][DIM];
     };
     struct TapeStage {
         TapeSub sub[4];
     };
-    struct SpringsTan {
-        double d[NP][DIM], n2[NP], r[NP], c[NP];
-    };
 
-    static void tape_springs(const Springs<double> &sp, TapeSub &ts) {
-        for (int p = 0; p < NP; ++p) {
-            for (int c = 0; c < DIM; ++c)
-                ts.d[p][c] = sp.d[p][c];
-            double q = Lspring / sp.r[p];
-            ts.c[p]  = sp.c[p];
-            ts.h[p]  = 0.5 / sp.r[p];
-            ts.kq[p] = (-q) / sp.r[p];
-            ts.n2[p] = sp.n2[p];
-            ts.r[p]  = sp.r[p];
-        }
-    }
-
-    /// fc_adj on doubles that also fills the adjoint part of the tape.
+    /// fc_adj on doubles that also records K and M of the substage.
     static void fc_adj_record(const Springs<double> &sp, const double *kbar, double *abar, TapeSub &ts) {
-        tape_springs(sp, ts);
         double ld[NP][DIM];
         for (int p = 0; p < NP; ++p) {
             double lF[DIM], pr[DIM];
@@ -309,19 +299,27 @@ struct Chain {
                     lF[c] = inv_m * (kbar[VOFF + DIM * (p - 1) + c] - 0.0);
                 else
                     lF[c] = inv_m * (kbar[VOFF + DIM * (p - 1) + c] - kbar[VOFF + DIM * p + c]);
-                pr[c]       = sp.d[p][c] * lF[c];
-                ts.lF[p][c] = lF[c];
+                pr[c] = sp.d[p][c] * lF[c];
             }
             double dt  = (pr[0] + pr[1]) + pr[2];
             double n2r = sp.n2[p] * sp.r[p];
             double w   = DL / n2r;
             double t   = dt * w;
-            ts.dt[p] = dt;
-            ts.w[p]  = w;
-            ts.kw[p] = (-w) / n2r;
-            ts.t[p]  = t;
             for (int c = 0; c < DIM; ++c)
                 ld[p][c] = (sp.c[p] * lF[c]) + (t * sp.d[p][c]);
+            double e = 3.0 / sp.n2[p];
+            for (int c = 0; c < DIM; ++c) {
+                double wd = w * sp.d[p][c];
+                double g  = e * sp.d[p][c];
+                for (int c2 = 0; c2 < DIM; ++c2) {
+                    ts.K[p][c][c2] = std::fma(wd, sp.d[p][c2], c2 == c ? sp.c[p] : 0.0);
+                    double m       = lF[c] * sp.d[p][c2];
+                    m              = std::fma(sp.d[p][c], lF[c2], m);
+                    double kd      = std::fma(-g, sp.d[p][c2], c2 == c ? 1.0 : 0.0);
+                    m              = std::fma(dt, kd, m);
+                    ts.M[p][c][c2] = w * m;
+                }
+            }
         }
         for (int p = 0; p < NP; ++p)
             for (int c = 0; c < DIM; ++c)
@@ -330,7 +328,7 @@ struct Chain {
             abar[VOFF + l] = kbar[l];
     }
 
-    /// rk4_adj on doubles, recording the stage's tape.
+    /// rk4_adj on doubles, recording the stage's tape (same arithmetic as rk4_adj<double>).
     static void rk4_adj_record(const double *s, const double *u, const double *mu, double *sbar,
                                double *ubar, TapeStage &tp) {
         double k[nx], w[nx];
@@ -378,26 +376,20 @@ struct Chain {
         }
     }
 
-    static void springs_tan(const TapeSub &g, const double *s_t, SpringsTan &st) {
-        for (int p = 0; p < NP; ++p) {
-            double sq[DIM];
-            for (int c = 0; c < DIM; ++c) {
-                st.d[p][c] = p == 0 ? s_t[c] : s_t[DIM * p + c] - s_t[DIM * (p - 1) + c];
-                sq[c]      = (g.d[p][c] * st.d[p][c]) + (st.d[p][c] * g.d[p][c]);
-            }
-            st.n2[p]    = (sq[0] + sq[1]) + sq[2];
-            st.r[p]     = st.n2[p] * g.h[p];
-            double q_t  = st.r[p] * g.kq[p];
-            double om_t = 0.0 - q_t;
-            st.c[p]     = Dspring * om_t;
-        }
-    }
-    static void fc_tan(const TapeSub &g, const double *s_t, const double *u_t, double *ds_t, SpringsTan &st) {
-        springs_tan(g, s_t, st);
+    /// Tangent of f_c over the tape: d_t (kept for the adjoint sweep) and ds_t.
+    static void fc_tan(const TapeSub &g, const double *s_t, const double *u_t, double *ds_t,
+                       double (&d_t)[NP][DIM]) {
         double F[NP][DIM];
-        for (int p = 0; p < NP; ++p)
+        for (int p = 0; p < NP; ++p) {
             for (int c = 0; c < DIM; ++c)
-                F[p][c] = (g.d[p][c] * st.c[p]) + (st.d[p][c] * g.c[p]);
+                d_t[p][c] = s_t[DIM * p + c] - (p == 0 ? 0.0 : s_t[DIM * (p - 1) + c]);
+            for (int c = 0; c < DIM; ++c) {
+                double f = g.K[p][c][0] * d_t[p][0];
+                f        = std::fma(g.K[p][c][1], d_t[p][1], f);
+                f        = std::fma(g.K[p][c][2], d_t[p][2], f);
+                F[p][c]  = f;
+            }
+        }
         for (int l = 0; l < DIM * NB; ++l)
             ds_t[l] = s_t[VOFF + l];
         for (int c = 0; c < DIM; ++c)
@@ -406,23 +398,25 @@ struct Chain {
             for (int c = 0; c < DIM; ++c)
                 ds_t[VOFF + DIM * i + c] = inv_m * (F[i + 1][c] - F[i][c]);
     }
-    static void fc_adj_tan(const TapeSub &g, const SpringsTan &st, const double *kbar_t, double *abar_t) {
+    /// Tangent of the f_c adjoint over the tape.
+    static void fc_adj_tan(const TapeSub &g, const double (&d_t)[NP][DIM], const double *kbar_t, double *abar_t) {
         double ld[NP][DIM];
         for (int p = 0; p < NP; ++p) {
-            double lF[DIM], pr[DIM];
+            double lF[DIM];
             for (int c = 0; c < DIM; ++c) {
                 double A = p == 0 ? 0.0 : kbar_t[VOFF + DIM * (p - 1) + c];
                 double B = p == NP - 1 ? 0.0 : kbar_t[VOFF + DIM * p + c];
                 lF[c]    = inv_m * (A - B);
-                pr[c]    = (g.d[p][c] * lF[c]) + (st.d[p][c] * g.lF[p][c]);
             }
-            double dt  = (pr[0] + pr[1]) + pr[2];
-            double n2r = (g.n2[p] * st.r[p]) + (st.n2[p] * g.r[p]);
-            double w   = n2r * g.kw[p];
-            double t   = (g.dt[p] * w) + (dt * g.w[p]);
-            for (int c = 0; c < DIM; ++c)
-                ld[p][c] = ((g.c[p] * lF[c]) + (st.c[p] * g.lF[p][c])) +
-                           ((g.t[p] * st.d[p][c]) + (t * g.d[p][c]));
+            for (int c = 0; c < DIM; ++c) {
+                double v = g.K[p][c][0] * lF[0];
+                v        = std::fma(g.K[p][c][1], lF[1], v);
+                v        = std::fma(g.K[p][c][2], lF[2], v);
+                v        = std::fma(g.M[p][c][0], d_t[p][0], v);
+                v        = std::fma(g.M[p][c][1], d_t[p][1], v);
+                v        = std::fma(g.M[p][c][2], d_t[p][2], v);
+                ld[p][c] = v;
+            }
         }
         for (int p = 0; p < NP; ++p)
             for (int c = 0; c < DIM; ++c)
@@ -430,36 +424,30 @@ struct Chain {
         for (int l = 0; l < DIM * NB; ++l)
             abar_t[VOFF + l] = kbar_t[l];
     }
-    static void rk4_tan(const TapeStage &tp, const double *s_t, const double *u_t, double *xn_t) {
+    struct StageTan {
+        double d_t[4][NP][DIM];
+    };
+    static void rk4_tan(const TapeStage &tp, const double *s_t, const double *u_t, double *xn_t, StageTan &st) {
         double k1[nx], k2[nx], k3[nx], k4[nx], w[nx];
-        SpringsTan st;
-        fc_tan(tp.sub[0], s_t, u_t, k1, st);
+        fc_tan(tp.sub[0], s_t, u_t, k1, st.d_t[0]);
         for (int l = 0; l < nx; ++l)
-            w[l] = s_t[l] + 0.5 * (Ts * k1[l]);
-        fc_tan(tp.sub[1], w, u_t, k2, st);
+            w[l] = std::fma(hTs, k1[l], s_t[l]);
+        fc_tan(tp.sub[1], w, u_t, k2, st.d_t[1]);
         for (int l = 0; l < nx; ++l)
-            w[l] = s_t[l] + 0.5 * (Ts * k2[l]);
-        fc_tan(tp.sub[2], w, u_t, k3, st);
+            w[l] = std::fma(hTs, k2[l], s_t[l]);
+        fc_tan(tp.sub[2], w, u_t, k3, st.d_t[2]);
         for (int l = 0; l < nx; ++l)
-            w[l] = s_t[l] + Ts * k3[l];
-        fc_tan(tp.sub[3], w, u_t, k4, st);
-        for (int l = 0; l < nx; ++l)
-            xn_t[l] = s_t[l] + c6 * (((k1[l] + 2.0 * k2[l]) + 2.0 * k3[l]) + k4[l]);
+            w[l] = std::fma(Ts, k3[l], s_t[l]);
+        fc_tan(tp.sub[3], w, u_t, k4, st.d_t[3]);
+        for (int l = 0; l < nx; ++l) {
+            double t = std::fma(2.0, k2[l], k1[l]);
+            t        = std::fma(2.0, k3[l], t);
+            t        = t + k4[l];
+            xn_t[l]  = std::fma(c6, t, s_t[l]);
+        }
     }
-    static void rk4_adj_tan(const TapeStage &tp, const double *s_t, const double *u_t, const double *mu_t,
-                            double *sbar_t, double *ubar_t) {
-        double k[nx], w[nx];
-        SpringsTan st1, st2, st3, st4;
-        fc_tan(tp.sub[0], s_t, u_t, k, st1);
-        for (int l = 0; l < nx; ++l)
-            w[l] = s_t[l] + 0.5 * (Ts * k[l]);
-        fc_tan(tp.sub[1], w, u_t, k, st2);
-        for (int l = 0; l < nx; ++l)
-            w[l] = s_t[l] + 0.5 * (Ts * k[l]);
-        fc_tan(tp.sub[2], w, u_t, k, st3);
-        for (int l = 0; l < nx; ++l)
-            w[l] = s_t[l] + Ts * k[l];
-        springs_tan(tp.sub[3], w, st4);
+    static void rk4_adj_tan(const TapeStage &tp, const StageTan &st, const double *mu_t, double *sbar_t,
+                            double *ubar_t) {
         double kb1[nx], kb2[nx], kb3[nx], kb4[nx], a[nx];
         for (int l = 0; l < nx; ++l) {
             double sg = c6 * mu_t[l];
@@ -469,22 +457,22 @@ struct Chain {
             kb4[l] = sg;
             sbar_t[l] = mu_t[l];
         }
-        fc_adj_tan(tp.sub[3], st4, kb4, a);
+        fc_adj_tan(tp.sub[3], st.d_t[3], kb4, a);
         for (int l = 0; l < nx; ++l) {
             sbar_t[l] = sbar_t[l] + a[l];
-            kb3[l]    = kb3[l] + Ts * a[l];
+            kb3[l]    = std::fma(Ts, a[l], kb3[l]);
         }
-        fc_adj_tan(tp.sub[2], st3, kb3, a);
+        fc_adj_tan(tp.sub[2], st.d_t[2], kb3, a);
         for (int l = 0; l < nx; ++l) {
             sbar_t[l] = sbar_t[l] + a[l];
-            kb2[l]    = kb2[l] + 0.5 * (Ts * a[l]);
+            kb2[l]    = std::fma(hTs, a[l], kb2[l]);
         }
-        fc_adj_tan(tp.sub[1], st2, kb2, a);
+        fc_adj_tan(tp.sub[1], st.d_t[1], kb2, a);
         for (int l = 0; l < nx; ++l) {
             sbar_t[l] = sbar_t[l] + a[l];
-            kb1[l]    = kb1[l] + 0.5 * (Ts * a[l]);
+            kb1[l]    = std::fma(hTs, a[l], kb1[l]);
         }
-        fc_adj_tan(tp.sub[0], st1, kb1, a);
+        fc_adj_tan(tp.sub[0], st.d_t[0], kb1, a);
         for (int l = 0; l < nx; ++l)
             sbar_t[l] = sbar_t[l] + a[l];
         for (int c = 0; c < DIM; ++c) {
@@ -495,10 +483,10 @@ struct Chain {
     static void cost_grad_x_add_tan(const double *s_t, double *lam_t) {
         for (int c = 0; c < DIM; ++c) {
             int l    = DIM * NB + c;
-            lam_t[l] = lam_t[l] + c2a * s_t[l];
+            lam_t[l] = std::fma(c2a, s_t[l], lam_t[l]);
         }
         for (int l = VOFF; l < nx; ++l)
-            lam_t[l] = lam_t[l] + c2b * s_t[l];
+            lam_t[l] = std::fma(c2b, s_t[l], lam_t[l]);
     }
 
     /// Per-component cost contribution of one stage (hanging_chain.cpp:127-131): components
@@ -517,8 +505,8 @@ struct Chain {
     }
 
     /// Total of the per-component running sums: per chain point
-    /// ((((x0 + x1) + x2) + v0) + v1) + v2, then the 64-lane butterfly over the points
-    /// (the kernels hold one point per lane).
+    /// ((((x0 + x1) + x2) + v0) + v1) + v2, then the 64-lane butterfly with point p at lane 4p
+    /// (the kernels hold point p's components on lanes 4p..4p+2).
     static double cost_total(const double *acc /*[64], indexed like the state vector*/) {
         double part[64] = {};
         for (int p = 0; p < NP; ++p) {
@@ -527,7 +515,7 @@ struct Chain {
                 ax[c] = acc[DIM * p + c];
                 av[c] = p < NB ? acc[VOFF + DIM * p + c] : 0.0;
             }
-            part[p] = ((((ax[0] + ax[1]) + ax[2]) + av[0]) + av[1]) + av[2];
+            part[4 * p] = ((((ax[0] + ax[1]) + ax[2]) + av[0]) + av[1]) + av[2]; // lane of the point's component 0
         }
         return wave_sum(part);
     }
@@ -557,6 +545,8 @@ struct SingleShooting {
     int N;
     std::vector<double> x0; ///< problem parameter (initial state), mpc-driver.cpp:126
     mutable EvalCounters cnt;
+    mutable std::vector<typename Model::TapeStage> tape_; ///< second-order tape ...
+    mutable std::vector<double> tape_u_;                  ///< ... and the point it was recorded at
     static constexpr int nx = Model::nx, nu = Model::nu;
 
     explicit SingleShooting(int N_) : N(N_), x0(nx) { Model::initial_state(x0.data()); }
@@ -585,15 +575,23 @@ struct SingleShooting {
         return eval_f_impl(u, nullptr);
     }
 
-    /// psi and its gradient by a forward sweep + reverse (adjoint) sweep.
-    double psi_grad_impl(const double *u, double *grad) const {
+    /// psi and its gradient by a forward sweep + reverse (adjoint) sweep.  With record = true
+    /// the adjoint sweep also records the second-order tape at u (same gradient arithmetic).
+    double psi_grad_impl(const double *u, double *grad, bool record = false) const {
         std::vector<double> X((N + 1) * nx);
         double psi = eval_f_impl(u, X.data());
+        if (record) {
+            tape_.resize(N);
+            tape_u_.assign(u, u + n());
+        }
         double lam[nx] = {}, sbar[nx], ubar[nu];
         Model::cost_grad_x_add(X.data() + N * nx, lam);
         for (int k = N - 1; k >= 0; --k) {
             const double *s = X.data() + k * nx;
-            Model::rk4_adj(s, u + nu * k, lam, sbar, ubar);
+            if (record)
+                Model::rk4_adj_record(s, u + nu * k, lam, sbar, ubar, tape_[k]);
+            else
+                Model::rk4_adj(s, u + nu * k, lam, sbar, ubar);
             for (int c = 0; c < nu; ++c)
                 grad[nu * k + c] = ubar[c] + Model::c2g * u[nu * k + c];
             std::copy(sbar, sbar + nx, lam);
@@ -610,15 +608,17 @@ struct SingleShooting {
         psi_grad_impl(u, grad);
     }
     /// grad_L(x, y) with m = 0 is the gradient of f (formulation.hpp:98-99).
+    /// (PANTR evaluates it at the point its Hessian-vector products follow, so this is where
+    /// the second-order tape is recorded, as in the kernels.)
     void eval_grad_L(const double *u, double *grad) const {
         ++cnt.grad_L;
-        psi_grad_impl(u, grad);
+        psi_grad_impl(u, grad, /*record=*/true);
     }
 
     /// Hv = d/du (grad psi(u)^T v): forward-over-reverse with dual numbers
-    /// (formulation.hpp:93-97 builds the same product symbolically).
-    void eval_hess_psi_prod(const double *u, const double *v, double *Hv) const {
-        ++cnt.hess_psi_prod;
+    /// (formulation.hpp:93-97 builds the same product symbolically).  Independent check of
+    /// eval_hess_psi_prod below (agrees to rounding, not bit for bit).
+    void eval_hess_psi_prod_dual(const double *u, const double *v, double *Hv) const {
         std::vector<Dual> X((N + 1) * nx);
         Dual s[nx], xn[nx], ud[nu];
         for (int l = 0; l < nx; ++l)
@@ -647,37 +647,34 @@ struct SingleShooting {
         }
     }
 
-    /// The kernels' Hessian-vector path: record the tape at u (one gradient sweep), replay
-    /// tangents over it.  Must equal eval_hess_psi_prod bit for bit.
-    void eval_hess_psi_prod_tape(const double *u, const double *v, double *Hv) const {
-        std::vector<double> X((N + 1) * nx), grad(n());
-        eval_f_impl(u, X.data());
-        std::vector<typename Model::TapeStage> tape(N);
-        double lam[nx] = {}, sbar[nx], ubar[nu];
-        Model::cost_grad_x_add(X.data() + N * nx, lam);
-        for (int k = N - 1; k >= 0; --k) {
-            const double *s = X.data() + k * nx;
-            Model::rk4_adj_record(s, u + nu * k, lam, sbar, ubar, tape[k]);
-            std::copy(sbar, sbar + nx, lam);
-            Model::cost_grad_x_add(s, lam);
-        }
+    /// H v over a recorded tape: tangent forward sweep, second-order adjoint sweep.
+    void hess_prod_tape(const std::vector<typename Model::TapeStage> &tape, const double *v, double *Hv) const {
         std::vector<double> Xt((N + 1) * nx);
+        std::vector<typename Model::StageTan> st(N);
         double s_t[nx] = {}, xn_t[nx];
         for (int k = 0; k < N; ++k) {
             std::copy(s_t, s_t + nx, Xt.data() + k * nx);
-            Model::rk4_tan(tape[k], s_t, v + nu * k, xn_t);
+            Model::rk4_tan(tape[k], s_t, v + nu * k, xn_t, st[k]);
             std::copy(xn_t, xn_t + nx, s_t);
         }
         double lam_t[nx] = {}, sbar_t[nx], ubar_t[nu];
         Model::cost_grad_x_add_tan(s_t, lam_t);
         for (int k = N - 1; k >= 0; --k) {
-            const double *sk_t = Xt.data() + k * nx;
-            Model::rk4_adj_tan(tape[k], sk_t, v + nu * k, lam_t, sbar_t, ubar_t);
+            Model::rk4_adj_tan(tape[k], st[k], lam_t, sbar_t, ubar_t);
             for (int c = 0; c < nu; ++c)
-                Hv[nu * k + c] = ubar_t[c] + Model::c2g * v[nu * k + c];
+                Hv[nu * k + c] = std::fma(Model::c2g, v[nu * k + c], ubar_t[c]);
             std::copy(sbar_t, sbar_t + nx, lam_t);
-            Model::cost_grad_x_add_tan(sk_t, lam_t);
+            Model::cost_grad_x_add_tan(Xt.data() + k * nx, lam_t);
         }
+    }
+    /// The Hessian-vector product of the problem (formulation.hpp:93-97, 163-168).
+    void eval_hess_psi_prod(const double *u, const double *v, double *Hv) const {
+        ++cnt.hess_psi_prod;
+        if (tape_u_.size() != (size_t)n() || !std::equal(u, u + n(), tape_u_.begin())) {
+            std::vector<double> g(n()); // tape is for another point: record it here
+            psi_grad_impl(u, g.data(), /*record=*/true);
+        }
+        hess_prod_tape(tape_, v, Hv);
     }
 
     /// Box C = U^N (formulation.hpp:220-227).

@@ -140,38 +140,10 @@ void oracle_chain_hess_prod(int N, const double *x0, const double *u, const doub
     std::copy(x0, x0 + Chain::nx, p.x0.begin());
     p.eval_hess_psi_prod(u, v, Hv);
 }
-void oracle_chain_hess_prod_tape(int N, const double *x0, const double *u, const double *v, double *Hv) {
+void oracle_chain_hess_prod_dual(int N, const double *x0, const double *u, const double *v, double *Hv) {
     Prob p(N);
     std::copy(x0, x0 + Chain::nx, p.x0.begin());
-    p.eval_hess_psi_prod_tape(u, v, Hv);
-}
-/// Debug: the tape of the record pass in the kernels' row layout [k][j][g][lane32][4].
-void oracle_chain_tape(int N, const double *x0, const double *u, double *out) {
-    Prob p(N);
-    std::copy(x0, x0 + Chain::nx, p.x0.begin());
-    const int nx = Chain::nx, nu = Chain::nu;
-    std::vector<double> X((N + 1) * nx);
-    p.eval_f_impl(u, X.data());
-    double lam[Chain::nx] = {}, sbar[Chain::nx], ubar[Chain::nu];
-    Chain::cost_grad_x_add(X.data() + N * nx, lam);
-    for (int k = N - 1; k >= 0; --k) {
-        Chain::TapeStage tp;
-        const double *s = X.data() + k * nx;
-        Chain::rk4_adj_record(s, u + nu * k, lam, sbar, ubar, tp);
-        std::copy(sbar, sbar + nx, lam);
-        Chain::cost_grad_x_add(s, lam);
-        for (int j = 0; j < 4; ++j)
-            for (int l = 0; l < 30; ++l) {
-                int pt = l / 3, c = l % 3;
-                const Chain::TapeSub &g = tp.sub[j];
-                double *o = out + ((((size_t)k * 4 + j) * 3) * 32 + l) * 4;
-                o[0] = g.d[pt][c]; o[1] = g.c[pt]; o[2] = g.h[pt]; o[3] = g.kq[pt];
-                o += 32 * 4;
-                o[0] = g.n2[pt]; o[1] = g.r[pt]; o[2] = g.lF[pt][c]; o[3] = g.dt[pt];
-                o += 32 * 4;
-                o[0] = g.w[pt]; o[1] = g.kw[pt]; o[2] = g.t[pt]; o[3] = 0;
-            }
-    }
+    p.eval_hess_psi_prod_dual(u, v, Hv);
 }
 void oracle_chain_prox_grad_step(int N, double gamma, const double *x, const double *grad,
                                  double *xh, double *p, double *pTp, double *gradTp) {

@@ -1,4 +1,4 @@
-// Hanging-chain stage model for one 64-wide wavefront (gfx950), lane = chain point.
+// Hanging-chain stage model for one 64-wide wavefront (gfx950), lane = (chain point, component).
 //
 // What the reference computes (paths relative to /root/reference):
 //   constants ............ problems/problems/hanging_chain.cpp:28-42
@@ -7,17 +7,18 @@
 //   l, l_N ................ problems/problems/hanging_chain.cpp:127-132
 //   input box ............. problems/problems/hanging_chain.cpp:107-110
 //   initial state ......... problems/problems/hanging_chain.cpp:121-124
-// The reference turns these into straight-line scalar C through CasADi.  Here lane p (0..9)
-// owns chain point p: its three position components and, for the nine free masses p < 9, its
-// three velocity components (point 9 is the actuated end).  Consequences:
-//   * the 3-term norms and dot products of a spring are in-lane (no cross-lane traffic),
-//   * a neighbouring point is one lane away inside a 16-lane row: DPP row_shr:1 / row_shl:1
-//     moves it at VALU speed (no LDS crossbar round trip),
-//   * the three components give three independent fp64 chains per lane (ILP 3).
-// Lanes 10..63 idle through the sweeps (they take part in the decision-vector algebra).
-// The adjoint of f_c is hand-derived.  Second-order information: dual numbers on the same
-// templates (validation path) and, in the solver, a recorded tape of the primal substage
-// quantities replayed by division-free tangent sweeps (bit-identical to the dual path).
+// The reference turns these into straight-line scalar C through CasADi.  Here lane 4p+c
+// (p = 0..9, c = 0..2; lanes 4p+3 and 40..63 idle) owns component c of chain point p: its
+// position and, for the nine free masses p < 9, its velocity.  A lone wavefront issues one fp64
+// instruction per ~8 cycles whatever its ILP, so the layout minimises instructions:
+//   * one instruction handles a component of all ten points,
+//   * the three components of a point sit in one DPP quad: 3-term sums and broadcasts are
+//     quad_perm moves (VALU speed),
+//   * position and velocity of a point share a lane (no shuffle between them),
+//   * the only LDS-crossbar traffic is the neighbouring point (lane +-4), one ds_bpermute pair.
+// Second-order information (Hessian-vector products): the gradient sweep at the current point
+// records, per RK4 substage and spring, the 3x3 matrices K = dF/dd and M = d(K lF)/dd; a product
+// is then two linear sweeps of a few FMAs per substage over that tape.
 #pragma once
 #include "wave_math.hip.h"
 
@@ -28,7 +29,7 @@ struct ChainModel {
     static constexpr int nx = DIM * NP + DIM * NB; // 57
     static constexpr int nu = DIM;                 // 3
     static constexpr int VOFF = DIM * NP;          // velocities start at x0[30]
-    static constexpr double Ts = 0.1;
+    static constexpr double Ts = 0.1, hTs = 0.5 * Ts;
     static constexpr double alpha = 25, beta = 1, gamma = 0.01;
     static constexpr double mass = 0.03, Dspring = 0.1, Lspring = 0.033;
     static constexpr double v_max = 1, g_grav = 9.81;
@@ -46,265 +47,181 @@ struct ChainModel {
 
     /// Per-lane role.
     struct Lane {
-        int l;
-        bool active, mass, end; ///< lane < 10, lane < 9 (has a velocity), lane == 9
-        __device__ explicit Lane(int lane) : l(lane), active(lane < NP), mass(lane < NB), end(lane == NB) {}
+        int l, p, c, q; ///< lane, point, component, compact slot 3p+c (tape rows)
+        bool active, mass, end, first, lead, grav;
+        double xref;       ///< reference position of this component of the end point (1,0,0)
+        __device__ explicit Lane(int lane) {
+            l      = lane;
+            p      = lane >> 2;
+            c      = lane & 3;
+            active = lane < 4 * NP && c < DIM;
+            mass   = active && p < NB;
+            end    = active && p == NB;
+            first  = p == 0;
+            lead   = active && c == 0;
+            grav   = c == DIM - 1;
+            q      = active ? DIM * p + c : 31;
+            xref = c == 0 ? 1.0 : 0.0;
+        }
     };
 
-    /// State (or adjoint, or time derivative) of one chain point.
-    template <class T>
+    /// Component of the state (or adjoint, or time derivative) of one chain point.
     struct State {
-        T x[DIM], v[DIM];
+        double x, v;
     };
-    /// Stage input u_k, held by every lane (lane 9 uses it).
-    template <class T>
-    struct Input {
-        T u[DIM];
-    };
-    template <class T>
-    __device__ static __forceinline__ State<T> zero_state() {
-        State<T> s;
-#pragma unroll
-        for (int c = 0; c < DIM; ++c)
-            s.x[c] = s.v[c] = make_const<T>(0.0);
-        return s;
-    }
 
-    // ---- memory <-> registers -------------------------------------------------------------------
-    /// Initial state of this lane's point from the reference's state vector layout
-    /// [vec(x) (30); vec(v) (27)]  (hanging_chain.cpp:70-73).
-    __device__ static __forceinline__ State<double> load_x0(const Lane &L, const double *x0) {
-        State<double> s = zero_state<double>();
+    // ---- cross-lane ----------------------------------------------------------------------------
+    /// Value of component k of this lane's point (DPP quad_perm broadcast).
+    template <int K>
+    __device__ static __forceinline__ double qb(double v) {
+        constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo     = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false);
+        hi     = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false);
+        return __hiloint2double(hi, lo);
+    }
+    /// (v0 + v1) + v2 over the three components of this lane's point.
+    __device__ static __forceinline__ double quad_sum(double v) { return (qb<0>(v) + qb<1>(v)) + qb<2>(v); }
+    /// Same component of the previous / next point (0 before point 0; the value after point 9
+    /// is never used).
+    __device__ static __forceinline__ double prev_point(const Lane &L, double v) {
+        double r = lane_read(v, L.l - 4);
+        return L.first ? 0.0 : r;
+    }
+    __device__ static __forceinline__ double next_point(const Lane &L, double v) { return lane_read(v, L.l + 4); }
+
+    // ---- memory <-> registers ------------------------------------------------------------------
+    /// Initial state from the reference's state vector layout [vec(x) (30); vec(v) (27)]
+    /// (hanging_chain.cpp:70-73).
+    __device__ static __forceinline__ State load_x0(const Lane &L, const double *x0) {
+        State s{0.0, 0.0};
         if (L.active)
-#pragma unroll
-            for (int c = 0; c < DIM; ++c)
-                s.x[c] = x0[DIM * L.l + c];
+            s.x = x0[L.q];
         if (L.mass)
-#pragma unroll
-            for (int c = 0; c < DIM; ++c)
-                s.v[c] = x0[VOFF + DIM * L.l + c];
+            s.v = x0[VOFF + L.q];
         return s;
     }
-    __device__ static __forceinline__ void store_x(const Lane &L, double *x, const State<double> &s) {
+    __device__ static __forceinline__ void store_x(const Lane &L, double *x, const State &s) {
         if (L.active)
-#pragma unroll
-            for (int c = 0; c < DIM; ++c)
-                x[DIM * L.l + c] = s.x[c];
+            x[L.q] = s.x;
         if (L.mass)
-#pragma unroll
-            for (int c = 0; c < DIM; ++c)
-                x[VOFF + DIM * L.l + c] = s.v[c];
+            x[VOFF + L.q] = s.v;
     }
-    /// Trajectory rows in the HBM workspace: 6 components x 16 lanes of doubles per stage.
-    static constexpr int TRAJ_LANES   = 16;
-    static constexpr int TRAJ_DOUBLES = 2 * DIM * TRAJ_LANES; // 96 doubles = 768 B per stage
-    __device__ static __forceinline__ void traj_store(const Lane &L, double *row, const State<double> &s) {
-        if (L.l < TRAJ_LANES) {
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) {
-                row[c * TRAJ_LANES + L.l]         = s.x[c];
-                row[(DIM + c) * TRAJ_LANES + L.l] = s.v[c];
-            }
-        }
+    /// Trajectory rows in the HBM workspace: {x, v} per lane, 1 KiB per stage.
+    static constexpr int TRAJ_DOUBLES = 2 * WAVE;
+    __device__ static __forceinline__ void traj_store(const Lane &L, double *row, const State &s) {
+        reinterpret_cast<double2 *>(row)[L.l] = make_double2(s.x, s.v);
     }
-    __device__ static __forceinline__ State<double> traj_load(const Lane &L, const double *row) {
-        State<double> s = zero_state<double>();
-        if (L.l < TRAJ_LANES) {
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) {
-                s.x[c] = row[c * TRAJ_LANES + L.l];
-                s.v[c] = row[(DIM + c) * TRAJ_LANES + L.l];
-            }
-        }
-        return s;
+    __device__ static __forceinline__ State traj_load(const Lane &L, const double *row) {
+        double2 a = reinterpret_cast<const double2 *>(row)[L.l];
+        return {a.x, a.y};
     }
-    /// u_k from a decision vector in LDS (same address in every lane: a broadcast read).
-    __device__ static __forceinline__ Input<double> load_input(const double *u_k) {
-        return {{u_k[0], u_k[1], u_k[2]}};
+    /// This lane's component of u_k from a decision vector in LDS.
+    __device__ static __forceinline__ double load_input(const Lane &L, const double *u_k) {
+        return u_k[L.c < DIM ? L.c : DIM - 1];
     }
-    __device__ static __forceinline__ Input<dual> load_input(const double *u_k, const double *v_k) {
-        return {{{u_k[0], v_k[0]}, {u_k[1], v_k[1]}, {u_k[2], v_k[2]}}};
-    }
-    /// Lane 9 owns the adjoint of the stage input.
-    __device__ static __forceinline__ void store_input_grad(const Lane &L, double *g_k, const double (&g)[DIM]) {
+    /// The end point's lanes own the adjoint of the stage input.
+    __device__ static __forceinline__ void store_input_grad(const Lane &L, double *g_k, double g) {
         if (L.end)
-#pragma unroll
-            for (int c = 0; c < DIM; ++c)
-                g_k[c] = g[c];
+            g_k[L.c] = g;
     }
 
-    // ---- springs ---------------------------------------------------------------------------------
-    template <class T>
+    // ---- springs (primal) -------------------------------------------------------------------------
     struct Springs {
-        T d[DIM], n2, r, c;
+        double d, n2, r, c;
     };
-
-    /// dist_vect, its length and the spring coefficient of the spring ending at this point.
-    template <class T>
-    __device__ static __forceinline__ void springs(const State<T> &s, Springs<T> &sp) {
-#pragma unroll
-        for (int c = 0; c < DIM; ++c)
-            sp.d[c] = s.x[c] - row_from_prev(s.x[c]); // point 0 is anchored at the origin: x - 0
-        sp.n2 = (sp.d[0] * sp.d[0] + sp.d[1] * sp.d[1]) + sp.d[2] * sp.d[2];
-        sp.r  = wsqrt(sp.n2);
-        sp.c  = Dspring * (1.0 - Lspring / sp.r);
+    __device__ static __forceinline__ void springs(const Lane &L, const State &s, Springs &sp) {
+        sp.d      = s.x - prev_point(L, s.x); // point 0 is anchored at the origin: x - 0
+        double sq = sp.d * sp.d;
+        sp.n2     = quad_sum(sq);
+        sp.r      = __builtin_sqrt(sp.n2);
+        sp.c      = Dspring * (1.0 - Lspring / sp.r);
     }
-
     /// ds = f_c(s, u).
-    template <class T>
-    __device__ static __forceinline__ State<T> fc(const Lane &L, const State<T> &s, const Input<T> &in,
-                                                  Springs<T> &sp) {
-        const T zero = make_const<T>(0.0);
-        springs(s, sp);
-        State<T> ds;
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            T F  = sp.d[c] * sp.c;
-            T Fn = row_from_next(F); // force of the spring towards point p+1
-            T a  = inv_m * (Fn - F);
-            if (c == DIM - 1)
-                a = a - g_grav;
-            ds.x[c] = select(L.end, in.u[c], s.v[c]);
-            ds.v[c] = select(L.mass, a, zero);
-        }
-        return ds;
+    __device__ static __forceinline__ State fc(const Lane &L, const State &s, double uc, Springs &sp) {
+        springs(L, s, sp);
+        double F  = sp.d * sp.c;
+        double Fn = next_point(L, F); // force of the spring towards point p+1
+        double a  = inv_m * (Fn - F);
+        a         = L.grav ? a - g_grav : a;
+        return {L.end ? uc : s.v, L.mass ? a : 0.0};
     }
-
-    /// Intermediates of the f_c adjoint that the tape records.
-    template <class T>
     struct AdjAux {
-        T lF[DIM], dt, n2r, w, t;
+        double lF, dt, w;
     };
-
-    /// Adjoint of f_c: kbar = adjoint of ds, returns the adjoint of s; the adjoint of u is
-    /// kbar.x on lane 9.
-    template <class T>
-    __device__ static __forceinline__ State<T> fc_adj(const Lane &L, const Springs<T> &sp,
-                                                      const State<T> &kbar, AdjAux<T> &ax) {
-        const T zero = make_const<T>(0.0);
-        T pr[DIM];
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            T A      = row_from_prev(kbar.v[c]);        // adjoint of a_{p-1} (0 for point 0)
-            T B      = select(L.mass, kbar.v[c], zero); // adjoint of a_p (none for point 9)
-            ax.lF[c] = inv_m * (A - B);
-            pr[c]    = sp.d[c] * ax.lF[c];
-        }
-        ax.dt  = (pr[0] + pr[1]) + pr[2];
-        ax.n2r = sp.n2 * sp.r;
-        ax.w   = DL / ax.n2r;
-        ax.t   = ax.dt * ax.w;
-        State<T> ab;
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            T ld    = (sp.c * ax.lF[c]) + (ax.t * sp.d[c]);
-            T ldn   = row_from_next(ld);
-            ab.x[c] = select(L.end, ld, ld - ldn);
-            ab.v[c] = select(L.mass, kbar.x[c], zero);
-        }
-        return ab;
-    }
-
-    template <class T>
-    __device__ static __forceinline__ State<T> axpy(double a, const State<T> &k, const State<T> &s) {
-        State<T> w;
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            w.x[c] = s.x[c] + a * k.x[c];
-            w.v[c] = s.v[c] + a * k.v[c];
-        }
-        return w;
-    }
-    /// s + 0.5 (Ts k)   (formulation.hpp:24-25: state + Ts * k / 2)
-    template <class T>
-    __device__ static __forceinline__ State<T> half_step(const State<T> &s, const State<T> &k) {
-        State<T> w;
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            w.x[c] = s.x[c] + 0.5 * (Ts * k.x[c]);
-            w.v[c] = s.v[c] + 0.5 * (Ts * k.v[c]);
-        }
-        return w;
+    /// Adjoint of f_c: kbar = adjoint of ds, returns the adjoint of s; the adjoint of u is kbar.x
+    /// on the end point's lanes.
+    __device__ static __forceinline__ State fc_adj(const Lane &L, const Springs &sp, const State &kbar, AdjAux &ax) {
+        double A   = prev_point(L, kbar.v);   // adjoint of a_{p-1} (0 for point 0)
+        double B   = L.mass ? kbar.v : 0.0;   // adjoint of a_p (none for point 9)
+        ax.lF      = inv_m * (A - B);
+        double pr  = sp.d * ax.lF;
+        ax.dt      = quad_sum(pr);
+        double n2r = sp.n2 * sp.r;
+        ax.w       = DL / n2r;
+        double t   = ax.dt * ax.w;
+        double ld  = (sp.c * ax.lF) + (t * sp.d);
+        double ldn = next_point(L, ld);
+        return {L.end ? ld : ld - ldn, L.mass ? kbar.x : 0.0};
     }
 
     /// One RK4 step of the plant (formulation.hpp:21-28).
-    template <class T>
-    __device__ static __forceinline__ State<T> rk4(const Lane &L, const State<T> &s, const Input<T> &in) {
-        Springs<T> sp;
-        State<T> k1 = fc(L, s, in, sp);
-        State<T> k2 = fc(L, half_step(s, k1), in, sp);
-        State<T> k3 = fc(L, half_step(s, k2), in, sp);
-        State<T> k4 = fc(L, axpy(Ts, k3, s), in, sp);
-        State<T> xn;
+    __device__ static __forceinline__ State rk4(const Lane &L, const State &s, double uc) {
+        Springs sp;
+        State k1 = fc(L, s, uc, sp);
+        State k2 = fc(L, {s.x + 0.5 * (Ts * k1.x), s.v + 0.5 * (Ts * k1.v)}, uc, sp);
+        State k3 = fc(L, {s.x + 0.5 * (Ts * k2.x), s.v + 0.5 * (Ts * k2.v)}, uc, sp);
+        State k4 = fc(L, {s.x + Ts * k3.x, s.v + Ts * k3.v}, uc, sp);
+        return {s.x + c6 * (((k1.x + 2.0 * k2.x) + 2.0 * k3.x) + k4.x),
+                s.v + c6 * (((k1.v + 2.0 * k2.v) + 2.0 * k3.v) + k4.v)};
+    }
+
+    // ---- the tape ------------------------------------------------------------------------------
+    // Per substage j and lane (p,c): row c of K = c I + w d d^T and of
+    // M = w [ lF d^T + d lF^T + dt (I - (3/n2) d d^T) ]: six doubles, stored in compact slot
+    // q = 3p+c (32 slots x 16 B = 512 B per row) as A = {K0,K1}, B = {K2,M0}, C = {M1,M2}.
+    // Stage layout in HBM (6 KiB): [j = 0..3: A row, B row] (4 KiB, all the forward sweep needs,
+    // one LDS-DMA instruction per substage) then [C rows of j = 0..3] (2 KiB).
+    // The forward sweep of each product writes its tangent spring vectors d_t to a second tape
+    // ("st": [j][32 slots] doubles, 1 KiB per stage) that its adjoint sweep streams back.
+    static constexpr int TAPE_STAGE_BYTES  = 6144;
+    static constexpr int ST_STAGE_BYTES    = 1024;
+    static constexpr int LDS_STAGE_BYTES   = TAPE_STAGE_BYTES + ST_STAGE_BYTES;
+    static constexpr int TAPE_D4_PER_STAGE = TAPE_STAGE_BYTES / 32;
+    static constexpr int ST_D4_PER_STAGE   = ST_STAGE_BYTES / 32;
+
+    __device__ static __forceinline__ void tape_store(const Lane &L, double4 *stage, int j, const Springs &sp,
+                                                      const AdjAux &ax) {
+        const double d0 = qb<0>(sp.d), d1 = qb<1>(sp.d), d2 = qb<2>(sp.d);
+        const double l0 = qb<0>(ax.lF), l1 = qb<1>(ax.lF), l2 = qb<2>(ax.lF);
+        const double dq[DIM] = {d0, d1, d2}, lq[DIM] = {l0, l1, l2};
+        const double e  = 3.0 / sp.n2;
+        const double wd = ax.w * sp.d;
+        const double g  = e * sp.d;
+        double K[DIM], M[DIM];
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            xn.x[c] = s.x[c] + c6 * (((k1.x[c] + 2.0 * k2.x[c]) + 2.0 * k3.x[c]) + k4.x[c]);
-            xn.v[c] = s.v[c] + c6 * (((k1.v[c] + 2.0 * k2.v[c]) + 2.0 * k3.v[c]) + k4.v[c]);
+        for (int c2 = 0; c2 < DIM; ++c2) {
+            K[c2]     = __builtin_fma(wd, dq[c2], L.c == c2 ? sp.c : 0.0);
+            double m  = ax.lF * dq[c2];
+            m         = __builtin_fma(sp.d, lq[c2], m);
+            double kd = __builtin_fma(-g, dq[c2], L.c == c2 ? 1.0 : 0.0);
+            m         = __builtin_fma(ax.dt, kd, m);
+            M[c2]     = ax.w * m;
         }
-        return xn;
-    }
-
-    // ---- the tape: primal quantities of one RK4 substage, recorded once per PANTR iteration ----
-    // Per substage, four groups of four doubles per lane (16 lanes; lanes 0..9 matter):
-    //   G0 = {d0, d1, d2, c}     dist_vect, c = D (1 - L/r)
-    //   G1 = {h, kq, n2, r}      h = 0.5/r, kq = (-(L/r))/r, squared length, length
-    //   G2 = {lF0, lF1, lF2, dt} adjoint force, dt = d.lF
-    //   G3 = {w, kw, t, -}       w = DL/(n2 r), kw = (-w)/(n2 r), t = dt w
-    // HBM layout: tape[((k*4 + j)*4 + g)*16 + lane] as double4: 512 B per group row, 2 KiB per
-    // substage, 8 KiB per stage.  G0,G1 of a substage are one contiguous KiB (= one LDS-DMA
-    // instruction), G2,G3 the next.
-    // The tangent spring quantities of a Hessian-vector product's forward sweep go to a second,
-    // per-product tape ("st"): T0 = {d0_t, d1_t, d2_t, n2_t}, T1 = {r_t, c_t, -, -}: 1 KiB per
-    // substage, 4 KiB per stage; its adjoint sweep reads them back instead of recomputing.
-    static constexpr int TAPE_GROUPS       = 4;
-    static constexpr int TAPE_LANES        = 16;
-    static constexpr int TAPE_D4_PER_STAGE = 4 * TAPE_GROUPS * TAPE_LANES; // 256 double4 = 8 KiB
-    static constexpr int ST_GROUPS         = 2;
-    static constexpr int ST_D4_PER_STAGE   = 4 * ST_GROUPS * TAPE_LANES;   // 128 double4 = 4 KiB
-    static constexpr int TAPE_STAGE_BYTES  = TAPE_D4_PER_STAGE * 32;
-    static constexpr int ST_STAGE_BYTES    = ST_D4_PER_STAGE * 32;
-    static constexpr int LDS_STAGE_BYTES   = TAPE_STAGE_BYTES + ST_STAGE_BYTES; // one landing buffer
-
-    struct TapeFwd {
-        double d[DIM], c, h, kq;
-    };
-    struct TapeRev {
-        double d[DIM], c, n2, r, lF[DIM], dt, w, kw, t;
-    };
-    struct SpringsTan {
-        double d[DIM], n2, r, c;
-    };
-
-    __device__ static __forceinline__ void tape_store(const Lane &L, double4 *stage, int j,
-                                                      const Springs<double> &sp, const AdjAux<double> &ax) {
-        if (L.l < TAPE_LANES) {
-            double q  = Lspring / sp.r; // the same quotient springs() forms
-            double h  = 0.5 / sp.r;
-            double kq = (-q) / sp.r;
-            double kw = (-ax.w) / ax.n2r;
-            double4 *p = stage + (j * TAPE_GROUPS) * TAPE_LANES + L.l;
-            p[0]              = make_double4(sp.d[0], sp.d[1], sp.d[2], sp.c);
-            p[TAPE_LANES]     = make_double4(h, kq, sp.n2, sp.r);
-            p[2 * TAPE_LANES] = make_double4(ax.lF[0], ax.lF[1], ax.lF[2], ax.dt);
-            p[3 * TAPE_LANES] = make_double4(ax.w, kw, ax.t, 0.0);
+        if (L.active) {
+            char *base = reinterpret_cast<char *>(stage);
+            *reinterpret_cast<double2 *>(base + j * 1024 + L.q * 16)        = make_double2(K[0], K[1]);
+            *reinterpret_cast<double2 *>(base + j * 1024 + 512 + L.q * 16)  = make_double2(K[2], M[0]);
+            *reinterpret_cast<double2 *>(base + 4096 + j * 512 + L.q * 16)  = make_double2(M[1], M[2]);
         }
     }
-    __device__ static __forceinline__ void st_store(const Lane &L, double4 *stage, int j, const SpringsTan &st) {
-        if (L.l < TAPE_LANES) {
-            double4 *p    = stage + (j * ST_GROUPS) * TAPE_LANES + L.l;
-            p[0]          = make_double4(st.d[0], st.d[1], st.d[2], st.n2);
-            p[TAPE_LANES] = make_double4(st.r, st.c, 0.0, 0.0);
-        }
-    }
-
-    /// Start the LDS-DMA of one stage into the landing buffer `buf`: the forward sweep needs the
-    /// G0,G1 KiB of each substage (4 instructions); the adjoint sweep all 8 KiB of the tape plus
-    /// the 4 KiB of the product's own tangent tape (12 instructions).
+    /// Start the LDS-DMA of one stage into the landing buffer `buf`: 4 KiB (K rows) for the
+    /// forward sweep; 6 KiB of tape + 1 KiB of tangent tape for the adjoint sweep.
     __device__ static __forceinline__ void prefetch_fwd(const Lane &L, const double4 *tape_stage, char *buf) {
         const char *src = reinterpret_cast<const char *>(tape_stage) + L.l * 16;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            lds_dma_row(src + j * 2048, buf + j * 2048);
+        for (int i = 0; i < 4; ++i)
+            lds_dma_row(src + i * 1024, buf + i * 1024);
     }
     __device__ static __forceinline__ void prefetch_rev(const Lane &L, const double4 *tape_stage,
                                                         const double4 *st_stage, char *buf) {
@@ -312,252 +229,161 @@ struct ChainModel {
 #pragma unroll
         for (int i = 0; i < TAPE_STAGE_BYTES / 1024; ++i)
             lds_dma_row(src + i * 1024, buf + i * 1024);
-        const char *src2 = reinterpret_cast<const char *>(st_stage) + L.l * 16;
-#pragma unroll
-        for (int i = 0; i < ST_STAGE_BYTES / 1024; ++i)
-            lds_dma_row(src2 + i * 1024, buf + TAPE_STAGE_BYTES + i * 1024);
+        lds_dma_row(reinterpret_cast<const char *>(st_stage) + L.l * 16, buf + TAPE_STAGE_BYTES);
     }
-    __device__ static __forceinline__ TapeFwd tape_fwd(const Lane &L, const char *buf, int j) {
-        const double4 *p = reinterpret_cast<const double4 *>(buf) + (j * TAPE_GROUPS) * TAPE_LANES + (L.l & 15);
-        double4 a = p[0], b = p[TAPE_LANES];
-        return {{a.x, a.y, a.z}, a.w, b.x, b.y};
+    struct TapeK {
+        double K[DIM];
+    };
+    struct TapeKM {
+        double K[DIM], M[DIM], D[DIM]; ///< D = d_t of this lane's point (from the tangent tape)
+    };
+    __device__ static __forceinline__ TapeK tape_fwd(const Lane &L, const char *buf, int j) {
+        double2 a = *reinterpret_cast<const double2 *>(buf + j * 1024 + L.q * 16);
+        double2 b = *reinterpret_cast<const double2 *>(buf + j * 1024 + 512 + L.q * 16);
+        return {{a.x, a.y, b.x}};
     }
-    __device__ static __forceinline__ TapeRev tape_rev(const Lane &L, const char *buf, int j) {
-        const double4 *p = reinterpret_cast<const double4 *>(buf) + (j * TAPE_GROUPS) * TAPE_LANES + (L.l & 15);
-        double4 a = p[0], b = p[TAPE_LANES], c = p[2 * TAPE_LANES], d = p[3 * TAPE_LANES];
-        return {{a.x, a.y, a.z}, a.w, b.z, b.w, {c.x, c.y, c.z}, c.w, d.x, d.y, d.z};
-    }
-    __device__ static __forceinline__ SpringsTan st_rev(const Lane &L, const char *buf, int j) {
-        const double4 *p = reinterpret_cast<const double4 *>(buf + TAPE_STAGE_BYTES) +
-                           (j * ST_GROUPS) * TAPE_LANES + (L.l & 15);
-        double4 a = p[0], b = p[TAPE_LANES];
-        return {{a.x, a.y, a.z}, a.w, b.x, b.y};
-    }
-
-    /// Tangent of springs(): the .t parts of the dual evaluation, primal values from the tape.
-    __device__ static __forceinline__ void springs_tan(const TapeFwd &g, const State<double> &s_t, SpringsTan &st) {
-        double sq[DIM];
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            st.d[c] = s_t.x[c] - row_from_prev(s_t.x[c]);
-            sq[c]   = (g.d[c] * st.d[c]) + (st.d[c] * g.d[c]);
-        }
-        st.n2       = (sq[0] + sq[1]) + sq[2];
-        st.r        = st.n2 * g.h;
-        double q_t  = st.r * g.kq;
-        double om_t = 0.0 - q_t;
-        st.c        = Dspring * om_t;
+    __device__ static __forceinline__ TapeKM tape_rev(const Lane &L, const char *buf, int j) {
+        double2 a = *reinterpret_cast<const double2 *>(buf + j * 1024 + L.q * 16);
+        double2 b = *reinterpret_cast<const double2 *>(buf + j * 1024 + 512 + L.q * 16);
+        double2 c = *reinterpret_cast<const double2 *>(buf + 4096 + j * 512 + L.q * 16);
+        const double *st = reinterpret_cast<const double *>(buf + TAPE_STAGE_BYTES + j * 256) + (L.q - L.c);
+        return {{a.x, a.y, b.x}, {b.y, c.x, c.y}, {st[0], st[1], st[2]}};
     }
 
-    /// Tangent of f_c.
-    __device__ static __forceinline__ State<double> fc_tan(const Lane &L, const TapeFwd &g, const State<double> &s_t,
-                                                           const Input<double> &in_t, SpringsTan &st) {
-        springs_tan(g, s_t, st);
-        State<double> ds;
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            double F  = (g.d[c] * st.c) + (st.d[c] * g.c);
-            double Fn = row_from_next(F);
-            double a  = inv_m * (Fn - F);
-            ds.x[c]   = L.end ? in_t.u[c] : s_t.v[c];
-            ds.v[c]   = L.mass ? a : 0.0;
-        }
-        return ds;
+    // ---- tangent sweeps over the tape ---------------------------------------------------------------
+    /// Tangent of f_c: F_t = K d_t.  Writes d_t to the tangent tape.
+    __device__ static __forceinline__ State fc_tan(const Lane &L, const TapeK &g, const State &s_t, double uc_t,
+                                                   double4 *st_stage, int j) {
+        double d_t = s_t.x - prev_point(L, s_t.x);
+        if (L.active)
+            reinterpret_cast<double *>(reinterpret_cast<char *>(st_stage) + j * 256)[L.q] = d_t;
+        double F  = g.K[0] * qb<0>(d_t);
+        F         = __builtin_fma(g.K[1], qb<1>(d_t), F);
+        F         = __builtin_fma(g.K[2], qb<2>(d_t), F);
+        double Fn = next_point(L, F);
+        double a  = inv_m * (Fn - F);
+        return {L.end ? uc_t : s_t.v, L.mass ? a : 0.0};
+    }
+    /// Tangent of the f_c adjoint: ld_t = K lF_t + M d_t.
+    __device__ static __forceinline__ State fc_adj_tan(const Lane &L, const TapeKM &g, const State &kbar_t) {
+        double A   = prev_point(L, kbar_t.v);
+        double B   = L.mass ? kbar_t.v : 0.0;
+        double lF  = inv_m * (A - B);
+        double ld  = g.K[0] * qb<0>(lF);
+        ld         = __builtin_fma(g.K[1], qb<1>(lF), ld);
+        ld         = __builtin_fma(g.K[2], qb<2>(lF), ld);
+        ld         = __builtin_fma(g.M[0], g.D[0], ld);
+        ld         = __builtin_fma(g.M[1], g.D[1], ld);
+        ld         = __builtin_fma(g.M[2], g.D[2], ld);
+        double ldn = next_point(L, ld);
+        return {L.end ? ld : ld - ldn, L.mass ? kbar_t.x : 0.0};
+    }
+    /// Tangent of one RK4 step; the stage's K rows are in LDS at `buf`.
+    __device__ static __forceinline__ State rk4_tan(const Lane &L, const char *buf, const State &s_t, double uc_t,
+                                                    double4 *st_stage) {
+        State k1 = fc_tan(L, tape_fwd(L, buf, 0), s_t, uc_t, st_stage, 0);
+        State k2 = fc_tan(L, tape_fwd(L, buf, 1),
+                          {__builtin_fma(hTs, k1.x, s_t.x), __builtin_fma(hTs, k1.v, s_t.v)}, uc_t, st_stage, 1);
+        State k3 = fc_tan(L, tape_fwd(L, buf, 2),
+                          {__builtin_fma(hTs, k2.x, s_t.x), __builtin_fma(hTs, k2.v, s_t.v)}, uc_t, st_stage, 2);
+        State k4 = fc_tan(L, tape_fwd(L, buf, 3),
+                          {__builtin_fma(Ts, k3.x, s_t.x), __builtin_fma(Ts, k3.v, s_t.v)}, uc_t, st_stage, 3);
+        double tx = __builtin_fma(2.0, k2.x, k1.x), tv = __builtin_fma(2.0, k2.v, k1.v);
+        tx        = __builtin_fma(2.0, k3.x, tx);
+        tv        = __builtin_fma(2.0, k3.v, tv);
+        tx        = tx + k4.x;
+        tv        = tv + k4.v;
+        return {__builtin_fma(c6, tx, s_t.x), __builtin_fma(c6, tv, s_t.v)};
+    }
+    /// Tangent of the RK4 adjoint (second-order adjoint).  ubar_t is valid on the end point's lanes.
+    __device__ static __forceinline__ void rk4_adj_tan(const Lane &L, const char *buf, const State &mu_t,
+                                                       State &sbar_t, double &ubar_t) {
+        double sgx = c6 * mu_t.x, sgv = c6 * mu_t.v;
+        State kb1{sgx, sgv}, kb2{2.0 * sgx, 2.0 * sgv}, kb3{2.0 * sgx, 2.0 * sgv}, kb4{sgx, sgv};
+        sbar_t  = mu_t;
+        State a = fc_adj_tan(L, tape_rev(L, buf, 3), kb4);
+        sbar_t  = {sbar_t.x + a.x, sbar_t.v + a.v};
+        kb3     = {__builtin_fma(Ts, a.x, kb3.x), __builtin_fma(Ts, a.v, kb3.v)};
+        a       = fc_adj_tan(L, tape_rev(L, buf, 2), kb3);
+        sbar_t  = {sbar_t.x + a.x, sbar_t.v + a.v};
+        kb2     = {__builtin_fma(hTs, a.x, kb2.x), __builtin_fma(hTs, a.v, kb2.v)};
+        a       = fc_adj_tan(L, tape_rev(L, buf, 1), kb2);
+        sbar_t  = {sbar_t.x + a.x, sbar_t.v + a.v};
+        kb1     = {__builtin_fma(hTs, a.x, kb1.x), __builtin_fma(hTs, a.v, kb1.v)};
+        a       = fc_adj_tan(L, tape_rev(L, buf, 0), kb1);
+        sbar_t  = {sbar_t.x + a.x, sbar_t.v + a.v};
+        ubar_t  = ((kb4.x + kb3.x) + kb2.x) + kb1.x;
     }
 
-    /// Tangent of the f_c adjoint.
-    __device__ static __forceinline__ State<double> fc_adj_tan(const Lane &L, const TapeRev &g, const SpringsTan &st,
-                                                               const State<double> &kbar_t) {
-        double lF[DIM], pr[DIM];
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            double A = row_from_prev(kbar_t.v[c]);
-            double B = L.mass ? kbar_t.v[c] : 0.0;
-            lF[c]    = inv_m * (A - B);
-            pr[c]    = (g.d[c] * lF[c]) + (st.d[c] * g.lF[c]);
-        }
-        double dt  = (pr[0] + pr[1]) + pr[2];
-        double n2r = (g.n2 * st.r) + (st.n2 * g.r);
-        double w   = n2r * g.kw;
-        double t   = (g.dt * w) + (dt * g.w);
-        State<double> ab;
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            double ld  = ((g.c * lF[c]) + (st.c * g.lF[c])) + ((g.t * st.d[c]) + (t * g.d[c]));
-            double ldn = row_from_next(ld);
-            ab.x[c]    = L.end ? ld : ld - ldn;
-            ab.v[c]    = L.mass ? kbar_t.x[c] : 0.0;
-        }
-        return ab;
+    /// Adjoint of one RK4 step.  mu = adjoint of x_next; sbar = adjoint of s; ubar (valid on the
+    /// end point's lanes) = adjoint of u through the dynamics.  With tape_stage != nullptr the
+    /// K and M rows of the four substages are recorded.
+    __device__ static __forceinline__ void rk4_adj(const Lane &L, const State &s, double uc, const State &mu,
+                                                   State &sbar, double &ubar, double4 *tape_stage = nullptr) {
+        Springs sp1, sp2, sp3, sp4;
+        AdjAux ax;
+        State k = fc(L, s, uc, sp1);
+        k       = fc(L, {s.x + 0.5 * (Ts * k.x), s.v + 0.5 * (Ts * k.v)}, uc, sp2);
+        k       = fc(L, {s.x + 0.5 * (Ts * k.x), s.v + 0.5 * (Ts * k.v)}, uc, sp3);
+        springs(L, {s.x + Ts * k.x, s.v + Ts * k.v}, sp4);
+
+        double sgx = c6 * mu.x, sgv = c6 * mu.v;
+        State kb1{sgx, sgv}, kb2{2.0 * sgx, 2.0 * sgv}, kb3{2.0 * sgx, 2.0 * sgv}, kb4{sgx, sgv};
+        sbar    = mu;
+        State a = fc_adj(L, sp4, kb4, ax);
+        if (tape_stage)
+            tape_store(L, tape_stage, 3, sp4, ax);
+        sbar = {sbar.x + a.x, sbar.v + a.v};
+        kb3  = {kb3.x + Ts * a.x, kb3.v + Ts * a.v};
+        a    = fc_adj(L, sp3, kb3, ax);
+        if (tape_stage)
+            tape_store(L, tape_stage, 2, sp3, ax);
+        sbar = {sbar.x + a.x, sbar.v + a.v};
+        kb2  = {kb2.x + 0.5 * (Ts * a.x), kb2.v + 0.5 * (Ts * a.v)};
+        a    = fc_adj(L, sp2, kb2, ax);
+        if (tape_stage)
+            tape_store(L, tape_stage, 1, sp2, ax);
+        sbar = {sbar.x + a.x, sbar.v + a.v};
+        kb1  = {kb1.x + 0.5 * (Ts * a.x), kb1.v + 0.5 * (Ts * a.v)};
+        a    = fc_adj(L, sp1, kb1, ax);
+        if (tape_stage)
+            tape_store(L, tape_stage, 0, sp1, ax);
+        sbar = {sbar.x + a.x, sbar.v + a.v};
+        ubar = ((kb4.x + kb3.x) + kb2.x) + kb1.x;
     }
 
-    /// Tangent of one RK4 step; the stage's tape rows are in LDS at `buf`; the tangent spring
-    /// quantities of the four substages are written to `st_stage` for the adjoint sweep.
-    __device__ static __forceinline__ State<double> rk4_tan(const Lane &L, const char *buf, const State<double> &s_t,
-                                                            const Input<double> &in_t, double4 *st_stage) {
-        SpringsTan st;
-        State<double> k1 = fc_tan(L, tape_fwd(L, buf, 0), s_t, in_t, st);
-        st_store(L, st_stage, 0, st);
-        State<double> k2 = fc_tan(L, tape_fwd(L, buf, 1), half_step(s_t, k1), in_t, st);
-        st_store(L, st_stage, 1, st);
-        State<double> k3 = fc_tan(L, tape_fwd(L, buf, 2), half_step(s_t, k2), in_t, st);
-        st_store(L, st_stage, 2, st);
-        State<double> k4 = fc_tan(L, tape_fwd(L, buf, 3), axpy(Ts, k3, s_t), in_t, st);
-        st_store(L, st_stage, 3, st);
-        State<double> xn;
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            xn.x[c] = s_t.x[c] + c6 * (((k1.x[c] + 2.0 * k2.x[c]) + 2.0 * k3.x[c]) + k4.x[c]);
-            xn.v[c] = s_t.v[c] + c6 * (((k1.v[c] + 2.0 * k2.v[c]) + 2.0 * k3.v[c]) + k4.v[c]);
-        }
-        return xn;
-    }
-
-    template <class T>
-    __device__ static __forceinline__ void adj_chain_init(const State<T> &mu, State<T> &kb1, State<T> &kb2,
-                                                          State<T> &kb3, State<T> &kb4, State<T> &sbar) {
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            T sx = c6 * mu.x[c], sv = c6 * mu.v[c];
-            kb1.x[c] = sx; kb2.x[c] = 2.0 * sx; kb3.x[c] = 2.0 * sx; kb4.x[c] = sx;
-            kb1.v[c] = sv; kb2.v[c] = 2.0 * sv; kb3.v[c] = 2.0 * sv; kb4.v[c] = sv;
-            sbar.x[c] = mu.x[c];
-            sbar.v[c] = mu.v[c];
+    // ---- cost (hanging_chain.cpp:127-131) ---------------------------------------------------------
+    /// Per-component running sums: the end point's lanes add alpha (x_end - ref)^2 then gamma u^2
+    /// to acc.x, the masses' lanes add beta v^2 to acc.v.
+    __device__ static __forceinline__ void cost_accumulate(const Lane &L, const State &s, double uc, bool has_u,
+                                                           State &acc) {
+        double t  = s.x - L.xref;
+        double a1 = alpha * (t * t);
+        double b1 = beta * (s.v * s.v);
+        acc.x     = L.end ? acc.x + a1 : acc.x;
+        acc.v     = L.mass ? acc.v + b1 : acc.v;
+        if (has_u) {
+            double a2 = gamma * (uc * uc);
+            acc.x     = L.end ? acc.x + a2 : acc.x;
         }
     }
-    template <class T>
-    __device__ static __forceinline__ void add_to(State<T> &s, const State<T> &a) {
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            s.x[c] = s.x[c] + a.x[c];
-            s.v[c] = s.v[c] + a.v[c];
-        }
-    }
-    template <class T>
-    __device__ static __forceinline__ void add_scaled_full(State<T> &kb, const State<T> &a) { // kb + Ts a
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            kb.x[c] = kb.x[c] + Ts * a.x[c];
-            kb.v[c] = kb.v[c] + Ts * a.v[c];
-        }
-    }
-    template <class T>
-    __device__ static __forceinline__ void add_scaled_half(State<T> &kb, const State<T> &a) { // kb + 0.5 (Ts a)
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            kb.x[c] = kb.x[c] + 0.5 * (Ts * a.x[c]);
-            kb.v[c] = kb.v[c] + 0.5 * (Ts * a.v[c]);
-        }
-    }
-
-    /// Tangent of the RK4 adjoint (second-order adjoint): tape and tangent springs from LDS.
-    /// ubar_t (valid on lane 9) = tangent of the adjoint of u through the dynamics.
-    __device__ static __forceinline__ void rk4_adj_tan(const Lane &L, const char *buf, const State<double> &mu_t,
-                                                       State<double> &sbar_t, double (&ubar_t)[DIM]) {
-        State<double> kb1, kb2, kb3, kb4;
-        adj_chain_init(mu_t, kb1, kb2, kb3, kb4, sbar_t);
-        State<double> a = fc_adj_tan(L, tape_rev(L, buf, 3), st_rev(L, buf, 3), kb4);
-        add_to(sbar_t, a);
-        add_scaled_full(kb3, a);
-        a = fc_adj_tan(L, tape_rev(L, buf, 2), st_rev(L, buf, 2), kb3);
-        add_to(sbar_t, a);
-        add_scaled_half(kb2, a);
-        a = fc_adj_tan(L, tape_rev(L, buf, 1), st_rev(L, buf, 1), kb2);
-        add_to(sbar_t, a);
-        add_scaled_half(kb1, a);
-        a = fc_adj_tan(L, tape_rev(L, buf, 0), st_rev(L, buf, 0), kb1);
-        add_to(sbar_t, a);
-#pragma unroll
-        for (int c = 0; c < DIM; ++c)
-            ubar_t[c] = ((kb4.x[c] + kb3.x[c]) + kb2.x[c]) + kb1.x[c];
-    }
-
-    /// Adjoint of one RK4 step.  mu = adjoint of x_next; sbar = adjoint of s; ubar (valid on
-    /// lane 9) = adjoint of u through the dynamics.  With tape_stage != nullptr (T = double)
-    /// the substage quantities are recorded.
-    template <class T>
-    __device__ static __forceinline__ void rk4_adj(const Lane &L, const State<T> &s, const Input<T> &in,
-                                                   const State<T> &mu, State<T> &sbar, T (&ubar)[DIM],
-                                                   double4 *tape_stage = nullptr) {
-        Springs<T> sp1, sp2, sp3, sp4;
-        AdjAux<T> ax;
-        State<T> k = fc(L, s, in, sp1);
-        k          = fc(L, half_step(s, k), in, sp2);
-        k          = fc(L, half_step(s, k), in, sp3);
-        springs(axpy(Ts, k, s), sp4);
-
-        State<T> kb1, kb2, kb3, kb4;
-        adj_chain_init(mu, kb1, kb2, kb3, kb4, sbar);
-        State<T> a = fc_adj(L, sp4, kb4, ax);
-        record(L, tape_stage, 3, sp4, ax);
-        add_to(sbar, a);
-        add_scaled_full(kb3, a);
-        a = fc_adj(L, sp3, kb3, ax);
-        record(L, tape_stage, 2, sp3, ax);
-        add_to(sbar, a);
-        add_scaled_half(kb2, a);
-        a = fc_adj(L, sp2, kb2, ax);
-        record(L, tape_stage, 1, sp2, ax);
-        add_to(sbar, a);
-        add_scaled_half(kb1, a);
-        a = fc_adj(L, sp1, kb1, ax);
-        record(L, tape_stage, 0, sp1, ax);
-        add_to(sbar, a);
-#pragma unroll
-        for (int c = 0; c < DIM; ++c)
-            ubar[c] = ((kb4.x[c] + kb3.x[c]) + kb2.x[c]) + kb1.x[c];
-    }
-    __device__ static __forceinline__ void record(const Lane &L, double4 *stage, int j,
-                                                  const Springs<double> &sp, const AdjAux<double> &ax) {
-        if (stage)
-            tape_store(L, stage, j, sp, ax);
-    }
-    __device__ static __forceinline__ void record(const Lane &, double4 *, int, const Springs<dual> &,
-                                                  const AdjAux<dual> &) {}
-
-    // ---- cost (hanging_chain.cpp:127-131) -----------------------------------------------------------
-    /// Per-component running sums: lane 9 adds alpha (x_end - ref)^2 then gamma u^2 to acc.x,
-    /// lanes 0..8 add beta v^2 to acc.v.
-    template <class T>
-    __device__ static __forceinline__ void cost_accumulate(const Lane &L, const State<T> &s, const Input<T> &in,
-                                                           bool has_u, State<T> &acc) {
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            T t      = s.x[c] - (c == 0 ? 1.0 : 0.0); // reference position (1,0,0) of the end point
-            T a1     = alpha * (t * t);
-            T b1     = beta * (s.v[c] * s.v[c]);
-            acc.x[c] = select(L.end, acc.x[c] + a1, acc.x[c]);
-            acc.v[c] = select(L.mass, acc.v[c] + b1, acc.v[c]);
-            if (has_u) {
-                T a2     = gamma * (in.u[c] * in.u[c]);
-                acc.x[c] = select(L.end, acc.x[c] + a2, acc.x[c]);
-            }
-        }
-    }
-    /// Total cost: per point ((((x0 + x1) + x2) + v0) + v1) + v2, then the 64-lane butterfly.
-    __device__ static __forceinline__ double cost_total(const Lane &L, const State<double> &acc) {
-        double p = ((((acc.x[0] + acc.x[1]) + acc.x[2]) + acc.v[0]) + acc.v[1]) + acc.v[2];
-        return uniform(wave_sum(L.active ? p : 0.0));
+    /// Total cost: per point ((((x0 + x1) + x2) + v0) + v1) + v2 on the lane of its component 0,
+    /// then the 64-lane butterfly.
+    __device__ static __forceinline__ double cost_total(const Lane &L, const State &acc) {
+        double p = ((((qb<0>(acc.x) + qb<1>(acc.x)) + qb<2>(acc.x)) + qb<0>(acc.v)) + qb<1>(acc.v)) + qb<2>(acc.v);
+        return uniform(wave_sum(L.lead ? p : 0.0));
     }
     /// lam + d(l or l_N)/dx.
-    template <class T>
-    __device__ static __forceinline__ void cost_grad_x_add(const Lane &L, const State<T> &s, State<T> &lam) {
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            T ge     = c2a * (s.x[c] - (c == 0 ? 1.0 : 0.0));
-            T gv     = c2b * s.v[c];
-            lam.x[c] = select(L.end, lam.x[c] + ge, lam.x[c]);
-            lam.v[c] = select(L.mass, lam.v[c] + gv, lam.v[c]);
-        }
+    __device__ static __forceinline__ void cost_grad_x_add(const Lane &L, const State &s, State &lam) {
+        double ge = c2a * (s.x - L.xref);
+        double gv = c2b * s.v;
+        lam.x     = L.end ? lam.x + ge : lam.x;
+        lam.v     = L.mass ? lam.v + gv : lam.v;
     }
-    /// Tangent of cost_grad_x_add: lam_t + d2(l)/dx2 s_t.
-    __device__ static __forceinline__ void cost_grad_x_add_tan(const Lane &L, const State<double> &s_t,
-                                                               State<double> &lam_t) {
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            lam_t.x[c] = L.end ? lam_t.x[c] + c2a * s_t.x[c] : lam_t.x[c];
-            lam_t.v[c] = L.mass ? lam_t.v[c] + c2b * s_t.v[c] : lam_t.v[c];
-        }
+    /// Tangent of cost_grad_x_add.
+    __device__ static __forceinline__ void cost_grad_x_add_tan(const Lane &L, const State &s_t, State &lam_t) {
+        lam_t.x = L.end ? __builtin_fma(c2a, s_t.x, lam_t.x) : lam_t.x;
+        lam_t.v = L.mass ? __builtin_fma(c2b, s_t.v, lam_t.v) : lam_t.v;
     }
 };
 

@@ -480,13 +480,6 @@ int pantr_batch_eval_hess_psi_prod(pantr_batch_t *b, int32_t B, const double *x0
 
 extern "C" void pantr_debug_set_eval_reps(int r) { g_eval_reps = r; }
 
-int pantr_batch_eval_hess_psi_prod_dual(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
-                                        const double *v, double *Hv) {
-    if (!x0 || !u || !v || !Hv)
-        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
-    return run_eval(b, B, EVAL_HESS_PROD, 0, x0, u, v, nullptr, Hv, nullptr);
-}
-
 int pantr_batch_eval_prox_grad_step(pantr_batch_t *b, int32_t B, double gamma, const double *x,
                                     const double *grad, double *xhat, double *p, double *scalars) {
     if (!x || !grad || !xhat || !p || !scalars)

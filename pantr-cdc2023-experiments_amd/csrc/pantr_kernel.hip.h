@@ -72,18 +72,17 @@ struct SolveArgs {
 // ---------------------------------------------------------------------------------------
 template <class M>
 struct WaveProblem {
-    using Lane = typename M::Lane;
-    template <class T>
-    using State = typename M::template State<T>;
+    using Lane  = typename M::Lane;
+    using State = typename M::State;
     const Lane &L;
     double *lds; ///< base of this wavefront's vectors
     int N, n, npad, nj;
-    State<double> x0; ///< this lane's share of the initial state
-    double *X;        ///< global: primal trajectory rows, M::TRAJ_DOUBLES per stage
-    double *Xt;       ///< global: tangent trajectory rows
-    double4 *tape;    ///< global: recorded primal substage quantities, M::TAPE_D4_PER_STAGE per stage
-    double4 *st;      ///< global: tangent spring quantities of the current Hv, M::ST_D4_PER_STAGE per stage
-    char *tape_lds;   ///< LDS: two stage-sized landing buffers for the tape's LDS-DMA
+    State x0;       ///< this lane's share of the initial state
+    double *X;      ///< global: primal trajectory rows, M::TRAJ_DOUBLES per stage
+    double *Xt;     ///< global: tangent trajectory rows
+    double4 *tape;  ///< global: recorded second-order rows, M::TAPE_D4_PER_STAGE per stage
+    double4 *st;    ///< global: tangent spring vectors of the current Hv, M::ST_D4_PER_STAGE per stage
+    char *tape_lds; ///< LDS: two stage-sized landing buffers for the tape's LDS-DMA
 
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
 
@@ -104,17 +103,17 @@ struct WaveProblem {
     template <bool STORE>
     __device__ __forceinline__ double psi_forward(const double *u) const {
         wave_sync(); // u was written by its owner lanes
-        State<double> s = x0, acc = M::template zero_state<double>();
+        State s = x0, acc{0.0, 0.0};
         for (int k = 0; k < N; ++k) {
-            auto in = M::load_input(u + M::nu * k);
+            double uc = M::load_input(L, u + M::nu * k);
             if (STORE)
                 M::traj_store(L, X + (size_t)k * M::TRAJ_DOUBLES, s);
-            M::cost_accumulate(L, s, in, true, acc);
-            s = M::rk4(L, s, in);
+            M::cost_accumulate(L, s, uc, true, acc);
+            s = M::rk4(L, s, uc);
         }
         if (STORE)
             M::traj_store(L, X + (size_t)N * M::TRAJ_DOUBLES, s);
-        M::cost_accumulate(L, s, typename M::template Input<double>{}, false, acc);
+        M::cost_accumulate(L, s, 0.0, false, acc);
         return M::cost_total(L, acc);
     }
 
@@ -124,22 +123,18 @@ struct WaveProblem {
     __device__ __forceinline__ double psi_grad(const double *u, double *grad) const {
         double psi = psi_forward<true>(u);
         wave_sync(); // the sweep below re-reads rows this wavefront has just written
-        State<double> lam = M::template zero_state<double>();
+        State lam{0.0, 0.0};
         M::cost_grad_x_add(L, M::traj_load(L, X + (size_t)N * M::TRAJ_DOUBLES), lam);
-        State<double> s = M::traj_load(L, X + (size_t)(N - 1) * M::TRAJ_DOUBLES);
+        State s = M::traj_load(L, X + (size_t)(N - 1) * M::TRAJ_DOUBLES);
         for (int k = N - 1; k >= 0; --k) {
-            State<double> s_prev = s;
+            State s_prev = s;
             if (k > 0) // one stage ahead
                 s_prev = M::traj_load(L, X + (size_t)(k - 1) * M::TRAJ_DOUBLES);
-            auto in = M::load_input(u + M::nu * k);
-            State<double> sbar;
-            double ubar[M::nu];
-            M::rk4_adj(L, s, in, lam, sbar, ubar, RECORD ? tape + (size_t)k * M::TAPE_D4_PER_STAGE : nullptr);
-            double g[M::nu];
-#pragma unroll
-            for (int c = 0; c < M::nu; ++c)
-                g[c] = ubar[c] + M::c2g * in.u[c];
-            M::store_input_grad(L, grad + M::nu * k, g);
+            double uc = M::load_input(L, u + M::nu * k);
+            State sbar;
+            double ubar;
+            M::rk4_adj(L, s, uc, lam, sbar, ubar, RECORD ? tape + (size_t)k * M::TAPE_D4_PER_STAGE : nullptr);
+            M::store_input_grad(L, grad + M::nu * k, ubar + M::c2g * uc);
             lam = sbar;
             M::cost_grad_x_add(L, s, lam);
             s = s_prev;
@@ -148,92 +143,30 @@ struct WaveProblem {
         return psi;
     }
 
-    /// Hv = d/du (grad psi(u)^T v), forward-over-reverse on dual numbers (validation path: every
-    /// primal quantity is recomputed; the solver uses hess_prod_tape).
-    __device__ __forceinline__ void hess_prod(const double *u, const double *v, double *Hv) const {
-        wave_sync();
-        State<dual> s;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            s.x[c] = {x0.x[c], 0.0};
-            s.v[c] = {x0.v[c], 0.0};
-        }
-        auto split_store = [&](int k, const State<dual> &sd) {
-            State<double> pv, pt;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                pv.x[c] = sd.x[c].v; pv.v[c] = sd.v[c].v;
-                pt.x[c] = sd.x[c].t; pt.v[c] = sd.v[c].t;
-            }
-            M::traj_store(L, X + (size_t)k * M::TRAJ_DOUBLES, pv);
-            M::traj_store(L, Xt + (size_t)k * M::TRAJ_DOUBLES, pt);
-        };
-        auto joint_load = [&](int k) {
-            State<double> pv = M::traj_load(L, X + (size_t)k * M::TRAJ_DOUBLES);
-            State<double> pt = M::traj_load(L, Xt + (size_t)k * M::TRAJ_DOUBLES);
-            State<dual> sd;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                sd.x[c] = {pv.x[c], pt.x[c]};
-                sd.v[c] = {pv.v[c], pt.v[c]};
-            }
-            return sd;
-        };
-        for (int k = 0; k < N; ++k) {
-            auto in = M::load_input(u + M::nu * k, v + M::nu * k);
-            split_store(k, s);
-            s = M::rk4(L, s, in);
-        }
-        split_store(N, s);
-        wave_sync();
-        State<dual> lam = M::template zero_state<dual>();
-        M::cost_grad_x_add(L, s, lam);
-        s = joint_load(N - 1);
-        for (int k = N - 1; k >= 0; --k) {
-            State<dual> s_prev = s;
-            if (k > 0)
-                s_prev = joint_load(k - 1);
-            auto in = M::load_input(u + M::nu * k, v + M::nu * k);
-            State<dual> sbar;
-            dual ubar[M::nu];
-            M::rk4_adj(L, s, in, lam, sbar, ubar);
-            double g[M::nu];
-#pragma unroll
-            for (int c = 0; c < M::nu; ++c)
-                g[c] = (ubar[c] + M::c2g * in.u[c]).t;
-            M::store_input_grad(L, Hv + M::nu * k, g);
-            lam = sbar;
-            M::cost_grad_x_add(L, s, lam);
-            s = s_prev;
-        }
-        wave_sync();
-    }
-
-    /// Hv at the point the tape was recorded at: tangent-only forward sweep and second-order
-    /// adjoint sweep, every primal quantity streamed from the tape (no sqrt, no division; the
-    /// adjoint sweep also streams the forward sweep's tangent spring quantities instead of
-    /// recomputing them).  Bit-identical to hess_prod() at the same point.
+    /// Hv = d/du (grad psi(u)^T v) at the point the tape was recorded at (psi_grad<true>):
+    /// tangent forward sweep F_t = K d_t, second-order adjoint sweep ld_t = K lF_t + M d_t.
+    /// Stage k+-1's rows stream from HBM into LDS (LDS-DMA) while stage k computes.
     __device__ __forceinline__ void hess_prod_tape(const double *v, double *Hv) const {
         wave_sync();
         char *buf[2] = {tape_lds, tape_lds + M::LDS_STAGE_BYTES};
-        // ---- forward tangent sweep: stage k+1's rows stream into LDS while stage k runs ----
-        State<double> s_t = M::template zero_state<double>();
+        // ---- forward tangent sweep ----
+        State s_t{0.0, 0.0};
         M::prefetch_fwd(L, tape, buf[0]);
         for (int k = 0; k < N; ++k) {
             wait_vmem(); // stage k's rows have landed
             if (k + 1 < N)
                 M::prefetch_fwd(L, tape + (size_t)(k + 1) * M::TAPE_D4_PER_STAGE, buf[(k + 1) & 1]);
-            auto in_t = M::load_input(v + M::nu * k);
+            double uc_t = M::load_input(L, v + M::nu * k);
             M::traj_store(L, Xt + (size_t)k * M::TRAJ_DOUBLES, s_t);
-            s_t = M::rk4_tan(L, buf[k & 1], s_t, in_t, st + (size_t)k * M::ST_D4_PER_STAGE);
+            s_t = M::rk4_tan(L, buf[k & 1], s_t, uc_t, st + (size_t)k * M::ST_D4_PER_STAGE);
         }
         wave_sync();
         // ---- second-order adjoint sweep ----
-        State<double> lam_t = M::template zero_state<double>();
+        State lam_t{0.0, 0.0};
         M::cost_grad_x_add_tan(L, s_t, lam_t);
         M::prefetch_rev(L, tape + (size_t)(N - 1) * M::TAPE_D4_PER_STAGE, st + (size_t)(N - 1) * M::ST_D4_PER_STAGE,
                         buf[(N - 1) & 1]);
-        State<double> s_n = M::traj_load(L, Xt + (size_t)(N - 1) * M::TRAJ_DOUBLES);
+        State s_n = M::traj_load(L, Xt + (size_t)(N - 1) * M::TRAJ_DOUBLES);
         for (int k = N - 1; k >= 0; --k) {
             wait_vmem(); // stage k's rows and Xt row have landed
             s_t = s_n;
@@ -242,14 +175,11 @@ struct WaveProblem {
                                 st + (size_t)(k - 1) * M::ST_D4_PER_STAGE, buf[(k - 1) & 1]);
                 s_n = M::traj_load(L, Xt + (size_t)(k - 1) * M::TRAJ_DOUBLES);
             }
-            auto in_t = M::load_input(v + M::nu * k);
-            State<double> sbar_t;
-            double ubar_t[M::nu], g[M::nu];
+            double uc_t = M::load_input(L, v + M::nu * k);
+            State sbar_t;
+            double ubar_t;
             M::rk4_adj_tan(L, buf[k & 1], lam_t, sbar_t, ubar_t);
-#pragma unroll
-            for (int c = 0; c < M::nu; ++c)
-                g[c] = ubar_t[c] + M::c2g * in_t.u[c];
-            M::store_input_grad(L, Hv + M::nu * k, g);
+            M::store_input_grad(L, Hv + M::nu * k, __builtin_fma(M::c2g, uc_t, ubar_t));
             lam_t = sbar_t;
             M::cost_grad_x_add_tan(L, s_t, lam_t);
         }
@@ -800,8 +730,6 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
         s0 = pb.template psi_forward<false>(u);
     } else if (a.mode == EVAL_PSI_GRAD) {
         s0 = pb.psi_grad(u, o);
-    } else if (a.mode == EVAL_HESS_PROD) {
-        pb.hess_prod(u, v, o); // dual-number path (validation)
     } else if (a.mode == EVAL_HESS_PROD_TAPE) {
         s0 = pb.template psi_grad<true>(u, o2); // record at u, then replay (the solver's path)
         for (int r = 0; r < (a.reps > 0 ? a.reps : 1); ++r)
@@ -833,9 +761,9 @@ __global__ __launch_bounds__(WAVE) void pantr_simulate_kernel(int B, const doubl
     if (inst >= B)
         return;
     typename M::Lane L(lane);
-    auto s  = M::load_x0(L, x + (size_t)inst * M::nx);
-    auto in = M::load_input(u + (size_t)inst * M::nu);
-    auto r  = M::rk4(L, s, in);
+    auto s    = M::load_x0(L, x + (size_t)inst * M::nx);
+    double uc = M::load_input(L, u + (size_t)inst * M::nu);
+    auto r    = M::rk4(L, s, uc);
     M::store_x(L, xn + (size_t)inst * M::nx, r);
 }
 

@@ -66,8 +66,7 @@ EXPORTS = (
     "pantr_batch_get_param", "pantr_batch_solve", "pantr_batch_solve_device",
     "pantr_batch_last_kernel_ms", "pantr_batch_set_launch_order", "pantr_batch_set_trace",
     "pantr_batch_get_trace", "pantr_batch_eval_psi", "pantr_batch_eval_psi_grad_psi",
-    "pantr_batch_eval_hess_psi_prod", "pantr_batch_eval_hess_psi_prod_dual",
-    "pantr_batch_eval_prox_grad_step",
+    "pantr_batch_eval_hess_psi_prod", "pantr_batch_eval_prox_grad_step",
     "pantr_batch_simulate_dynamics", "pantr_last_error", "pantr_version", "pantr_device_count",
     "pantr_batch_footprint",
 )
@@ -124,7 +123,6 @@ def lib():
         L.pantr_batch_eval_psi.argtypes = [vp, _i32, vp, vp, vp]
         L.pantr_batch_eval_psi_grad_psi.argtypes = [vp, _i32, vp, vp, vp, vp]
         L.pantr_batch_eval_hess_psi_prod.argtypes = [vp, _i32, vp, vp, vp, vp]
-        L.pantr_batch_eval_hess_psi_prod_dual.argtypes = [vp, _i32, vp, vp, vp, vp]
         L.pantr_batch_eval_prox_grad_step.argtypes = [vp, _i32, _dbl, vp, vp, vp, vp, vp]
         L.pantr_batch_simulate_dynamics.argtypes = [vp, _i32, vp, vp, vp]
         L.pantr_batch_footprint.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -278,13 +276,12 @@ class PantrBatch:
                                                    _ptr(grad)))
         return psi, grad
 
-    def eval_hess_psi_prod(self, x0, u, v, dual=False):
-        """Hv by tape record + replay (the solver's path) or, dual=True, by the dual-number sweep."""
+    def eval_hess_psi_prod(self, x0, u, v):
+        """Hv: records the second-order tape at u, then replays it for v (the solver's path)."""
         x0, u, v = _f64(x0), _f64(u), _f64(v)
         B = x0.shape[0]
         Hv = np.zeros((B, self.n))
-        fn = lib().pantr_batch_eval_hess_psi_prod_dual if dual else lib().pantr_batch_eval_hess_psi_prod
-        _check(fn(self._h, B, _ptr(x0), _ptr(u), _ptr(v), _ptr(Hv)))
+        _check(lib().pantr_batch_eval_hess_psi_prod(self._h, B, _ptr(x0), _ptr(u), _ptr(v), _ptr(Hv)))
         return Hv
 
     def eval_prox_grad_step(self, gamma, x, grad):

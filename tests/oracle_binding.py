@@ -82,7 +82,7 @@ def lib():
         L.oracle_chain_psi_grad.argtypes = [C.c_int, _pd, _pd, _pd]
         L.oracle_chain_psi_grad.restype = _dbl
         L.oracle_chain_hess_prod.argtypes = [C.c_int, _pd, _pd, _pd, _pd]
-        L.oracle_chain_hess_prod_tape.argtypes = [C.c_int, _pd, _pd, _pd, _pd]
+        L.oracle_chain_hess_prod_dual.argtypes = [C.c_int, _pd, _pd, _pd, _pd]
         L.oracle_chain_prox_grad_step.argtypes = [C.c_int, _dbl, _pd, _pd, _pd, _pd,
                                                   C.POINTER(_dbl), C.POINTER(_dbl)]
         L.oracle_dot.argtypes = [_pd, _pd, C.c_int]
@@ -149,10 +149,10 @@ def psi_grad(N, x0, u):
     return v, g
 
 
-def hess_prod(N, x0, u, v, tape=False):
-    """Hv by the dual-number sweep, or (tape=True) by the record/replay algorithm of the kernels."""
+def hess_prod(N, x0, u, v, dual=False):
+    """Hv over the recorded K/M tape (the problem's product), or (dual=True) by dual numbers."""
     Hv = np.zeros(NU * N)
-    fn = lib().oracle_chain_hess_prod_tape if tape else lib().oracle_chain_hess_prod
+    fn = lib().oracle_chain_hess_prod_dual if dual else lib().oracle_chain_hess_prod
     fn(N, np.ascontiguousarray(x0, float), np.ascontiguousarray(u, float),
                                  np.ascontiguousarray(v, float), Hv)
     return Hv

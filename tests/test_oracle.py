@@ -106,6 +106,9 @@ def test_hessian_vector_product(rng, N):
     assert abs(w @ Hv - v @ Hw) <= 1e-12 * abs(w @ Hv)          # symmetry
     assert np.array_equal(ob.hess_prod(N, x0, u, np.zeros(NU * N)), np.zeros(NU * N))
     assert np.allclose(ob.hess_prod(N, x0, u, 2.5 * v), 2.5 * Hv, rtol=1e-13)  # linearity
+    # the K/M tape product against the independent dual-number (forward-over-reverse) product
+    Hd = ob.hess_prod(N, x0, u, v, dual=True)
+    assert np.abs(Hv - Hd).max() <= 1e-12 * np.abs(Hd).max()
 
 
 def test_prox_grad_step_is_box_projection(rng):
