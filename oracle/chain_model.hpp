@@ -320,6 +320,12 @@ struct Chain {
                     ts.M[p][c][c2] = w * m;
                 }
             }
+            // K and M are symmetric in exact arithmetic; the tape stores their upper triangles
+            for (int c = 0; c < DIM; ++c)
+                for (int c2 = 0; c2 < c; ++c2) {
+                    ts.K[p][c][c2] = ts.K[p][c2][c];
+                    ts.M[p][c][c2] = ts.M[p][c2][c];
+                }
         }
         for (int p = 0; p < NP; ++p)
             for (int c = 0; c < DIM; ++c)

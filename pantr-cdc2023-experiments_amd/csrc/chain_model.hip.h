@@ -45,9 +45,16 @@ struct ChainModel {
                                           : 0.0;
     }
 
+    /// Index of entry (c, c2) in the upper-triangle order.
+    __host__ __device__ static constexpr int sym(int c, int c2) {
+        return c <= c2 ? (c == 0 ? c2 : c == 1 ? 2 + c2 : 5) : sym(c2, c);
+    }
+
     /// Per-lane role.
     struct Lane {
-        int l, p, c, q; ///< lane, point, component, compact slot 3p+c (tape rows)
+        int l, p, c, q; ///< lane, point, component, compact slot 3p+c
+        int pc;         ///< point clamped to 0..9 (idle lanes read valid LDS)
+        int e[DIM];     ///< upper-triangle indices of row c of a symmetric 3x3
         bool active, mass, end, first, lead, grav;
         double xref;       ///< reference position of this component of the end point (1,0,0)
         __device__ explicit Lane(int lane) {
@@ -61,6 +68,10 @@ struct ChainModel {
             lead   = active && c == 0;
             grav   = c == DIM - 1;
             q      = active ? DIM * p + c : 31;
+            pc     = p < NP ? p : NP - 1;
+            int cc = c < DIM ? c : 0;
+            for (int k = 0; k < DIM; ++k)
+                e[k] = sym(cc, k);
             xref = c == 0 ? 1.0 : 0.0;
         }
     };
@@ -116,6 +127,12 @@ struct ChainModel {
         double2 a = reinterpret_cast<const double2 *>(row)[L.l];
         return {a.x, a.y};
     }
+    /// Tangent-state row of the Hv sweeps: one double per compact slot, the component the cost
+    /// Hessian multiplies (x of the end point, v of the masses).
+    __device__ static __forceinline__ void xt_store(const Lane &L, double *row, const State &s_t) {
+        row[L.q] = L.end ? s_t.x : s_t.v; // idle lanes: slot 31
+    }
+    __device__ static __forceinline__ double xt_load(const Lane &L, const double *row) { return row[L.q]; }
     /// This lane's component of u_k from a decision vector in LDS.
     __device__ static __forceinline__ double load_input(const Lane &L, const double *u_k) {
         return u_k[L.c < DIM ? L.c : DIM - 1];
@@ -177,18 +194,20 @@ struct ChainModel {
     }
 
     // ---- the tape ------------------------------------------------------------------------------
-    // Per substage j and lane (p,c): row c of K = c I + w d d^T and of
-    // M = w [ lF d^T + d lF^T + dt (I - (3/n2) d d^T) ]: six doubles, stored in compact slot
-    // q = 3p+c (32 slots x 16 B = 512 B per row) as A = {K0,K1}, B = {K2,M0}, C = {M1,M2}.
-    // Stage layout in HBM (6 KiB): [j = 0..3: A row, B row] (4 KiB, all the forward sweep needs,
-    // one LDS-DMA instruction per substage) then [C rows of j = 0..3] (2 KiB).
+    // Per substage j and spring p: the upper triangles of K = c I + w d d^T and of
+    // M = w [ lF d^T + d lF^T + dt (I - (3/n2) d d^T) ] (both symmetric), six doubles each in the
+    // order (0,0) (0,1) (0,2) (1,1) (1,2) (2,2): spring p's block at doubles [6p, 6p+6) of a
+    // 512-byte row.  Stage layout in HBM (4 KiB): [K rows of j = 0..3] (2 KiB: all the forward sweep
+    // needs) then [M rows of j = 0..3].  Lane (p,c) reads row c of the full matrices from LDS.
     // The forward sweep of each product writes its tangent spring vectors d_t to a second tape
-    // ("st": [j][32 slots] doubles, 1 KiB per stage) that its adjoint sweep streams back.
-    static constexpr int TAPE_STAGE_BYTES  = 6144;
+    // ("st": [j][32 slots] doubles, 1 KiB per stage) that its adjoint sweep streams back, and one
+    // 256-byte row per stage with the tangent-state components the cost Hessian needs.
+    static constexpr int TAPE_STAGE_BYTES  = 4096;
     static constexpr int ST_STAGE_BYTES    = 1024;
     static constexpr int LDS_STAGE_BYTES   = TAPE_STAGE_BYTES + ST_STAGE_BYTES;
     static constexpr int TAPE_D4_PER_STAGE = TAPE_STAGE_BYTES / 32;
     static constexpr int ST_D4_PER_STAGE   = ST_STAGE_BYTES / 32;
+    static constexpr int XT_DOUBLES        = 32; ///< tangent-state row per stage (compact slots)
 
     __device__ static __forceinline__ void tape_store(const Lane &L, double4 *stage, int j, const Springs &sp,
                                                       const AdjAux &ax) {
@@ -198,29 +217,29 @@ struct ChainModel {
         const double e  = 3.0 / sp.n2;
         const double wd = ax.w * sp.d;
         const double g  = e * sp.d;
-        double K[DIM], M[DIM];
+        double *Krow = reinterpret_cast<double *>(reinterpret_cast<char *>(stage) + j * 512) + 6 * L.p;
+        double *Mrow = reinterpret_cast<double *>(reinterpret_cast<char *>(stage) + 2048 + j * 512) + 6 * L.p;
 #pragma unroll
         for (int c2 = 0; c2 < DIM; ++c2) {
-            K[c2]     = __builtin_fma(wd, dq[c2], L.c == c2 ? sp.c : 0.0);
+            double K  = __builtin_fma(wd, dq[c2], L.c == c2 ? sp.c : 0.0);
             double m  = ax.lF * dq[c2];
             m         = __builtin_fma(sp.d, lq[c2], m);
             double kd = __builtin_fma(-g, dq[c2], L.c == c2 ? 1.0 : 0.0);
             m         = __builtin_fma(ax.dt, kd, m);
-            M[c2]     = ax.w * m;
-        }
-        if (L.active) {
-            char *base = reinterpret_cast<char *>(stage);
-            *reinterpret_cast<double2 *>(base + j * 1024 + L.q * 16)        = make_double2(K[0], K[1]);
-            *reinterpret_cast<double2 *>(base + j * 1024 + 512 + L.q * 16)  = make_double2(K[2], M[0]);
-            *reinterpret_cast<double2 *>(base + 4096 + j * 512 + L.q * 16)  = make_double2(M[1], M[2]);
+            double M  = ax.w * m;
+            if (L.active && L.c <= c2) { // upper triangle: row c, column c2 >= c
+                int e_idx    = L.c == 0 ? c2 : (L.c == 1 ? 2 + c2 : 5);
+                Krow[e_idx]  = K;
+                Mrow[e_idx]  = M;
+            }
         }
     }
-    /// Start the LDS-DMA of one stage into the landing buffer `buf`: 4 KiB (K rows) for the
-    /// forward sweep; 6 KiB of tape + 1 KiB of tangent tape for the adjoint sweep.
+    /// Start the LDS-DMA of one stage into the landing buffer `buf`: 2 KiB (K rows) for the
+    /// forward sweep; 4 KiB of tape + 1 KiB of tangent tape for the adjoint sweep.
     __device__ static __forceinline__ void prefetch_fwd(const Lane &L, const double4 *tape_stage, char *buf) {
         const char *src = reinterpret_cast<const char *>(tape_stage) + L.l * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
             lds_dma_row(src + i * 1024, buf + i * 1024);
     }
     __device__ static __forceinline__ void prefetch_rev(const Lane &L, const double4 *tape_stage,
@@ -238,16 +257,14 @@ struct ChainModel {
         double K[DIM], M[DIM], D[DIM]; ///< D = d_t of this lane's point (from the tangent tape)
     };
     __device__ static __forceinline__ TapeK tape_fwd(const Lane &L, const char *buf, int j) {
-        double2 a = *reinterpret_cast<const double2 *>(buf + j * 1024 + L.q * 16);
-        double2 b = *reinterpret_cast<const double2 *>(buf + j * 1024 + 512 + L.q * 16);
-        return {{a.x, a.y, b.x}};
+        const double *K = reinterpret_cast<const double *>(buf + j * 512) + 6 * L.pc;
+        return {{K[L.e[0]], K[L.e[1]], K[L.e[2]]}};
     }
     __device__ static __forceinline__ TapeKM tape_rev(const Lane &L, const char *buf, int j) {
-        double2 a = *reinterpret_cast<const double2 *>(buf + j * 1024 + L.q * 16);
-        double2 b = *reinterpret_cast<const double2 *>(buf + j * 1024 + 512 + L.q * 16);
-        double2 c = *reinterpret_cast<const double2 *>(buf + 4096 + j * 512 + L.q * 16);
-        const double *st = reinterpret_cast<const double *>(buf + TAPE_STAGE_BYTES + j * 256) + (L.q - L.c);
-        return {{a.x, a.y, b.x}, {b.y, c.x, c.y}, {st[0], st[1], st[2]}};
+        const double *K  = reinterpret_cast<const double *>(buf + j * 512) + 6 * L.pc;
+        const double *M  = reinterpret_cast<const double *>(buf + 2048 + j * 512) + 6 * L.pc;
+        const double *st = reinterpret_cast<const double *>(buf + TAPE_STAGE_BYTES + j * 256) + DIM * L.pc;
+        return {{K[L.e[0]], K[L.e[1]], K[L.e[2]]}, {M[L.e[0]], M[L.e[1]], M[L.e[2]]}, {st[0], st[1], st[2]}};
     }
 
     // ---- tangent sweeps over the tape ---------------------------------------------------------------
@@ -255,8 +272,7 @@ struct ChainModel {
     __device__ static __forceinline__ State fc_tan(const Lane &L, const TapeK &g, const State &s_t, double uc_t,
                                                    double4 *st_stage, int j) {
         double d_t = s_t.x - prev_point(L, s_t.x);
-        if (L.active)
-            reinterpret_cast<double *>(reinterpret_cast<char *>(st_stage) + j * 256)[L.q] = d_t;
+        reinterpret_cast<double *>(reinterpret_cast<char *>(st_stage) + j * 256)[L.q] = d_t; // idle lanes: slot 31
         double F  = g.K[0] * qb<0>(d_t);
         F         = __builtin_fma(g.K[1], qb<1>(d_t), F);
         F         = __builtin_fma(g.K[2], qb<2>(d_t), F);
@@ -380,10 +396,10 @@ struct ChainModel {
         lam.x     = L.end ? lam.x + ge : lam.x;
         lam.v     = L.mass ? lam.v + gv : lam.v;
     }
-    /// Tangent of cost_grad_x_add.
-    __device__ static __forceinline__ void cost_grad_x_add_tan(const Lane &L, const State &s_t, State &lam_t) {
-        lam_t.x = L.end ? __builtin_fma(c2a, s_t.x, lam_t.x) : lam_t.x;
-        lam_t.v = L.mass ? __builtin_fma(c2b, s_t.v, lam_t.v) : lam_t.v;
+    /// Tangent of cost_grad_x_add; xt = the lane's xt_store()d component of s_t.
+    __device__ static __forceinline__ void cost_grad_x_add_tan(const Lane &L, double xt, State &lam_t) {
+        lam_t.x = L.end ? __builtin_fma(c2a, xt, lam_t.x) : lam_t.x;
+        lam_t.v = L.mass ? __builtin_fma(c2b, xt, lam_t.v) : lam_t.v;
     }
 };
 

@@ -173,8 +173,7 @@ int run_eval(pantr_batch *b, int32_t B, int mode, double gamma, const double *x0
     a.reps = g_eval_reps;
     a.x0 = b->d_x0; a.u = b->d_u; a.v = v ? b->d_v : nullptr;
     a.out_s = b->d_s; a.out_v = b->d_o1; a.out_v2 = b->d_o2; a.ws = b->d_ws; a.gamma = gamma;
-    hipLaunchKernelGGL(pantr_eval_kernel<ChainModel>, dim3(B), dim3(WAVE),
-                       4 * b->npad * sizeof(double) + WaveProblem<ChainModel>::tape_lds_bytes(), 0, a);
+    hipLaunchKernelGGL(pantr_eval_kernel<ChainModel>, dim3(B), dim3(WAVE), 4 * b->npad * sizeof(double), 0, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     std::vector<double> s((size_t)B * 4);
@@ -253,8 +252,8 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
         return fail(PANTR_ERR_OUT_OF_RANGE, "horizon too long: n = nu*N must be <= 2048");
     b->maxB            = max_instances;
     b->ws_per_instance = WaveProblem<ChainModel>::workspace_doubles(b->N);
-    b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double) + WaveProblem<ChainModel>::tape_lds_bytes();
-    if (b->lds_bytes > 160 * 1024)
+    b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double); // dynamic part (vectors)
+    if (b->lds_bytes + WaveProblem<ChainModel>::tape_lds_bytes() > 160 * 1024)
         return fail(PANTR_ERR_OUT_OF_RANGE, "decision vectors do not fit the 160 KiB LDS");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_solve_kernel<ChainModel>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
@@ -346,7 +345,7 @@ int pantr_batch_get_param(const pantr_batch_t *b, const char *key, double *value
 int pantr_batch_footprint(const pantr_batch_t *b, int64_t *lds_bytes, int64_t *ws_bytes_per_instance) {
     if (!b)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
-    if (lds_bytes) *lds_bytes = (int64_t)b->lds_bytes;
+    if (lds_bytes) *lds_bytes = (int64_t)(b->lds_bytes + WaveProblem<ChainModel>::tape_lds_bytes());
     if (ws_bytes_per_instance) *ws_bytes_per_instance = (int64_t)(b->ws_per_instance * sizeof(double));
     return PANTR_OK;
 }
@@ -476,6 +475,12 @@ int pantr_batch_eval_hess_psi_prod(pantr_batch_t *b, int32_t B, const double *x0
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
     // the solver's own path: record the tape at u, then replay it for v
     return run_eval(b, B, EVAL_HESS_PROD_TAPE, 0, x0, u, v, nullptr, Hv, nullptr);
+}
+
+/// Development aid: same as above, also returning {psi, shader cycles, 100 MHz ticks, 0} per instance.
+extern "C" int pantr_debug_hess_prod_timed(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
+                                           const double *v, double *Hv, double *scal) {
+    return run_eval(b, B, EVAL_HESS_PROD_TAPE, 0, x0, u, v, scal, Hv, nullptr);
 }
 
 extern "C" void pantr_debug_set_eval_reps(int r) { g_eval_reps = r; }

@@ -79,23 +79,24 @@ struct WaveProblem {
     int N, n, npad, nj;
     State x0;       ///< this lane's share of the initial state
     double *X;      ///< global: primal trajectory rows, M::TRAJ_DOUBLES per stage
-    double *Xt;     ///< global: tangent trajectory rows
+    double *Xt;     ///< global: tangent-state rows of the current Hv, M::XT_DOUBLES per stage
     double4 *tape;  ///< global: recorded second-order rows, M::TAPE_D4_PER_STAGE per stage
     double4 *st;    ///< global: tangent spring vectors of the current Hv, M::ST_D4_PER_STAGE per stage
-    char *tape_lds; ///< LDS: two stage-sized landing buffers for the tape's LDS-DMA
+    char *tbuf0, *tbuf1; ///< LDS: two stage-sized landing buffers (distinct objects) for the LDS-DMA
 
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
 
-    /// Bytes of LDS behind the decision vectors: two landing buffers for the tape's LDS-DMA.
+    /// Static LDS of a kernel using this problem: the two landing buffers.
     __host__ __device__ static size_t tape_lds_bytes() { return 2 * (size_t)M::LDS_STAGE_BYTES; }
     /// Doubles of HBM workspace one instance needs: X and Xt rows, the tape, the tangent tape.
     __host__ __device__ static size_t workspace_doubles(int N) {
-        return (size_t)2 * (N + 1) * M::TRAJ_DOUBLES + (size_t)N * (M::TAPE_D4_PER_STAGE + M::ST_D4_PER_STAGE) * 4;
+        return (size_t)(N + 1) * (M::TRAJ_DOUBLES + M::XT_DOUBLES) +
+               (size_t)N * (M::TAPE_D4_PER_STAGE + M::ST_D4_PER_STAGE) * 4;
     }
     __device__ __forceinline__ void bind_workspace(double *ws, int inst) {
         X    = ws + (size_t)inst * workspace_doubles(N);
         Xt   = X + (size_t)(N + 1) * M::TRAJ_DOUBLES;
-        tape = reinterpret_cast<double4 *>(Xt + (size_t)(N + 1) * M::TRAJ_DOUBLES);
+        tape = reinterpret_cast<double4 *>(Xt + (size_t)(N + 1) * M::XT_DOUBLES);
         st   = tape + (size_t)N * M::TAPE_D4_PER_STAGE;
     }
 
@@ -145,43 +146,60 @@ struct WaveProblem {
 
     /// Hv = d/du (grad psi(u)^T v) at the point the tape was recorded at (psi_grad<true>):
     /// tangent forward sweep F_t = K d_t, second-order adjoint sweep ld_t = K lF_t + M d_t.
-    /// Stage k+-1's rows stream from HBM into LDS (LDS-DMA) while stage k computes.
+    /// Stage k+-1's rows stream from HBM into LDS (LDS-DMA) while stage k computes.  The two
+    /// landing buffers are distinct __shared__ objects and the stage loops are unrolled by two,
+    /// so every LDS read names a buffer no DMA is writing (otherwise the compiler drains the
+    /// in-flight DMA with vmcnt(0) before each read and the prefetch hides nothing).
     __device__ __forceinline__ void hess_prod_tape(const double *v, double *Hv) const {
         wave_sync();
-        char *buf[2] = {tape_lds, tape_lds + M::LDS_STAGE_BYTES};
         // ---- forward tangent sweep ----
         State s_t{0.0, 0.0};
-        M::prefetch_fwd(L, tape, buf[0]);
-        for (int k = 0; k < N; ++k) {
-            wait_vmem(); // stage k's rows have landed
+        auto stage_fwd = [&](int k, char *cur, char *nxt) {
+            wait_vmem(); // stage k's rows have landed in `cur`
             if (k + 1 < N)
-                M::prefetch_fwd(L, tape + (size_t)(k + 1) * M::TAPE_D4_PER_STAGE, buf[(k + 1) & 1]);
+                M::prefetch_fwd(L, tape + (size_t)(k + 1) * M::TAPE_D4_PER_STAGE, nxt);
             double uc_t = M::load_input(L, v + M::nu * k);
-            M::traj_store(L, Xt + (size_t)k * M::TRAJ_DOUBLES, s_t);
-            s_t = M::rk4_tan(L, buf[k & 1], s_t, uc_t, st + (size_t)k * M::ST_D4_PER_STAGE);
+            M::xt_store(L, Xt + (size_t)k * M::XT_DOUBLES, s_t);
+            s_t = M::rk4_tan(L, cur, s_t, uc_t, st + (size_t)k * M::ST_D4_PER_STAGE);
+        };
+        M::prefetch_fwd(L, tape, tbuf0);
+        for (int k = 0; k < N; k += 2) {
+            stage_fwd(k, tbuf0, tbuf1);
+            if (k + 1 < N)
+                stage_fwd(k + 1, tbuf1, tbuf0);
         }
         wave_sync();
-        // ---- second-order adjoint sweep ----
+        // ---- second-order adjoint sweep (even stages land in tbuf0, odd ones in tbuf1) ----
         State lam_t{0.0, 0.0};
-        M::cost_grad_x_add_tan(L, s_t, lam_t);
-        M::prefetch_rev(L, tape + (size_t)(N - 1) * M::TAPE_D4_PER_STAGE, st + (size_t)(N - 1) * M::ST_D4_PER_STAGE,
-                        buf[(N - 1) & 1]);
-        State s_n = M::traj_load(L, Xt + (size_t)(N - 1) * M::TRAJ_DOUBLES);
-        for (int k = N - 1; k >= 0; --k) {
+        M::cost_grad_x_add_tan(L, L.end ? s_t.x : s_t.v, lam_t);
+        double xt = 0.0, xt_n = M::xt_load(L, Xt + (size_t)(N - 1) * M::XT_DOUBLES);
+        auto stage_rev = [&](int k, char *cur, char *nxt) {
             wait_vmem(); // stage k's rows and Xt row have landed
-            s_t = s_n;
+            xt = xt_n;
             if (k > 0) { // one stage ahead
                 M::prefetch_rev(L, tape + (size_t)(k - 1) * M::TAPE_D4_PER_STAGE,
-                                st + (size_t)(k - 1) * M::ST_D4_PER_STAGE, buf[(k - 1) & 1]);
-                s_n = M::traj_load(L, Xt + (size_t)(k - 1) * M::TRAJ_DOUBLES);
+                                st + (size_t)(k - 1) * M::ST_D4_PER_STAGE, nxt);
+                xt_n = M::xt_load(L, Xt + (size_t)(k - 1) * M::XT_DOUBLES);
             }
             double uc_t = M::load_input(L, v + M::nu * k);
             State sbar_t;
             double ubar_t;
-            M::rk4_adj_tan(L, buf[k & 1], lam_t, sbar_t, ubar_t);
+            M::rk4_adj_tan(L, cur, lam_t, sbar_t, ubar_t);
             M::store_input_grad(L, Hv + M::nu * k, __builtin_fma(M::c2g, uc_t, ubar_t));
             lam_t = sbar_t;
-            M::cost_grad_x_add_tan(L, s_t, lam_t);
+            M::cost_grad_x_add_tan(L, xt, lam_t);
+        };
+        int k = N - 1;
+        if (k & 1) {
+            M::prefetch_rev(L, tape + (size_t)k * M::TAPE_D4_PER_STAGE, st + (size_t)k * M::ST_D4_PER_STAGE, tbuf1);
+        } else {
+            M::prefetch_rev(L, tape + (size_t)k * M::TAPE_D4_PER_STAGE, st + (size_t)k * M::ST_D4_PER_STAGE, tbuf0);
+            stage_rev(k, tbuf0, tbuf1);
+            --k;
+        }
+        for (; k >= 1; k -= 2) {
+            stage_rev(k, tbuf1, tbuf0);
+            stage_rev(k - 1, tbuf0, tbuf1);
         }
         wave_sync();
     }
@@ -307,10 +325,11 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
     const KernelParams &P   = a.prm;
     typename M::Lane L(lane);
 
-    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, nullptr};
+    __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
+    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
     pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
-    pb.tape_lds = reinterpret_cast<char *>(lds + NUM_VEC * a.npad);
     const int n = a.n, nj = a.nj;
 
     // vector slots
@@ -712,10 +731,11 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
     if (inst >= a.B)
         return;
     typename M::Lane L(lane);
-    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, nullptr};
+    __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
+    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
     pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
-    pb.tape_lds = reinterpret_cast<char *>(lds + 4 * a.npad);
     double *u = pb.vec(0), *v = pb.vec(1), *o = pb.vec(2), *o2 = pb.vec(3);
     for (int i = lane; i < 4 * a.npad; i += WAVE)
         lds[i] = 0.0;
@@ -732,8 +752,11 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
         s0 = pb.psi_grad(u, o);
     } else if (a.mode == EVAL_HESS_PROD_TAPE) {
         s0 = pb.template psi_grad<true>(u, o2); // record at u, then replay (the solver's path)
+        long long c0 = clock64(), w0 = wall_clock64();
         for (int r = 0; r < (a.reps > 0 ? a.reps : 1); ++r)
             pb.hess_prod_tape(v, o);
+        s1 = (double)(clock64() - c0);      // shader cycles
+        s2 = (double)(wall_clock64() - w0); // 100 MHz ticks
     } else {
         pb.prox_grad_step(a.gamma, u, v, o, o2, s0, s1);
         s2 = pb.proj_grad_unit_norm(u, v);

@@ -17,5 +17,14 @@ for reps in (1, 101):
     L.pantr_debug_set_eval_reps(reps)
     b.eval_hess_psi_prod(x0, u, v)
     t = time.perf_counter(); Hv = b.eval_hess_psi_prod(x0, u, v); res[reps] = time.perf_counter() - t
+import ctypes as C
+vp = C.c_void_p
+sc = np.zeros((B, 4)); Hv = np.zeros_like(u)
+x0c, uc, vc = map(np.ascontiguousarray, (x0, u, v))
+L.pantr_debug_hess_prod_timed(b._h, B, x0c.ctypes.data_as(vp), uc.ctypes.data_as(vp), vc.ctypes.data_as(vp),
+                              Hv.ctypes.data_as(vp), sc.ctypes.data_as(vp))
+cyc, ticks = sc[:, 1], sc[:, 2]
+print(f"in-kernel: {np.median(cyc)/101/60:.0f} shader cycles per stage (fwd+adj), clock {np.median(cyc/ticks)*100:.0f} MHz, "
+      f"{np.median(ticks)/101*10/1e3:.1f} us per product")
 print(f"B={B}: Hv (tape replay) = {(res[101]-res[1])/100*1e6:.1f} us per product per wave "
       f"({60*(res[101]-res[1])/100/60*1e9/60:.0f} ns/stage)")
