@@ -123,6 +123,12 @@ struct WaveProblem {
     template <bool RECORD = false>
     __device__ __forceinline__ double psi_grad(const double *u, double *grad) const {
         double psi = psi_forward<true>(u);
+        grad_reverse<RECORD>(u, grad);
+        return psi;
+    }
+    /// The adjoint sweep alone, over the trajectory the last psi_forward<true>(u) stored (same u).
+    template <bool RECORD = false>
+    __device__ __forceinline__ void grad_reverse(const double *u, double *grad) const {
         wave_sync(); // the sweep below re-reads rows this wavefront has just written
         State lam{0.0, 0.0};
         M::cost_grad_x_add(L, M::traj_load(L, X + (size_t)N * M::TRAJ_DOUBLES), lam);
@@ -141,7 +147,6 @@ struct WaveProblem {
             s = s_prev;
         }
         wave_sync(); // grad was written by the owner of the input adjoint
-        return psi;
     }
 
     /// Hv = d/du (grad psi(u)^T v) at the point the tape was recorded at (psi_grad<true>):
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
             swap_iter(curr, prox);
         // ---- psi(xhat) + quadratic upper bound backtracking on the new current iterate ----
         while (true) {
-            curr.psi_xh = pb.template psi_forward<false>(XH_(curr));
+            curr.psi_xh = pb.template psi_forward<true>(XH_(curr)); // keeps X for grad_L(xhat) below
             ++st.n_psi;
             double margin = (1.0 + fabs(curr.psi_x)) * P.quadratic_upperbound_tolerance_factor;
             bool violated = curr.psi_xh > ((curr.psi_x + curr.gradTp) + (0.5 * curr.L) * curr.pTp) + margin;
@@ -466,7 +471,9 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
                 X_(prox)[i] = XH_(curr)[i];
         }
         prox.psi_x = curr.psi_xh;
-        pb.template psi_grad<true>(X_(prox), G_(prox)); // records the tape at xbar
+        // grad_L(xhat): xbar = xhat_k was the last point psi was evaluated at (trajectory X is still
+        // in the workspace), so only the adjoint sweep runs; it records the tape at xbar
+        pb.template grad_reverse<true>(X_(prox), G_(prox));
         ++st.n_grad_L;
         prox.gamma = curr.gamma;
         prox.L     = curr.L;

@@ -9,6 +9,7 @@ set -e
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
+rm -rf $OUT
 mkdir -p $OUT
 ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/stats.log 2>&1

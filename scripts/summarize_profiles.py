@@ -8,6 +8,11 @@ on gfx950 FETCH_SIZE counts 64 B per 128-B read request, so it is doubled before
 """
 import csv, glob, json, os, shutil, sys
 
+
+def newest(pattern):
+    files = glob.glob(pattern)
+    return max(files, key=os.path.getmtime) if files else None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", "prof")
@@ -17,14 +22,14 @@ KERNEL = "pantr_solve_kernel"
 
 summary = {"tag": tag, "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
            "kernel": "pantr::pantr_solve_kernel<pantr::ChainModel>"}
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 for r in csv.DictReader(open(stats)):
     if KERNEL in r["Name"]:
         summary["kernel_trace"] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                                    "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
                                    "percentage": float(r["Percentage"])}
-trace = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))[0]
+trace = newest(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
 for r in csv.DictReader(open(trace)):
     if KERNEL in r["Kernel_Name"]:
         summary["dispatch"] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size",
@@ -33,11 +38,11 @@ for r in csv.DictReader(open(trace)):
         break
 pmc = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    files = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))
-    if not files:
+    f = newest(os.path.join(src, name, "*", "*_counter_collection.csv"))
+    if not f:
         continue
     agg = {}
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(f)):
         if KERNEL in r["Kernel_Name"]:
             agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for k, v in agg.items():
