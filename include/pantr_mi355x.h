@@ -134,6 +134,18 @@ int pantr_batch_eval_prox_grad_step(pantr_batch_t *b, int32_t B, double gamma, c
 int pantr_batch_simulate_dynamics(pantr_batch_t *b, int32_t B, const double *x, const double *u,
                                   double *x_next);
 
+/* ---- closed loops: replaces do_mpc_experiment (mpc-driver.cpp:123-210) ---------------------
+ * B independent MPC trajectories advanced in lock-step on the device (no host round trip between
+ * steps): initial state x_init[B][nx] (NULL = the problem's), num_dist plant steps under the
+ * disturbance u_dist[B][nu] (:153-154), an unrecorded first solve (:158), then num_sim times
+ * { warm: shift the previous solution by nu (:168-170) | cold: the initial guess (:192-193) ;
+ * solve ; record ; plant step with the first input block (:205) }.  Outputs (host):
+ * states[num_sim+1][B][nx], inputs[num_sim][B][n] (the whole optimal u per step, as
+ * results.hpp:227-251 stores it), stats[num_sim][B]. */
+int pantr_batch_mpc(pantr_batch_t *b, int32_t B, int32_t num_sim, int32_t warm, int32_t num_dist,
+                    const double *x_init, const double *u_dist, double *states, double *inputs,
+                    pantr_stats_t *stats);
+
 /* ---- misc -------------------------------------------------------------------------------- */
 const char *pantr_last_error(void);
 const char *pantr_version(void);

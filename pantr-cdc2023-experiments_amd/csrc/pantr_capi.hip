@@ -502,10 +502,56 @@ int pantr_batch_simulate_dynamics(pantr_batch_t *b, int32_t B, const double *x, 
     HIP_TRY(hipMemcpy(b->d_x0, x, (size_t)B * b->nx * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_v, u, (size_t)B * b->nu * sizeof(double), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(pantr_simulate_kernel<ChainModel>, dim3(B), dim3(WAVE), 0, 0, B, b->d_x0, b->d_v,
-                       b->d_o1);
+                       b->nu, b->d_o1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(x_next, b->d_o1, (size_t)B * b->nx * sizeof(double), hipMemcpyDeviceToHost));
+    return PANTR_OK;
+}
+
+// ---- closed loops on the device -------------------------------------------------------------
+int pantr_batch_mpc(pantr_batch_t *b, int32_t B, int32_t num_sim, int32_t warm, int32_t num_dist,
+                    const double *x_init, const double *u_dist, double *states, double *inputs,
+                    pantr_stats_t *stats) {
+    if (int rc = check_batch(b, B))
+        return rc;
+    if (!u_dist || !states || !inputs || !stats)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    if (num_sim < 1 || num_dist < 0)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "num_sim must be >= 1 and num_dist >= 0");
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t xb = (size_t)B * b->nx * sizeof(double), ub = (size_t)B * b->n * sizeof(double);
+    // x0: the problem's initial state (or the caller's), u: the initial guess
+    std::vector<double> x0((size_t)B * b->nx);
+    for (int i = 0; i < B; ++i)
+        for (int l = 0; l < b->nx; ++l)
+            x0[(size_t)i * b->nx + l] = x_init ? x_init[(size_t)i * b->nx + l] : ChainModel::initial_state(l);
+    HIP_TRY(hipMemcpy(b->d_x0, x0.data(), xb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(b->d_u, 0, ub)); // hanging_chain.cpp:135
+    HIP_TRY(hipMemcpy(b->d_v, u_dist, (size_t)B * b->nu * sizeof(double), hipMemcpyHostToDevice));
+    auto simulate = [&](const double *u, int stride) {
+        hipLaunchKernelGGL(pantr_simulate_kernel<ChainModel>, dim3(B), dim3(WAVE), 0, 0, B, b->d_x0, u, stride,
+                           b->d_x0);
+    };
+    for (int i = 0; i < num_dist; ++i) // initial disturbance (mpc-driver.cpp:153-154)
+        simulate(b->d_v, b->nu);
+    if (int rc = launch_solve(b, B, b->d_x0, b->d_u, b->d_stats, nullptr)) // untimed first solve (:158)
+        return rc;
+    simulate(b->d_u, b->n); // :160-161
+    for (int i = 0; i < num_sim; ++i) {
+        hipLaunchKernelGGL(pantr_shift_kernel, dim3(B), dim3(256), 0, 0, B, b->n, b->nu, warm, b->d_u);
+        // record the state this step is solved for, then solve, record, advance the plant
+        HIP_TRY(hipMemcpyAsync(states + (size_t)i * B * b->nx, b->d_x0, xb, hipMemcpyDeviceToHost, nullptr));
+        if (int rc = launch_solve(b, B, b->d_x0, b->d_u, b->d_stats, nullptr))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(inputs + (size_t)i * B * b->n, b->d_u, ub, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipMemcpyAsync(stats + (size_t)i * B, b->d_stats, (size_t)B * sizeof(DeviceStats),
+                               hipMemcpyDeviceToHost, nullptr));
+        simulate(b->d_u, b->n); // :205
+    }
+    HIP_TRY(hipMemcpyAsync(states + (size_t)num_sim * B * b->nx, b->d_x0, xb, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
     return PANTR_OK;
 }
 

@@ -783,18 +783,39 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
     }
 }
 
-/// Plant step x+ = f_d(x, u) for a batch (formulation.hpp:258-261).
+/// Plant step x+ = f_d(x, u) for a batch (formulation.hpp:258-261).  u rows are `u_stride`
+/// doubles apart (nu for a plain input batch, n to take the first block of a decision vector);
+/// xn may alias x.
 template <class M>
 __global__ __launch_bounds__(WAVE) void pantr_simulate_kernel(int B, const double *x, const double *u,
-                                                              double *xn) {
+                                                              int u_stride, double *xn) {
     const int lane = threadIdx.x, inst = blockIdx.x;
     if (inst >= B)
         return;
     typename M::Lane L(lane);
     auto s    = M::load_x0(L, x + (size_t)inst * M::nx);
-    double uc = M::load_input(L, u + (size_t)inst * M::nu);
+    double uc = M::load_input(L, u + (size_t)inst * u_stride);
     auto r    = M::rk4(L, s, uc);
     M::store_x(L, xn + (size_t)inst * M::nx, r);
+}
+
+/// Warm-start shift of the closed loop (mpc-driver.cpp:168-170): u[0:n-nu] = u[nu:n], last block
+/// kept; or, cold, u = the initial guess (mpc-driver.cpp:192-193; zero for this problem).
+__global__ void pantr_shift_kernel(int B, int n, int nu, int warm, double *u) {
+    const int inst = blockIdx.x;
+    if (inst >= B)
+        return;
+    double *ui = u + (size_t)inst * n;
+    for (int base = 0; base < n; base += blockDim.x) { // ascending blocks: reads stay ahead of writes
+        int i    = base + threadIdx.x;
+        double v = 0.0;
+        if (warm && i < n)
+            v = i + nu < n ? ui[i + nu] : ui[i];
+        __syncthreads();
+        if (i < n)
+            ui[i] = v;
+        __syncthreads();
+    }
 }
 
 } // namespace pantr

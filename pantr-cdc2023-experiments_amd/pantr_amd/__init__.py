@@ -67,7 +67,7 @@ EXPORTS = (
     "pantr_batch_last_kernel_ms", "pantr_batch_set_launch_order", "pantr_batch_set_trace",
     "pantr_batch_get_trace", "pantr_batch_eval_psi", "pantr_batch_eval_psi_grad_psi",
     "pantr_batch_eval_hess_psi_prod", "pantr_batch_eval_prox_grad_step",
-    "pantr_batch_simulate_dynamics", "pantr_last_error", "pantr_version", "pantr_device_count",
+    "pantr_batch_simulate_dynamics", "pantr_batch_mpc", "pantr_last_error", "pantr_version", "pantr_device_count",
     "pantr_batch_footprint",
 )
 
@@ -125,6 +125,7 @@ def lib():
         L.pantr_batch_eval_hess_psi_prod.argtypes = [vp, _i32, vp, vp, vp, vp]
         L.pantr_batch_eval_prox_grad_step.argtypes = [vp, _i32, _dbl, vp, vp, vp, vp, vp]
         L.pantr_batch_simulate_dynamics.argtypes = [vp, _i32, vp, vp, vp]
+        L.pantr_batch_mpc.argtypes = [vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp, vp]
         L.pantr_batch_footprint.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         _lib = L
     return _lib
@@ -298,6 +299,23 @@ class PantrBatch:
         xn = np.zeros((B, self.nx))
         _check(lib().pantr_batch_simulate_dynamics(self._h, B, _ptr(x), _ptr(u), _ptr(xn)))
         return xn
+
+
+    def mpc(self, num_sim, warm, u_dist, num_dist=5, x_init=None):
+        """B closed loops in lock-step on the device (do_mpc_experiment, mpc-driver.cpp:123-210).
+
+        u_dist: (B, nu) disturbance per trajectory.  Returns states (num_sim+1, B, nx),
+        inputs (num_sim, B, n), stats (num_sim, B)."""
+        u_dist = _f64(u_dist)
+        B = u_dist.shape[0]
+        states = np.zeros((num_sim + 1, B, self.nx))
+        inputs = np.zeros((num_sim, B, self.n))
+        stats = np.zeros((num_sim, B), dtype=STATS_DTYPE)
+        xi = None if x_init is None else _f64(x_init, (B, self.nx))
+        _check(lib().pantr_batch_mpc(self._h, B, num_sim, int(bool(warm)), num_dist,
+                                     None if xi is None else _ptr(xi), _ptr(u_dist), _ptr(states),
+                                     _ptr(inputs), _ptr(stats)))
+        return states, inputs, stats
 
 
 def device_count():

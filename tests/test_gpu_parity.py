@@ -126,3 +126,54 @@ def test_unsupported_option_fails_loudly():
     with pytest.raises(pa.PantrError):
         batch.solve(np.zeros((1, NX)), np.zeros((1, 15)))
     batch.close()
+
+
+@pytest.mark.parametrize("warm", [True, False])
+def test_closed_loops_in_lock_step_match_oracle(rng, warm):
+    """B trajectories advanced on the device (solve, plant step, shift) == B oracle closed loops."""
+    N, B, num_sim = 15, 6, 7
+    u_dist = rng.uniform(-1, 1, (B, NU))
+    u_dist[0] = (-1.0, 1.0, 1.0)                       # dodo.py:94-95
+    batch = pa.PantrBatch("hanging_chain", N, B, opts=pa.DODO_PANTR_OPTS)
+    states, inputs, stats = batch.mpc(num_sim, warm, u_dist, num_dist=5)
+    batch.close()
+    for b in range(B):
+        st_o, in_o, _, stats_o = ob.mpc(N, num_sim, warm, num_dist=5, u_dist=u_dist[b])
+        assert np.array_equal(states[:, b, :], st_o) and np.array_equal(inputs[:, b, :], in_o)
+        assert [s["iterations"] for s in stats_o] == stats["iterations"][:, b].tolist()
+        assert np.all(stats["status"][:, b] == 1)
+
+
+def test_config5_stress_horizon_120(rng):
+    """BASELINE.json configs[4]: N=120 (n=360), synthetic initial states x0_j = f_d^5(x_rest, d_j)."""
+    from pantr_amd import workloads
+    N, B = 120, 16
+    d = workloads.config5_disturbances(B)
+    batch = pa.PantrBatch("hanging_chain", N, B, opts=pa.DODO_PANTR_OPTS)
+    x0 = np.tile(batch.initial_state(), (B, 1))
+    for _ in range(5):
+        x0 = batch.simulate_dynamics(x0, d)
+    u, st = batch.solve(x0, np.zeros((B, NU * N)))
+    lds, ws = batch.footprint()
+    batch.close()
+    assert lds <= 160 * 1024 and np.all(st["status"] == 1) and np.all(st["eps"] <= 1e-8)
+    assert np.all(np.abs(u) <= 1.0)
+    for b in (0, 7, 15):
+        xo = ob.initial_state()
+        for _ in range(5):
+            xo = ob.simulate(xo, d[b])
+        assert np.array_equal(xo, x0[b])
+        u_o, st_o, _ = ob.solve(N, xo, np.zeros(NU * N))
+        assert np.array_equal(u[b], u_o) and st["iterations"][b] == st_o["iterations"]
+
+
+def test_config4_horizon_sweep(rng):
+    """BASELINE.json configs[3] in miniature: horizons x {cold, warm} closed loops == oracle."""
+    num_sim = 4
+    for N in (10, 20, 30):
+        for warm in (True, False):
+            batch = pa.PantrBatch("hanging_chain", N, 1, opts=pa.DODO_PANTR_OPTS)
+            states, inputs, stats = batch.mpc(num_sim, warm, np.array([[-1.0, 1.0, 1.0]]))
+            batch.close()
+            st_o, in_o, _, _ = ob.mpc(N, num_sim, warm)
+            assert np.array_equal(states[:, 0], st_o) and np.array_equal(inputs[:, 0], in_o)

@@ -151,3 +151,32 @@ def test_two_rank_sharded_batch_gloo(tmp_path):
     assert np.array_equal(d["gathered"], d["serial"])      # sharded == unsharded, bit for bit
     assert d["tmax"] >= max(d["t0"], d["t1"]) - 1e-12 and d["world"] == 2
     assert sorted(np.concatenate([d["idx0"], d["idx1"]]).tolist()) == list(range(len(d["serial"])))
+
+
+def test_mt19937_64_and_config5_disturbances():
+    from pantr_amd import workloads
+    g = workloads.MT19937_64()
+    for _ in range(9999):
+        g()
+    assert g() == 9981545732273789042          # C++ standard: 10000th output of a default mt19937_64
+    d = workloads.config5_disturbances(8)
+    assert d.shape == (8, 3) and np.all((d >= -1) & (d < 1))
+    assert np.array_equal(d, workloads.config5_disturbances(8))
+    # first draw of mt19937_64(12345), scaled: x / 2^64 * 2 - 1
+    x = workloads.MT19937_64(12345)()
+    assert abs(d[0, 0] - (x / 2.0 ** 64 * 2 - 1)) < 1e-15
+
+
+def test_dodo_enumeration():
+    """The PANTR rows of dodo.py:69-111 for hanging_chain."""
+    from pantr_amd import workloads
+    tasks = workloads.dodo_pantr_tasks("hanging_chain")
+    assert len(tasks) == 12
+    assert tasks[0]["name"] == "mpc-hanging_chain-10,60-warm-pantr"
+    assert tasks[-1]["name"] == "mpc-hanging_chain-60,60-cold-pantr"
+    t = tasks[5]
+    assert t["argv"][:4] == ["hanging_chain", "60", "ss2p", "method=pantr"]
+    assert "num_dist=5" in t["argv"] and "u_dist=-1,1,1" in t["argv"] and "warm=true" in t["argv"]
+    assert "solver.radius_factor_good=10" in t["argv"] and "alm.max_time=30s" in t["argv"]
+    q = workloads.dodo_pantr_tasks("realistic_quadcopter")[0]["argv"]
+    assert q.index("accel.tol_scale=1") > q.index("accel.tol_scale=1e-2")  # later option overrides
