@@ -86,6 +86,11 @@ inline Dual operator/(double c, Dual b) {
     double k = (-q) / b.v;
     return {q, b.t * k};
 }
+/// a / b = q with tangent (a.t - q b.t) / b.v
+inline Dual operator/(Dual a, Dual b) {
+    double q = a.v / b.v;
+    return {q, (a.t - q * b.t) / b.v};
+}
 /// sqrt(a) = r with tangent a.t * h, h = 0.5 / r
 inline Dual sqrt(Dual a) {
     double r = std::sqrt(a.v);
@@ -576,10 +581,11 @@ struct SingleShooting {
         return Model::cost_total(acc);
     }
 
-    double eval_psi(const double *u) const {
+    double eval_psi(const double *u, double * /*yhat: m = 0*/ = nullptr) const {
         ++cnt.psi;
         return eval_f_impl(u, nullptr);
     }
+    void set_al(const double *, const double *) {} ///< no general constraints
 
     /// psi and its gradient by a forward sweep + reverse (adjoint) sweep.  With record = true
     /// the adjoint sweep also records the second-order tape at u (same gradient arithmetic).

@@ -5,6 +5,7 @@
 // drivers/mpc-driver.cpp:123-210 and a threaded batch driver used as the CPU
 // baseline ("port") by bench.py.
 #include "pantr_oracle.hpp"
+#include "quad_models.hpp"
 #include <atomic>
 #include <thread>
 
@@ -24,13 +25,18 @@ struct OracleParams {
     double hessian_vec_factor, tol_scale, tol_scale_root, tol_max, max_iter_factor;
     // alm.*
     double alm_tolerance, alm_max_time_s;
+    double alm_dual_tolerance, alm_initial_penalty, alm_penalty_update_factor, alm_initial_tolerance,
+        alm_tolerance_update_factor;
     int32_t max_iter, stop_crit, max_no_progress, disable_acceleration;
+    int32_t alm_max_iter, pad0;
 };
 
 struct OracleStats {
     double eps, final_gamma, final_psi, final_fbe, final_radius, elapsed_s;
     int32_t status, iterations, cg_iterations, accepted, rejected, qub_backtracks;
     int32_t n_psi, n_grad_psi, n_psi_grad_psi, n_grad_L, n_hess_psi_prod, n_prox_grad_step;
+    int32_t outer_iterations, inner_convergence_failures;
+    double delta, penalty_norm;
 };
 
 /// Defaults = alpaqa defaults + mpc-driver.cpp:51-53,109-111.
@@ -54,6 +60,11 @@ void oracle_default_params(OracleParams *p) {
     p->tol_scale = c.tol_scale; p->tol_scale_root = c.tol_scale_root; p->tol_max = c.tol_max;
     p->max_iter_factor = c.max_iter_factor;
     p->alm_tolerance = alm.tolerance; p->alm_max_time_s = alm.max_time_s;
+    p->alm_dual_tolerance = alm.dual_tolerance; p->alm_initial_penalty = alm.initial_penalty;
+    p->alm_penalty_update_factor = alm.penalty_update_factor;
+    p->alm_initial_tolerance = alm.initial_tolerance;
+    p->alm_tolerance_update_factor = alm.tolerance_update_factor;
+    p->alm_max_iter = alm.max_iter; p->pad0 = 0;
     p->max_iter = 50000;          // mpc-driver.cpp:51
     p->stop_crit = FPRNorm;       // mpc-driver.cpp:53
     p->max_no_progress = a.max_no_progress;
@@ -64,6 +75,12 @@ void oracle_default_params(OracleParams *p) {
 void oracle_dodo_params(OracleParams *p) {
     oracle_default_params(p);
     p->alm_max_time_s = 30;               // alm.max_time=30s
+    p->alm_max_iter = 300;                // alm.max_iter=300
+    p->alm_initial_penalty = 1e4;         // alm.initial_penalty=1e4
+    p->alm_penalty_update_factor = 5;     // alm.penalty_update_factor=5
+    p->alm_initial_tolerance = 1e2;       // alm.initial_tolerance=1e2
+    p->alm_tolerance_update_factor = 0.1; // alm.tolerance_update_factor=0.1
+    p->alm_dual_tolerance = 1e-8;         // alm.dual_tolerance
     p->stop_crit = ProjGradUnitNorm;      // solver.stop_crit=ProjGradUnitNorm
     p->alm_tolerance = 1e-8;              // alm.tolerance
     p->radius_factor_rejected = 0.35;
@@ -75,8 +92,19 @@ void oracle_dodo_params(OracleParams *p) {
     p->tol_scale = 1e-2;
 }
 
-static PANTRSolver<Prob> make_solver(const OracleParams &p) {
-    PANTRSolver<Prob> s;
+static ALMParams make_alm(const OracleParams &p) {
+    ALMParams a;
+    a.max_iter = p.alm_max_iter; a.tolerance = p.alm_tolerance; a.dual_tolerance = p.alm_dual_tolerance;
+    a.max_time_s = p.alm_max_time_s; a.initial_penalty = p.alm_initial_penalty;
+    a.penalty_update_factor = p.alm_penalty_update_factor; a.initial_tolerance = p.alm_initial_tolerance;
+    a.tolerance_update_factor = p.alm_tolerance_update_factor;
+    return a;
+}
+
+extern "C++" {
+template <class P = Prob>
+static PANTRSolver<P> make_solver(const OracleParams &p) {
+    PANTRSolver<P> s;
     auto &a = s.params;
     a.L_0 = p.L_0; a.lip_eps = p.lip_eps; a.lip_delta = p.lip_delta;
     a.Lgamma_factor = p.Lgamma_factor; a.max_time_s = p.max_time_s;
@@ -96,6 +124,7 @@ static PANTRSolver<Prob> make_solver(const OracleParams &p) {
     s.accel_params.tol_max = p.tol_max; s.accel_params.max_iter_factor = p.max_iter_factor;
     return s;
 }
+} // extern "C++"
 
 static void export_stats(const Stats &s, OracleStats *o) {
     o->eps = s.eps; o->final_gamma = s.final_gamma; o->final_psi = s.final_psi;
@@ -106,6 +135,8 @@ static void export_stats(const Stats &s, OracleStats *o) {
     o->n_psi_grad_psi = (int32_t)s.n_psi_grad_psi; o->n_grad_L = (int32_t)s.n_grad_L;
     o->n_hess_psi_prod = (int32_t)s.n_hess_psi_prod;
     o->n_prox_grad_step = (int32_t)s.n_prox_grad_step;
+    o->outer_iterations = s.outer_iterations; o->inner_convergence_failures = s.inner_convergence_failures;
+    o->delta = s.delta; o->penalty_norm = s.penalty_norm;
 }
 
 // ---- problem functions --------------------------------------------------------------------
@@ -235,6 +266,111 @@ void oracle_chain_mpc(int N, const OracleParams *prm, int num_sim, int warm, int
         x0 = xn;
     }
     std::copy(x0.begin(), x0.end(), states + (size_t)num_sim * nx);
+}
+
+// ---- quadcopter problems (general constraints, ALM) -------------------------------------------
+extern "C++" {
+template <class F>
+static auto with_quad(int realistic, int N, F &&f) {
+    if (realistic) {
+        SingleShootingAL<RealisticQuadcopter> p(N);
+        return f(p);
+    }
+    SingleShootingAL<Quadcopter> p(N);
+    return f(p);
+}
+} // extern "C++"
+void oracle_sincos(double x, double *s, double *c) { sincos_det(x, *s, *c); }
+void oracle_quad_initial_state(double *x0) { Quadcopter::initial_state(x0); }
+void oracle_quad_bounds(double *ulb, double *uub, double *dlb, double *dub) {
+    for (int c = 0; c < 4; ++c) {
+        ulb[c] = Quadcopter::u_lb(c); uub[c] = Quadcopter::u_ub(c);
+        dlb[c] = Quadcopter::d_lb(c); dub[c] = Quadcopter::d_ub(c);
+    }
+}
+void oracle_quad_simulate(int realistic, const double *x, const double *u, double *xn) {
+    with_quad(realistic, 1, [&](auto &p) { p.simulate_dynamics(x, u, xn); return 0; });
+}
+void oracle_quad_fc(int realistic, const double *s, const double *u, double *ds) {
+    if (realistic) RealisticQuadcopter::fc(s, u, ds); else Quadcopter::fc(s, u, ds);
+}
+double oracle_quad_f_g(int realistic, int N, const double *x0, const double *u, double *g) {
+    return with_quad(realistic, N, [&](auto &p) {
+        std::copy(x0, x0 + 9, p.x0.begin());
+        p.eval_g(u, g);
+        return p.eval_f(u);
+    });
+}
+double oracle_quad_psi_grad(int realistic, int N, const double *x0, const double *y, const double *Sig,
+                            const double *u, double *grad, double *yhat) {
+    return with_quad(realistic, N, [&](auto &p) {
+        std::copy(x0, x0 + 9, p.x0.begin());
+        p.set_al(y, Sig);
+        p.eval_psi(u, yhat);
+        return p.eval_psi_grad_psi(u, grad);
+    });
+}
+void oracle_quad_hess_prod(int realistic, int N, const double *x0, const double *y, const double *Sig,
+                           const double *u, const double *v, double *Hv) {
+    with_quad(realistic, N, [&](auto &p) {
+        std::copy(x0, x0 + 9, p.x0.begin());
+        p.set_al(y, Sig);
+        p.eval_hess_psi_prod(u, v, Hv);
+        return 0;
+    });
+}
+/// ALM solve of one instance: u (n) and y (m) in/out.
+int oracle_quad_solve(int realistic, int N, const OracleParams *prm, const double *x0, double *u, double *y,
+                      OracleStats *st) {
+    return with_quad(realistic, N, [&](auto &p) {
+        using P = std::decay_t<decltype(p)>;
+        std::copy(x0, x0 + 9, p.x0.begin());
+        auto solver = make_solver<P>(*prm);
+        Stats s     = alm_solve(make_alm(*prm), solver, p, u, y);
+        export_stats(s, st);
+        return s.status;
+    });
+}
+/// Closed loop of mpc-driver.cpp:123-210 with multipliers: warm start shifts u by nu and y by nc.
+void oracle_quad_mpc(int realistic, int N, const OracleParams *prm, int num_sim, int warm, int num_dist,
+                     const double *u_dist, double *states, double *inputs, OracleStats *stats) {
+    with_quad(realistic, N, [&](auto &p) {
+        using P = std::decay_t<decltype(p)>;
+        const int nx = P::nx, nu = P::nu, nc = P::nc, n = p.n(), m = p.m();
+        auto solver = make_solver<P>(*prm);
+        ALMParams alm = make_alm(*prm);
+        std::vector<double> x0(nx), xn(nx), u(n), u_initial(n), y(m, 0.0);
+        Quadcopter::initial_state(x0.data());
+        for (int i = 0; i < n; ++i)
+            u_initial[i] = Quadcopter::initial_guess(i % nu);
+        u = u_initial;
+        for (int i = 0; i < num_dist; ++i) {
+            P::simulate_dynamics(x0.data(), u_dist, xn.data());
+            x0 = xn;
+        }
+        p.x0 = x0;
+        alm_solve(alm, solver, p, u.data(), y.data());
+        P::simulate_dynamics(x0.data(), u.data(), xn.data());
+        x0 = xn;
+        for (int i = 0; i < num_sim; ++i) {
+            if (warm) { // mpc-driver.cpp:168-175
+                std::copy(u.begin() + nu, u.end(), u.begin());
+                std::copy(y.begin() + nc, y.end(), y.begin());
+            } else {
+                u = u_initial;
+                std::fill(y.begin(), y.end(), 0.0);
+            }
+            p.x0 = x0;
+            Stats s = alm_solve(alm, solver, p, u.data(), y.data());
+            export_stats(s, &stats[i]);
+            std::copy(x0.begin(), x0.end(), states + (size_t)i * nx);
+            std::copy(u.begin(), u.end(), inputs + (size_t)i * n);
+            P::simulate_dynamics(x0.data(), u.data(), xn.data());
+            x0 = xn;
+        }
+        std::copy(x0.begin(), x0.end(), states + (size_t)num_sim * nx);
+        return 0;
+    });
 }
 
 /// Steihaug CG on a dense symmetric matrix (cross-check against SciPy).

@@ -72,6 +72,9 @@ struct Stats {
          n_prox_grad_step = 0;
     double eps = NaN, final_gamma = NaN, final_psi = NaN, final_fbe = NaN, final_radius = NaN;
     double elapsed_s = 0;
+    // ALM
+    int outer_iterations = 1, inner_convergence_failures = 0;
+    double delta = 0, penalty_norm = 0;
 };
 
 /// One record per PANTR iteration, used by the iterate-parity tests.
@@ -176,21 +179,25 @@ struct PANTRSolver {
     std::vector<TraceRow> *trace = nullptr;
 
     struct Iterate {
-        std::vector<double> x, xh, grad, p;
+        std::vector<double> x, xh, grad, p, yh; ///< yh = candidate multipliers yhat(xhat)
         double psi_x = NaN, psi_xh = NaN, gamma = NaN, L = NaN, pTp = NaN, gradTp = NaN;
-        explicit Iterate(int n) : x(n), xh(n), grad(n), p(n) {}
+        Iterate(int n, int m) : x(n), xh(n), grad(n), p(n), yh(m) {}
         /// forward-backward envelope (h(xhat) = 0 for a box)
         double fbe() const { return (psi_x + pTp / (2.0 * gamma)) + gradTp; }
     };
 
-    Stats operator()(const Problem &problem, double tolerance, double max_time_s,
-                     bool always_overwrite_results, double *x /*in/out, n*/) const {
+    /// x in/out (n); y in/out and Sigma (m) the multipliers/penalties of the ALM iteration
+    /// (nullptr when m = 0); err_z out (m): Sigma^{-1} (yhat - y).
+    Stats operator()(Problem &problem, double tolerance, double max_time_s,
+                     bool always_overwrite_results, double *x, double *y = nullptr,
+                     const double *Sigma = nullptr, double *err_z = nullptr) const {
         using clk = std::chrono::steady_clock;
         auto t0   = clk::now();
-        const int n = problem.n();
+        const int n = problem.n(), m = problem.m();
+        problem.set_al(y, Sigma);
         Stats s;
         const EvalCounters c0 = problem.cnt;
-        Iterate it0(n), it1(n), it2(n);
+        Iterate it0(n, m), it1(n, m), it2(n, m);
         Iterate *curr = &it0, *prox = &it1, *cand = &it2;
         std::vector<double> q(n), work(n), work2(n), rJ(n), wz(n), wr(n), wd(n), wBd(n), wev(n),
             vfull(n);
@@ -201,7 +208,7 @@ struct PANTRSolver {
             i.pTp    = dot(i.p.data(), i.p.data(), n);
             i.gradTp = dot(i.p.data(), i.grad.data(), n);
         };
-        auto eval_psi_xh = [&](Iterate &i) { i.psi_xh = problem.eval_psi(i.xh.data()); };
+        auto eval_psi_xh = [&](Iterate &i) { i.psi_xh = problem.eval_psi(i.xh.data(), i.yh.data()); };
         auto qub_violated = [&](const Iterate &i) {
             double margin = (1.0 + std::fabs(i.psi_x)) * params.quadratic_upperbound_tolerance_factor;
             return i.psi_xh > ((i.psi_x + i.gradTp) + (0.5 * i.L) * i.pTp) + margin;
@@ -216,8 +223,13 @@ struct PANTRSolver {
             }
         };
         auto finish = [&](int status, double eps_k, double radius) {
-            if (status == Converged || status == Interrupted || always_overwrite_results)
+            if (status == Converged || status == Interrupted || always_overwrite_results) {
+                for (int j = 0; j < m; ++j) { // err_z = Sigma^{-1} (yhat - y), then y <- yhat
+                    err_z[j] = (curr->yh[j] - y[j]) / Sigma[j];
+                    y[j]     = curr->yh[j];
+                }
                 std::copy(curr->xh.begin(), curr->xh.end(), x);
+            }
             s.status       = status;
             s.eps          = eps_k;
             s.final_gamma  = curr->gamma;
@@ -388,21 +400,93 @@ struct PANTRSolver {
     }
 };
 
-/// ALM shell (mpc-driver.cpp:104-115).  With m = 0 upstream ALM performs a single
-/// inner solve at alm.tolerance with always_overwrite_results = true.
+/// ALMParams: alpaqa defaults; mpc-driver.cpp:109-111 and dodo.py:12-22 override.
 struct ALMParams {
     int max_iter = 200;              // mpc-driver.cpp:109, dodo.py:13 sets 300
     double tolerance = 1e-8, dual_tolerance = 1e-8; // mpc-driver.cpp:110-111
     double max_time_s = 300;         // dodo.py:14 sets 30 s
     double initial_penalty = 1, penalty_update_factor = 10, initial_tolerance = 1,
-           tolerance_update_factor = 1e-1; // dodo.py:15-18 (unused while m = 0)
+           tolerance_update_factor = 1e-1; // dodo.py:15-18
+    double rel_penalty_increase_threshold = 0.1, max_multiplier = 1e9, max_penalty = 1e9;
+    int single_penalty_factor = 0;
 };
 
+/// ALM outer loop (alpaqa::ALMSolver::operator(), named at mpc-driver.cpp:107,114,217).
+/// m == 0: a single inner solve at alm.tolerance with always_overwrite_results = true.
+/// m > 0: Sigma_0 = initial_penalty, eps_0 = initial_tolerance; per outer iteration: project the
+/// multipliers, inner solve (y <- yhat, err = Sigma^{-1}(yhat - y)), stop when the inner solver
+/// converged with eps <= tolerance and ||err||_inf <= dual_tolerance; otherwise raise the
+/// penalty of the components whose violation did not shrink by the threshold factor,
+/// Sigma_i <- min(max_penalty, max(Delta |e_i| / ||e||_inf, 1) Sigma_i), and tighten eps.
 template <class Problem>
-Stats alm_solve(const ALMParams &alm, const PANTRSolver<Problem> &inner, const Problem &problem,
-                double *x) {
-    // m == 0: no general constraints
-    return inner(problem, alm.tolerance, alm.max_time_s, /*always_overwrite_results=*/true, x);
+Stats alm_solve(const ALMParams &alm, const PANTRSolver<Problem> &inner, Problem &problem, double *x,
+                double *y = nullptr) {
+    using clk = std::chrono::steady_clock;
+    auto t0   = clk::now();
+    const int m = problem.m();
+    if (m == 0)
+        return inner(problem, alm.tolerance, alm.max_time_s, /*always_overwrite_results=*/true, x);
+    std::vector<double> Sigma(m, alm.initial_penalty), e1(m, NaN), e2(m, NaN);
+    double norm_e1 = NaN, eps = alm.initial_tolerance;
+    const double Delta = alm.penalty_update_factor, rho = alm.tolerance_update_factor;
+    Stats total;
+    int num_successful = 0;
+    for (int i = 0; i < alm.max_iter; ++i) {
+        for (int j = 0; j < m; ++j) { // eval_proj_multipliers(y, M)
+            double ylb = problem.d_lb(j) == -inf ? 0.0 : -alm.max_multiplier;
+            double yub = problem.d_ub(j) == +inf ? 0.0 : +alm.max_multiplier;
+            y[j]       = std::fmin(std::fmax(y[j], ylb), yub);
+        }
+        double elapsed = std::chrono::duration<double>(clk::now() - t0).count();
+        Stats ps = inner(problem, eps, std::fmax(alm.max_time_s - elapsed, 0.0), true, x, y, Sigma.data(),
+                         e2.data());
+        bool inner_converged = ps.status == Converged;
+        total.iterations += ps.iterations;
+        total.cg_iterations += ps.cg_iterations;
+        total.accepted += ps.accepted;
+        total.rejected += ps.rejected;
+        total.qub_backtracks += ps.qub_backtracks;
+        total.n_psi += ps.n_psi; total.n_grad_psi += ps.n_grad_psi; total.n_psi_grad_psi += ps.n_psi_grad_psi;
+        total.n_grad_L += ps.n_grad_L; total.n_hess_psi_prod += ps.n_hess_psi_prod;
+        total.n_prox_grad_step += ps.n_prox_grad_step;
+        total.inner_convergence_failures += inner_converged ? 0 : 1;
+        double norm_e2 = norm_inf(e2.data(), m);
+        elapsed        = std::chrono::duration<double>(clk::now() - t0).count();
+        bool alm_converged = ps.eps <= alm.tolerance && inner_converged && norm_e2 <= alm.dual_tolerance;
+        bool out_of_time = elapsed > alm.max_time_s, out_of_iter = i + 1 == alm.max_iter;
+        if (alm_converged || out_of_iter || out_of_time) {
+            total.status = alm_converged ? Converged : out_of_time ? MaxTime : MaxIter;
+            total.eps = ps.eps; total.delta = norm_e2; total.outer_iterations = i + 1;
+            total.final_gamma = ps.final_gamma; total.final_psi = ps.final_psi; total.final_fbe = ps.final_fbe;
+            total.final_radius = ps.final_radius; total.elapsed_s = elapsed;
+            double sq = 0;
+            for (int j = 0; j < m; ++j)
+                sq += Sigma[j] * Sigma[j];
+            total.penalty_norm = std::sqrt(sq / m);
+            return total;
+        }
+        // update_penalty_weights: e2 = current error, e1 = previous
+        if (norm_e2 > alm.dual_tolerance) {
+            bool first = num_successful == 0;
+            if (alm.single_penalty_factor) {
+                if (first || norm_e2 > alm.rel_penalty_increase_threshold * norm_e1) {
+                    double ns = std::fmin(alm.max_penalty, Delta * Sigma[0]);
+                    std::fill(Sigma.begin(), Sigma.end(), ns);
+                }
+            } else {
+                for (int j = 0; j < m; ++j)
+                    if (first || std::fabs(e2[j]) > alm.rel_penalty_increase_threshold * std::fabs(e1[j]))
+                        Sigma[j] = std::fmin(alm.max_penalty,
+                                             std::fmax((Delta * std::fabs(e2[j])) / norm_e2, 1.0) * Sigma[j]);
+            }
+        }
+        eps = std::fmax(rho * eps, alm.tolerance);
+        ++num_successful;
+        std::swap(e1, e2);
+        norm_e1 = norm_e2;
+    }
+    total.status = MaxIter;
+    return total;
 }
 
 } // namespace oracle

@@ -1,0 +1,477 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle/README.md).
+//
+// Plain scalar restatement of the quadcopter and realistic_quadcopter optimal-control problems
+// and of the single-shooting augmented-Lagrangian problem functions for problems with general
+// constraints.  `method=pantr` loads the CasADi problem generated from the Python models
+// (problems/generate_problem.py:26-61), so those are the text followed:
+//   quadcopter ............ python/alpaqa_mpc_benchmarks/problems/quadcopter.py:6-112
+//                           (C++ twin problems/problems/quadcopter.cpp:69-160)
+//   realistic_quadcopter .. python/alpaqa_mpc_benchmarks/problems/realistic_quadcopter.py:6-118
+//                           (C++ twin problems/problems/realistic_quadcopter.cpp:69-162)
+//   single shooting ....... python/alpaqa_mpc_benchmarks/formulations/ss.py:20-55
+//                           (constraints on x_0..x_{N-1} and x_N: ss.py:39-40)
+//   psi, grad, Hv ......... problems/problems/formulation.hpp:79-99
+//                           zeta = g + y/Sigma, zhat = clamp(zeta, D), d = zeta - zhat,
+//                           yhat = Sigma d, psi = f + 1/2 yhat'd
+// sin/cos: one short deterministic routine (2-term Cody-Waite reduction + the fdlibm kernel
+// polynomials, explicit fma) used identically by the kernels, so trigonometric values agree
+// bit for bit between CPU and GPU (libm and the device math library do not).
+#pragma once
+#include "chain_model.hpp"
+
+namespace oracle {
+
+// ---------------------------------------------------------------------------
+// deterministic sin/cos
+// ---------------------------------------------------------------------------
+inline void sincos_det(double x, double &s, double &c) {
+    const double kd = std::nearbyint(x * 6.36619772367581382433e-01); // x * 2/pi, ties to even
+    double r        = std::fma(-kd, 1.57079632673412561417e+00, x);  // pi/2, leading bits
+    r               = std::fma(-kd, 6.07710050650619224932e-11, r);  // pi/2, next bits
+    const double z  = r * r;
+    double ps = std::fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps        = std::fma(z, ps, 2.75573137070700676789e-06);
+    ps        = std::fma(z, ps, -1.98412698298579493134e-04);
+    ps        = std::fma(z, ps, 8.33333333332248946124e-03);
+    ps        = std::fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = std::fma(r * z, ps, r);
+    double pc = std::fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc        = std::fma(z, pc, -2.75573143513906633035e-07);
+    pc        = std::fma(z, pc, 2.48015872894767294178e-05);
+    pc        = std::fma(z, pc, -1.38888888888741095749e-03);
+    pc        = std::fma(z, pc, 4.16666666666666019037e-02);
+    const double cr = std::fma(z * z, pc, std::fma(-0.5, z, 1.0));
+    const long long q = static_cast<long long>(kd) & 3;
+    s = q == 0 ? sr : q == 1 ? cr : q == 2 ? -sr : -cr;
+    c = q == 0 ? cr : q == 1 ? -sr : q == 2 ? -cr : sr;
+}
+inline void sincos_t(double x, double &s, double &c) { sincos_det(x, s, c); }
+inline void sincos_t(Dual x, Dual &s, Dual &c) {
+    double sv, cv;
+    sincos_det(x.v, sv, cv);
+    s = {sv, cv * x.t};
+    c = {cv, -(sv * x.t)};
+}
+inline Dual operator-(Dual a) { return {-a.v, -a.t}; }
+/// clamp pieces with the tangent of the selected branch
+inline double tmin(double a, double b) { return a < b ? a : b; }
+inline double tmax(double a, double b) { return a > b ? a : b; }
+inline Dual tmin(Dual a, double b) { return a.v < b ? a : Dual{b, 0.0}; }
+inline Dual tmax(Dual a, double b) { return a.v > b ? a : Dual{b, 0.0}; }
+
+// ---------------------------------------------------------------------------
+// quadcopter models: state (p[3], v[3], theta[3]), input (a_t, omega[3])
+// ---------------------------------------------------------------------------
+template <bool REALISTIC>
+struct QuadcopterT {
+    static constexpr int nx = 9, nu = 4, nc = 4;
+    static constexpr double Ts = 0.1, g_grav = 9.81, c6 = Ts / 6;
+    static constexpr double r2 = 0.1 * 0.1; ///< collision cylinder radius squared (quadcopter.py:70)
+    static constexpr double pf[3] = {0.25, 0.25, 0.5}; // quadcopter.py:90
+    static const char *name() { return REALISTIC ? "realistic_quadcopter" : "quadcopter"; }
+
+    static double u_lb(int c) { return c == 0 ? 0.0 : -0.1; }          // quadcopter.py:55-58
+    static double u_ub(int c) { return c == 0 ? 9.81 * 5 : 0.1; }
+    static double d_lb(int i) { // quadcopter.py:72-75
+        return i < 2 ? -1.5707963267948966 : i == 2 ? 0.8525245220595057 /* cos(1.1/2) */ : -inf_();
+    }
+    static double d_ub(int i) { return i < 2 ? 1.5707963267948966 : i == 2 ? inf_() : 0.0; }
+    static constexpr double inf_() { return std::numeric_limits<double>::infinity(); }
+    static void initial_state(double *x0) { // quadcopter.py:80-88
+        const double v[9] = {-0.2, -0.25, 0.5, 0, 0, 0, 0, 0, 0};
+        std::copy(v, v + 9, x0);
+    }
+    static double initial_guess(int c) { return c == 0 ? 9.81 : 0.0; } // quadcopter.py:111
+
+    /// Third column of the body-to-world rotation and, for the realistic model, the Euler-rate
+    /// map d_orient = Omega^{-1} omega, with the trigonometric values they are built from.
+    template <class T>
+    struct Trig {
+        T s0, c0, s1, c1, s2, c2;
+    };
+    template <class T>
+    static Trig<T> trig(const T *s) {
+        Trig<T> t;
+        sincos_t(s[6], t.s0, t.c0);
+        sincos_t(s[7], t.s1, t.c1);
+        sincos_t(s[8], t.s2, t.c2);
+        return t;
+    }
+
+    /// f_c(state, input) (quadcopter.py:30-46, realistic_quadcopter.py:30-50)
+    template <class T>
+    static void fc(const T *s, const T *u, T *ds) {
+        const Trig<T> t = trig(s);
+        T r0, r1, r2_;
+        if (!REALISTIC) { // (cr,sr)=(c0,s0) roll, (cp,sp)=(c1,s1) pitch, (cy,sy)=(c2,s2) yaw
+            r0  = ((t.c2 * t.s1) * t.c0) + (t.s2 * t.s0);
+            r1  = ((t.s2 * t.s1) * t.c0) - (t.c2 * t.s0);
+            r2_ = t.c1 * t.c0;
+        } else { // phi = s[6], theta = s[7], psi = s[8]
+            r0  = (t.c2 * t.s1) + ((t.c1 * t.s0) * t.s2);
+            r1  = (t.s2 * t.s1) - ((t.c2 * t.c1) * t.s0);
+            r2_ = t.c0 * t.c1;
+        }
+        ds[0] = s[3];
+        ds[1] = s[4];
+        ds[2] = s[5];
+        ds[3] = r0 * u[0];
+        ds[4] = r1 * u[0];
+        ds[5] = (r2_ * u[0]) - g_grav;
+        if (!REALISTIC) {
+            ds[6] = u[1];
+            ds[7] = u[2];
+            ds[8] = u[3];
+        } else { // Omega [a b c]' = omega, Omega = [[c1,0,-c0 s1],[0,1,s0],[s1,0,c0 c1]], det = c0
+            T a   = (t.c1 * u[1]) + (t.s1 * u[3]);
+            T cc  = ((t.c1 * u[3]) - (t.s1 * u[1])) / t.c0;
+            T b   = u[2] - (t.s0 * cc);
+            ds[6] = a;
+            ds[7] = b;
+            ds[8] = cc;
+        }
+    }
+
+    /// Adjoint of f_c: sb = (df/ds)' kb, ub = (df/du)' kb.
+    template <class T>
+    static void fc_adj(const T *s, const T *u, const T *kb, T *sb, T *ub) {
+        const Trig<T> t = trig(s);
+        const T at = u[0];
+        T r0, r1, r2_, dr0[3], dr1[3], dr2[3]; // d r_i / d s[6+j]
+        if (!REALISTIC) {
+            r0     = ((t.c2 * t.s1) * t.c0) + (t.s2 * t.s0);
+            r1     = ((t.s2 * t.s1) * t.c0) - (t.c2 * t.s0);
+            r2_    = t.c1 * t.c0;
+            dr0[0] = (t.s2 * t.c0) - ((t.c2 * t.s1) * t.s0);
+            dr0[1] = (t.c2 * t.c1) * t.c0;
+            dr0[2] = (t.c2 * t.s0) - ((t.s2 * t.s1) * t.c0);
+            dr1[0] = -(((t.s2 * t.s1) * t.s0) + (t.c2 * t.c0));
+            dr1[1] = (t.s2 * t.c1) * t.c0;
+            dr1[2] = r0;
+            dr2[0] = -(t.c1 * t.s0);
+            dr2[1] = -(t.s1 * t.c0);
+            dr2[2] = T{} * t.c0; // 0
+        } else {
+            r0     = (t.c2 * t.s1) + ((t.c1 * t.s0) * t.s2);
+            r1     = (t.s2 * t.s1) - ((t.c2 * t.c1) * t.s0);
+            r2_    = t.c0 * t.c1;
+            dr0[0] = (t.c1 * t.c0) * t.s2;
+            dr0[1] = (t.c2 * t.c1) - ((t.s1 * t.s0) * t.s2);
+            dr0[2] = ((t.c1 * t.s0) * t.c2) - (t.s2 * t.s1);
+            dr1[0] = -((t.c2 * t.c1) * t.c0);
+            dr1[1] = (t.s2 * t.c1) + ((t.c2 * t.s1) * t.s0);
+            dr1[2] = r0;
+            dr2[0] = -(t.s0 * t.c1);
+            dr2[1] = -(t.c0 * t.s1);
+            dr2[2] = T{} * t.c0; // 0
+        }
+        const T a0 = kb[3], a1 = kb[4], a2 = kb[5];
+        sb[0] = T{} * at; // no dependence on p
+        sb[1] = sb[0];
+        sb[2] = sb[0];
+        sb[3] = kb[0];
+        sb[4] = kb[1];
+        sb[5] = kb[2];
+        ub[0] = ((r0 * a0) + (r1 * a1)) + (r2_ * a2);
+        const T w0 = at * a0, w1 = at * a1, w2 = at * a2;
+        for (int j = 0; j < 3; ++j)
+            sb[6 + j] = ((dr0[j] * w0) + (dr1[j] * w1)) + (dr2[j] * w2);
+        if (!REALISTIC) {
+            ub[1] = kb[6];
+            ub[2] = kb[7];
+            ub[3] = kb[8];
+        } else {
+            // a = c1 u1 + s1 u3 ; cc = (c1 u3 - s1 u1)/c0 ; b = u2 - s0 cc
+            const T ka = kb[6], kb_ = kb[7], kc = kb[8];
+            const T num = (t.c1 * u[3]) - (t.s1 * u[1]);
+            const T cc  = num / t.c0;
+            const T kcc = kc - (t.s0 * kb_);   // total adjoint of cc
+            const T q   = kcc / t.c0;          // adjoint of num
+            ub[1] = (t.c1 * ka) - (t.s1 * q);
+            ub[2] = kb_;
+            ub[3] = (t.s1 * ka) + (t.c1 * q);
+            // d/dphi (s[6]): b -> -c0 cc kb_ ; cc = num/c0 -> num s0/c0^2 = cc s0/c0
+            sb[6] = sb[6] + (((cc * t.s0) / t.c0) * kcc - ((t.c0 * cc) * kb_));
+            // d/dtheta (s[7]): a -> (-s1 u1 + c1 u3) ka = num ka ; num -> (-s1 u3 - c1 u1) q
+            sb[7] = sb[7] + ((num * ka) - (((t.s1 * u[3]) + (t.c1 * u[1])) * q));
+        }
+    }
+
+    /// l(x,u) (quadcopter.py:93-106): lu + lx
+    template <class T>
+    static T stage_cost(const T *s, const T *u) {
+        T su  = (((u[0] * u[0]) + (u[1] * u[1])) + (u[2] * u[2])) + (u[3] * u[3]);
+        T so  = ((u[1] * u[1]) + (u[2] * u[2])) + (u[3] * u[3]);
+        T lu  = (1e-4 * su) + (10.0 * so);
+        return lu + state_cost(s, 1.0, 10.0, 1.0);
+    }
+    /// l_N(x) (quadcopter.py:107-112)
+    template <class T>
+    static T term_cost(const T *s) { return state_cost(s, 25.0, 250.0, 10.0); }
+    template <class T>
+    static T state_cost(const T *s, double qv, double qp, double qth) {
+        T d0 = s[0] - pf[0], d1 = s[1] - pf[1], d2 = s[2] - pf[2];
+        T sp = ((d0 * d0) + (d1 * d1)) + (d2 * d2);
+        T sv = ((s[3] * s[3]) + (s[4] * s[4])) + (s[5] * s[5]);
+        T st = ((s[6] * s[6]) + (s[7] * s[7])) + (s[8] * s[8]);
+        return ((qv * sv) + (qp * sp)) + (qth * st);
+    }
+    /// gs += dl/dx, gu = dl/du  (u == nullptr: terminal cost)
+    template <class T>
+    static void cost_grad(const T *s, const T *u, T *gs, T *gu) {
+        const double qv = u ? 1.0 : 25.0, qp = u ? 10.0 : 250.0, qth = u ? 1.0 : 10.0;
+        for (int i = 0; i < 3; ++i) {
+            gs[i]     = gs[i] + (2.0 * qp) * (s[i] - pf[i]);
+            gs[3 + i] = gs[3 + i] + (2.0 * qv) * s[3 + i];
+            gs[6 + i] = gs[6 + i] + (2.0 * qth) * s[6 + i];
+        }
+        if (u) {
+            gu[0] = 2e-4 * u[0];
+            for (int j = 1; j < 4; ++j)
+                gu[j] = (2e-4 * u[j]) + (20.0 * u[j]);
+        }
+    }
+
+    /// c(x) (quadcopter.py:62-71)
+    template <class T>
+    static void constr(const T *s, T *c) {
+        T s0, c0, s1, c1;
+        sincos_t(s[6], s0, c0);
+        sincos_t(s[7], s1, c1);
+        c[0] = s[6];
+        c[1] = s[7];
+        c[2] = c0 * c1;
+        c[3] = (r2 - (s[0] * s[0])) - (s[1] * s[1]);
+    }
+    /// sb += (dc/dx)' yb
+    template <class T>
+    static void constr_adj(const T *s, const T *yb, T *sb) {
+        T s0, c0, s1, c1;
+        sincos_t(s[6], s0, c0);
+        sincos_t(s[7], s1, c1);
+        sb[6] = sb[6] + (yb[0] - ((s0 * c1) * yb[2]));
+        sb[7] = sb[7] + (yb[1] - ((c0 * s1) * yb[2]));
+        sb[0] = sb[0] - ((2.0 * s[0]) * yb[3]);
+        sb[1] = sb[1] - ((2.0 * s[1]) * yb[3]);
+    }
+};
+using Quadcopter          = QuadcopterT<false>;
+using RealisticQuadcopter = QuadcopterT<true>;
+
+// ---------------------------------------------------------------------------
+// Single shooting with general constraints (augmented Lagrangian), scalar models
+// ---------------------------------------------------------------------------
+template <class Model>
+struct SingleShootingAL {
+    int N;
+    std::vector<double> x0;
+    mutable EvalCounters cnt;
+    const double *y = nullptr, *Sig = nullptr; ///< multipliers and penalties of the current ALM iteration
+    static constexpr int nx = Model::nx, nu = Model::nu, nc = Model::nc;
+
+    explicit SingleShootingAL(int N_) : N(N_), x0(nx) { Model::initial_state(x0.data()); }
+    int n() const { return nu * N; }
+    int m() const { return nc * N + nc; } // ss.py:39-40: c on x_0..x_{N-1}, c_N on x_N
+    void set_al(const double *y_, const double *Sig_) { y = y_; Sig = Sig_; }
+    double lb(int i) const { return Model::u_lb(i % nu); }
+    double ub(int i) const { return Model::u_ub(i % nu); }
+    double d_lb(int i) const { return Model::d_lb(i % nc); } // formulation.hpp:229-238
+    double d_ub(int i) const { return Model::d_ub(i % nc); }
+
+    template <class T>
+    static void rk4(const T *s, const T *u, T *xn) {
+        T k1[nx], k2[nx], k3[nx], k4[nx], w[nx];
+        Model::fc(s, u, k1);
+        for (int l = 0; l < nx; ++l)
+            w[l] = s[l] + 0.5 * (Model::Ts * k1[l]);
+        Model::fc(w, u, k2);
+        for (int l = 0; l < nx; ++l)
+            w[l] = s[l] + 0.5 * (Model::Ts * k2[l]);
+        Model::fc(w, u, k3);
+        for (int l = 0; l < nx; ++l)
+            w[l] = s[l] + Model::Ts * k3[l];
+        Model::fc(w, u, k4);
+        for (int l = 0; l < nx; ++l)
+            xn[l] = s[l] + Model::c6 * (((k1[l] + 2.0 * k2[l]) + 2.0 * k3[l]) + k4[l]);
+    }
+    template <class T>
+    static void rk4_adj(const T *s, const T *u, const T *mu, T *sbar, T *ubar) {
+        T k[nx], w2[nx], w3[nx], w4[nx];
+        Model::fc(s, u, k);
+        for (int l = 0; l < nx; ++l)
+            w2[l] = s[l] + 0.5 * (Model::Ts * k[l]);
+        Model::fc(w2, u, k);
+        for (int l = 0; l < nx; ++l)
+            w3[l] = s[l] + 0.5 * (Model::Ts * k[l]);
+        Model::fc(w3, u, k);
+        for (int l = 0; l < nx; ++l)
+            w4[l] = s[l] + Model::Ts * k[l];
+        T kb1[nx], kb2[nx], kb3[nx], kb4[nx], a[nx], ua[nu];
+        for (int l = 0; l < nx; ++l) {
+            T sg   = Model::c6 * mu[l];
+            kb1[l] = sg;
+            kb2[l] = 2.0 * sg;
+            kb3[l] = 2.0 * sg;
+            kb4[l] = sg;
+            sbar[l] = mu[l];
+        }
+        Model::fc_adj(w4, u, kb4, a, ubar);
+        for (int l = 0; l < nx; ++l) {
+            sbar[l] = sbar[l] + a[l];
+            kb3[l]  = kb3[l] + Model::Ts * a[l];
+        }
+        Model::fc_adj(w3, u, kb3, a, ua);
+        for (int c = 0; c < nu; ++c)
+            ubar[c] = ubar[c] + ua[c];
+        for (int l = 0; l < nx; ++l) {
+            sbar[l] = sbar[l] + a[l];
+            kb2[l]  = kb2[l] + 0.5 * (Model::Ts * a[l]);
+        }
+        Model::fc_adj(w2, u, kb2, a, ua);
+        for (int c = 0; c < nu; ++c)
+            ubar[c] = ubar[c] + ua[c];
+        for (int l = 0; l < nx; ++l) {
+            sbar[l] = sbar[l] + a[l];
+            kb1[l]  = kb1[l] + 0.5 * (Model::Ts * a[l]);
+        }
+        Model::fc_adj(s, u, kb1, a, ua);
+        for (int c = 0; c < nu; ++c)
+            ubar[c] = ubar[c] + ua[c];
+        for (int l = 0; l < nx; ++l)
+            sbar[l] = sbar[l] + a[l];
+    }
+
+    /// Forward sweep: psi (and yhat), trajectory.  u_t/X typed T for the dual-number product.
+    template <class T>
+    T forward(const T *u, T *X /*(N+1)*nx*/, T *yhat /*m or nullptr*/) const {
+        T s[nx], xn[nx], c[nc];
+        for (int l = 0; l < nx; ++l)
+            s[l] = T{} + x0[l];
+        T accf = T{}, accal = T{};
+        for (int k = 0; k <= N; ++k) {
+            for (int l = 0; l < nx; ++l)
+                X[k * nx + l] = s[l];
+            Model::constr(s, c);
+            for (int i = 0; i < nc; ++i) {
+                int j     = nc * k + i;
+                T zeta    = c[i] + (y[j] / Sig[j]);
+                T zhat    = tmax(tmin(zeta, d_ub(j)), d_lb(j));
+                T d       = zeta - zhat;
+                T yh      = Sig[j] * d;
+                if (yhat)
+                    yhat[j] = yh;
+                accal = accal + (yh * d);
+            }
+            if (k == N)
+                break;
+            accf = accf + Model::stage_cost(s, u + nu * k);
+            rk4(s, u + nu * k, xn);
+            for (int l = 0; l < nx; ++l)
+                s[l] = xn[l];
+        }
+        accf = accf + Model::term_cost(s);
+        return accf + (0.5 * accal);
+    }
+    /// Adjoint sweep over a stored trajectory with multipliers yhat: grad = grad_u (f + yhat' g).
+    template <class T>
+    void reverse(const T *u, const T *X, const T *yhat, T *grad) const {
+        T lam[nx], sbar[nx], ubar[nu], gu[nu];
+        for (int l = 0; l < nx; ++l)
+            lam[l] = T{};
+        Model::cost_grad(X + N * nx, static_cast<const T *>(nullptr), lam, gu);
+        Model::constr_adj(X + N * nx, yhat + nc * N, lam);
+        for (int k = N - 1; k >= 0; --k) {
+            const T *s = X + k * nx;
+            rk4_adj(s, u + nu * k, lam, sbar, ubar);
+            for (int l = 0; l < nx; ++l)
+                lam[l] = sbar[l];
+            Model::cost_grad(s, u + nu * k, lam, gu);
+            for (int c = 0; c < nu; ++c)
+                grad[nu * k + c] = ubar[c] + gu[c];
+            Model::constr_adj(s, yhat + nc * k, lam);
+        }
+    }
+
+    double eval_psi(const double *u, double *yhat) const {
+        ++cnt.psi;
+        std::vector<double> X((N + 1) * nx);
+        return forward(u, X.data(), yhat);
+    }
+    double psi_grad_impl(const double *u, double *grad) const {
+        std::vector<double> X((N + 1) * nx), yh(m());
+        double psi = forward(u, X.data(), yh.data());
+        reverse(u, X.data(), yh.data(), grad);
+        return psi;
+    }
+    double eval_psi_grad_psi(const double *u, double *grad) const {
+        ++cnt.psi_grad_psi;
+        return psi_grad_impl(u, grad);
+    }
+    void eval_grad_psi(const double *u, double *grad) const {
+        ++cnt.grad_psi;
+        psi_grad_impl(u, grad);
+    }
+    /// grad_L(xhat, yhat(xhat)) = grad psi(xhat)  (formulation.hpp:98-99 with y = yhat)
+    void eval_grad_L(const double *u, double *grad) const {
+        ++cnt.grad_L;
+        psi_grad_impl(u, grad);
+    }
+    /// Hessian-vector product of psi by forward-over-reverse on dual numbers
+    /// (formulation.hpp:93-97: gradient(jtimes(aug_lagr, u, v), u)).
+    void eval_hess_psi_prod(const double *u, const double *v, double *Hv) const {
+        ++cnt.hess_psi_prod;
+        std::vector<Dual> ud(n()), X((N + 1) * nx), yh(m()), g(n());
+        for (int i = 0; i < n(); ++i)
+            ud[i] = {u[i], v[i]};
+        forward(ud.data(), X.data(), yh.data());
+        reverse(ud.data(), X.data(), yh.data(), g.data());
+        for (int i = 0; i < n(); ++i)
+            Hv[i] = g[i].t;
+    }
+    double eval_f(const double *u) const { // formulation.hpp:57-60
+        std::vector<double> X((N + 1) * nx), zero(m(), 0.0), one(m(), 1.0);
+        SingleShootingAL tmp(*this);
+        tmp.set_al(zero.data(), one.data());
+        std::vector<double> s(nx), xn(nx);
+        double acc = 0;
+        std::copy(x0.begin(), x0.end(), s.begin());
+        for (int k = 0; k < N; ++k) {
+            acc = acc + Model::stage_cost(s.data(), u + nu * k);
+            rk4(s.data(), u + nu * k, xn.data());
+            s = xn;
+        }
+        return acc + Model::term_cost(s.data());
+    }
+    void eval_g(const double *u, double *g) const { // formulation.hpp:64-67
+        std::vector<double> s(x0), xn(nx);
+        for (int k = 0; k <= N; ++k) {
+            Model::constr(s.data(), g + nc * k);
+            if (k == N)
+                break;
+            rk4(s.data(), u + nu * k, xn.data());
+            s = xn;
+        }
+    }
+    void eval_prox_grad_step(double gamma, const double *x, const double *grad, double *xh,
+                             double *p) const {
+        ++cnt.prox_grad_step;
+        for (int i = 0; i < n(); ++i) {
+            double t = (-gamma) * grad[i];
+            p[i]     = std::fmin(std::fmax(t, lb(i) - x[i]), ub(i) - x[i]);
+            xh[i]    = x[i] + p[i];
+        }
+    }
+    int eval_inactive_indices_res_lna(double gamma, const double *x, const double *grad,
+                                      unsigned char *mask) const {
+        int nJ = 0;
+        for (int i = 0; i < n(); ++i) {
+            double xfw = x[i] - gamma * grad[i];
+            mask[i]    = lb(i) < xfw && xfw < ub(i);
+            nJ += mask[i];
+        }
+        return nJ;
+    }
+    static void simulate_dynamics(const double *x, const double *u, double *xn) { rk4(x, u, xn); }
+};
+
+} // namespace oracle

@@ -23,9 +23,10 @@ PARAM_DOUBLES = [
     "ratio_threshold_acceptable", "ratio_threshold_good", "radius_factor_rejected",
     "radius_factor_acceptable", "radius_factor_good", "initial_radius", "min_radius",
     "hessian_vec_factor", "tol_scale", "tol_scale_root", "tol_max", "max_iter_factor",
-    "alm_tolerance", "alm_max_time_s",
+    "alm_tolerance", "alm_max_time_s", "alm_dual_tolerance", "alm_initial_penalty",
+    "alm_penalty_update_factor", "alm_initial_tolerance", "alm_tolerance_update_factor",
 ]
-PARAM_INTS = ["max_iter", "stop_crit", "max_no_progress", "disable_acceleration"]
+PARAM_INTS = ["max_iter", "stop_crit", "max_no_progress", "disable_acceleration", "alm_max_iter", "pad0"]
 
 STOP_CRIT = {"ApproxKKT": 0, "ApproxKKT2": 1, "ProjGradNorm": 2, "ProjGradNorm2": 3,
              "ProjGradUnitNorm": 4, "ProjGradUnitNorm2": 5, "FPRNorm": 6, "FPRNorm2": 7}
@@ -43,7 +44,9 @@ class OracleStats(C.Structure):
                [(k, _i32) for k in ("status", "iterations", "cg_iterations", "accepted",
                                     "rejected", "qub_backtracks", "n_psi", "n_grad_psi",
                                     "n_psi_grad_psi", "n_grad_L", "n_hess_psi_prod",
-                                    "n_prox_grad_step")]
+                                    "n_prox_grad_step", "outer_iterations",
+                                    "inner_convergence_failures")] + \
+               [(k, _dbl) for k in ("delta", "penalty_norm")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -95,6 +98,21 @@ def lib():
                                                _pd, C.POINTER(OracleStats), C.c_int]
         L.oracle_chain_mpc.argtypes = [C.c_int, C.POINTER(OracleParams), C.c_int, C.c_int,
                                        C.c_int, _pd, _pd, _pd, _pd, C.POINTER(OracleStats)]
+        L.oracle_sincos.argtypes = [_dbl, C.POINTER(_dbl), C.POINTER(_dbl)]
+        L.oracle_quad_initial_state.argtypes = [_pd]
+        L.oracle_quad_bounds.argtypes = [_pd, _pd, _pd, _pd]
+        L.oracle_quad_simulate.argtypes = [C.c_int, _pd, _pd, _pd]
+        L.oracle_quad_fc.argtypes = [C.c_int, _pd, _pd, _pd]
+        L.oracle_quad_f_g.argtypes = [C.c_int, C.c_int, _pd, _pd, _pd]
+        L.oracle_quad_f_g.restype = _dbl
+        L.oracle_quad_psi_grad.argtypes = [C.c_int, C.c_int, _pd, _pd, _pd, _pd, _pd, _pd]
+        L.oracle_quad_psi_grad.restype = _dbl
+        L.oracle_quad_hess_prod.argtypes = [C.c_int, C.c_int, _pd, _pd, _pd, _pd, _pd, _pd]
+        L.oracle_quad_solve.argtypes = [C.c_int, C.c_int, C.POINTER(OracleParams), _pd, _pd, _pd,
+                                        C.POINTER(OracleStats)]
+        L.oracle_quad_solve.restype = C.c_int
+        L.oracle_quad_mpc.argtypes = [C.c_int, C.c_int, C.POINTER(OracleParams), C.c_int, C.c_int,
+                                      C.c_int, _pd, _pd, _pd, C.POINTER(OracleStats)]
         L.oracle_steihaug_dense.argtypes = [C.c_int, _pd, _pd, _dbl, _dbl, _dbl, _dbl, _pd,
                                             C.POINTER(C.c_int)]
         L.oracle_steihaug_dense.restype = _dbl
@@ -210,3 +228,83 @@ def steihaug_dense(H, g, radius, tol_scale=1.0, tol_scale_root=0.5, max_iter_fac
                                     radius, tol_scale, tol_scale_root, max_iter_factor, step,
                                     C.byref(its))
     return step, m, its.value
+
+
+# ---- quadcopter problems (general constraints, ALM) --------------------------------------------
+QUAD = {"quadcopter": 0, "realistic_quadcopter": 1}
+
+
+def quad_dodo_params(problem, **over):
+    """dodo.py:12-33 + the per-problem overrides of dodo.py:97-105."""
+    p = dodo_params(max_iter=250)                      # solver.max_iter=250
+    if problem == "realistic_quadcopter":
+        p.tol_scale = 1.0                              # accel.tol_scale=1
+        p.alm_initial_tolerance = 1e-1                 # alm.initial_tolerance=1e-1
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def sincos(x):
+    s, c = _dbl(), _dbl()
+    lib().oracle_sincos(x, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def quad_initial_state():
+    x = np.zeros(9)
+    lib().oracle_quad_initial_state(x)
+    return x
+
+
+def quad_initial_guess(N):
+    return np.tile([9.81, 0.0, 0.0, 0.0], N)
+
+
+def quad_simulate(problem, x, u):
+    xn = np.zeros(9)
+    lib().oracle_quad_simulate(QUAD[problem], np.ascontiguousarray(x, float), np.ascontiguousarray(u, float), xn)
+    return xn
+
+
+def quad_fc(problem, s, u):
+    ds = np.zeros(9)
+    lib().oracle_quad_fc(QUAD[problem], np.ascontiguousarray(s, float), np.ascontiguousarray(u, float), ds)
+    return ds
+
+
+def quad_f_g(problem, N, x0, u):
+    g = np.zeros(4 * N + 4)
+    f = lib().oracle_quad_f_g(QUAD[problem], N, np.ascontiguousarray(x0, float), np.ascontiguousarray(u, float), g)
+    return f, g
+
+
+def quad_psi_grad(problem, N, x0, y, Sig, u):
+    grad, yhat = np.zeros(4 * N), np.zeros(4 * N + 4)
+    psi = lib().oracle_quad_psi_grad(QUAD[problem], N, *[np.ascontiguousarray(a, float) for a in (x0, y, Sig, u)],
+                                     grad, yhat)
+    return psi, grad, yhat
+
+
+def quad_hess_prod(problem, N, x0, y, Sig, u, v):
+    Hv = np.zeros(4 * N)
+    lib().oracle_quad_hess_prod(QUAD[problem], N, *[np.ascontiguousarray(a, float) for a in (x0, y, Sig, u, v)], Hv)
+    return Hv
+
+
+def quad_solve(problem, N, x0, u0, y0=None, params=None):
+    params = params or quad_dodo_params(problem)
+    u = np.array(u0, dtype=float, copy=True)
+    y = np.zeros(4 * N + 4) if y0 is None else np.array(y0, dtype=float, copy=True)
+    st = OracleStats()
+    lib().oracle_quad_solve(QUAD[problem], N, C.byref(params), np.ascontiguousarray(x0, float), u, y, C.byref(st))
+    return u, y, st.as_dict()
+
+
+def quad_mpc(problem, N, num_sim, warm, num_dist=0, u_dist=(0.0, 0.0, 0.0, 0.0), params=None):
+    params = params or quad_dodo_params(problem)
+    states, inputs = np.zeros((num_sim + 1, 9)), np.zeros((num_sim, 4 * N))
+    stats = (OracleStats * num_sim)()
+    lib().oracle_quad_mpc(QUAD[problem], N, C.byref(params), num_sim, int(warm), num_dist,
+                          np.ascontiguousarray(u_dist, float), states, inputs, stats)
+    return states, inputs, [s.as_dict() for s in stats]

@@ -243,3 +243,107 @@ def test_golden_replay_fixture_is_a_pure_function_of_its_inputs(golden_dir):
     assert np.array_equal(d["guess"][1:, -NU:], d["sol"][:-1, -NU:])
     # and the next state is the plant step of the first input block
     assert np.array_equal(d["x0"][1], ob.simulate(d["x0"][0], d["sol"][0, :NU]))
+
+
+# ---- quadcopter problems: general constraints, ALM -------------------
+def test_deterministic_sincos():
+    xs = np.concatenate([np.linspace(-10, 10, 401), np.random.default_rng(3).uniform(-1e3, 1e3, 400)])
+    for x in xs:
+        s, c = ob.sincos(float(x))
+        assert abs(s - np.sin(x)) <= 2.5e-16 and abs(c - np.cos(x)) <= 2.5e-16
+    assert ob.sincos(0.0) == (0.0, 1.0)
+
+
+def numpy_quad_fc(problem, s, u):
+    """Independent transcription of quadcopter.py:30-46 / realistic_quadcopter.py:30-50."""
+    th, at, om = s[6:9], u[0], u[1:4]
+    if problem == "quadcopter":
+        cr, sr, cp, sp, cy, sy = np.cos(th[0]), np.sin(th[0]), np.cos(th[1]), np.sin(th[1]), np.cos(th[2]), np.sin(th[2])
+        R = np.array([[cy*cp, cy*sp*sr - sy*cr, cy*sp*cr + sy*sr],
+                      [sy*cp, sy*sp*sr + cy*cr, sy*sp*cr - cy*sr],
+                      [-sp, cp*sr, cp*cr]])
+        dth = om
+    else:
+        phi, tht, psi = th
+        cps, cph, cth, sps, sph, sth = np.cos(psi), np.cos(phi), np.cos(tht), np.sin(psi), np.sin(phi), np.sin(tht)
+        R = np.array([[cps*cth - sph*sps*sth, -cph*sps, cps*sth + cth*sph*sps],
+                      [cth*sps + cps*sph*sth, cph*cps, sps*sth - cps*cth*sph],
+                      [-cph*sth, sph, cph*cth]])
+        Om = np.array([[cth, 0, -cph*sth], [0, 1, sph], [sth, 0, cph*cth]])
+        dth = np.linalg.solve(Om, om)
+    a = R @ np.array([0, 0, at]) + np.array([0, 0, -9.81])
+    return np.concatenate([s[3:6], a, dth])
+
+
+@pytest.mark.parametrize("problem", ["quadcopter", "realistic_quadcopter"])
+def test_quadcopter_dynamics_and_derivatives(rng, problem):
+    N = 5
+    n, m = 4 * N, 4 * N + 4
+    for _ in range(3):
+        s = ob.quad_initial_state() + 0.3 * rng.standard_normal(9)
+        u = np.array([9.81, 0, 0, 0]) + 0.3 * rng.standard_normal(4)
+        assert np.allclose(ob.quad_fc(problem, s, u), numpy_quad_fc(problem, s, u), rtol=1e-13, atol=1e-13)
+    x0 = ob.quad_initial_state() + 0.05 * rng.standard_normal(9)
+    u = ob.quad_initial_guess(N) + 0.3 * rng.standard_normal(n)
+    y, Sig = rng.standard_normal(m), 10 ** rng.uniform(0, 3, m)
+    psi, g, yh = ob.quad_psi_grad(problem, N, x0, y, Sig, u)
+    # psi = f + 1/2 yhat'd with zeta = g + y/Sigma (formulation.hpp:79-86)
+    f, gc = ob.quad_f_g(problem, N, x0, u)
+    lb = np.tile([-np.pi / 2, -np.pi / 2, np.cos(0.55), -np.inf], N + 1)
+    ub = np.tile([np.pi / 2, np.pi / 2, np.inf, 0.0], N + 1)
+    zeta = gc + y / Sig
+    d = zeta - np.clip(zeta, lb, ub)
+    assert np.allclose(yh, Sig * d, rtol=1e-13, atol=1e-13)
+    assert abs(psi - (f + 0.5 * (Sig * d) @ d)) <= 1e-12 * abs(psi)
+    h = 1e-6
+    gfd = np.array([(ob.quad_psi_grad(problem, N, x0, y, Sig, u + h * e)[0] -
+                     ob.quad_psi_grad(problem, N, x0, y, Sig, u - h * e)[0]) / (2 * h) for e in np.eye(n)])
+    assert np.abs(g - gfd).max() <= 1e-6 * np.abs(g).max()
+    v, w = rng.standard_normal(n), rng.standard_normal(n)
+    Hv, Hw = ob.quad_hess_prod(problem, N, x0, y, Sig, u, v), ob.quad_hess_prod(problem, N, x0, y, Sig, u, w)
+    fd = (ob.quad_psi_grad(problem, N, x0, y, Sig, u + h * v)[1] -
+          ob.quad_psi_grad(problem, N, x0, y, Sig, u - h * v)[1]) / (2 * h)
+    assert np.abs(Hv - fd).max() <= 1e-6 * np.abs(Hv).max()
+    assert abs(w @ Hv - v @ Hw) <= 1e-11 * abs(w @ Hv)
+
+
+@pytest.mark.parametrize("problem,N", [("quadcopter", 12), ("realistic_quadcopter", 20)])
+def test_alm_reaches_kkt_point(problem, N):
+    """BASELINE.json configs[0] (quadcopter horizon 12) and a realistic_quadcopter case: the KKT
+    certificate of drivers/results.hpp:258-286 on the ALM solution."""
+    x0, u0 = ob.quad_initial_state(), ob.quad_initial_guess(N)
+    u, y, st = ob.quad_solve(problem, N, x0, u0)
+    assert ob.STATUS[st["status"]] == "Converged" and st["eps"] <= 1e-8 and st["delta"] <= 1e-8
+    assert 1 < st["outer_iterations"] <= 300
+    ulb, uub = np.tile([0, -0.1, -0.1, -0.1], N), np.tile([9.81 * 5, 0.1, 0.1, 0.1], N)
+    assert np.all(u >= ulb) and np.all(u <= uub)
+    # stationarity: || Pi_C(x - grad L(x,y)) - x ||_inf with grad L = grad psi at (y, Sigma) s.t. yhat = y
+    f, g = ob.quad_f_g(problem, N, x0, u)
+    lb = np.tile([-np.pi / 2, -np.pi / 2, np.cos(0.55), -np.inf], N + 1)
+    ub = np.tile([np.pi / 2, np.pi / 2, np.inf, 0.0], N + 1)
+    viol = g - np.clip(g, lb, ub)
+    assert np.abs(viol).max() <= 1e-7                                    # constraint violation
+    assert np.abs(y * viol).max() <= 1e-6                                 # complementarity
+    # gradient of the Lagrangian via psi with huge-penalty-free trick: Sigma=1, y' = y - g + clip(g + y)
+    Sig = np.ones_like(y)
+    zeta_target = y  # want yhat = Sigma (zeta - clip(zeta)) = y  with zeta = g + y'/Sigma
+    yprime = np.where(y != 0, y + np.clip(g + 0 * y, lb, ub) - g, 0.0)
+    _, gradL, yhat = ob.quad_psi_grad(problem, N, x0, yprime, Sig, u)
+    assert np.allclose(yhat, y, atol=1e-6)
+    stationarity = np.abs(np.clip(u - gradL, ulb, uub) - u).max()
+    assert stationarity <= 1e-6
+    # multipliers have the sign their bound allows
+    assert np.all(y[2::4] <= 1e-12) and np.all(y[3::4] >= -1e-12)
+
+
+def test_quadcopter_closed_loop():
+    """mpc-driver.cpp:123-210 with multipliers: every step converges; the loop drives the
+    quadcopter towards its target (0.25, 0.25, 0.5) around the cylinder at the origin."""
+    N, num_sim = 10, 6
+    _, _, cold = ob.quad_mpc("quadcopter", N, num_sim, warm=False)
+    st_w, in_w, warm = ob.quad_mpc("quadcopter", N, num_sim, warm=True)
+    assert all(s["status"] == 1 for s in cold + warm)
+    assert np.all(np.isfinite(st_w)) and st_w.shape == (num_sim + 1, 9)
+    target = np.array([0.25, 0.25, 0.5])
+    assert np.linalg.norm(st_w[-1, :3] - target) < np.linalg.norm(st_w[0, :3] - target)
+    assert np.all(st_w[:, 0] ** 2 + st_w[:, 1] ** 2 >= 0.01 - 1e-6)   # stays outside the cylinder
