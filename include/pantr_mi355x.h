@@ -53,6 +53,10 @@ typedef struct pantr_stats {
     int32_t cg_iterations;
     int32_t accepted, rejected, qub_backtracks;
     int32_t n_psi, n_grad_psi, n_psi_grad_psi, n_grad_L, n_hess_psi_prod, n_prox_grad_step;
+    int32_t outer_iterations;           /* ALM iterations (1 when m = 0) */
+    int32_t inner_convergence_failures; /* inner solves that did not reach their tolerance */
+    double delta;                       /* ||Sigma^{-1}(yhat - y)||_inf at exit (0 when m = 0) */
+    double penalty_norm;                /* ||Sigma||_2 / sqrt(m) at exit */
 } pantr_stats_t;
 
 typedef struct pantr_params pantr_params_t; /* solver option set */

@@ -50,10 +50,13 @@ struct DeviceStats {
     double eps, final_gamma, final_psi, final_fbe, final_radius, elapsed_s;
     int32_t status, iterations, cg_iterations, accepted, rejected, qub_backtracks;
     int32_t n_psi, n_grad_psi, n_psi_grad_psi, n_grad_L, n_hess_psi_prod, n_prox_grad_step;
+    int32_t outer_iterations, inner_convergence_failures; ///< ALM
+    double delta, penalty_norm;                           ///< ||Sigma^{-1}(yhat - y)||_inf, ||Sigma|| / sqrt(m)
 };
 
 constexpr int TRACE_COLS = 11;
-constexpr int NUM_VEC    = 20;
+constexpr int NUM_VEC    = 21; ///< 20 working vectors + the in/out vector of the inner solver
+constexpr int S_XIO      = 20;
 
 struct SolveArgs {
     int32_t B, N, n, npad, nj;
@@ -99,6 +102,13 @@ struct WaveProblem {
         tape = reinterpret_cast<double4 *>(Xt + (size_t)(N + 1) * M::XT_DOUBLES);
         st   = tape + (size_t)N * M::TAPE_D4_PER_STAGE;
     }
+
+    // ---- the interface pantr_inner() drives (m = 0: no multipliers) ----------------------------
+    __device__ __forceinline__ double eval_psi_grad(const double *u, double *grad) const { return psi_grad<false>(u, grad); }
+    __device__ __forceinline__ double eval_psi_xhat(const double *u, int) const { return psi_forward<true>(u); }
+    __device__ __forceinline__ void eval_grad_xhat(const double *u, double *grad, int) const { grad_reverse<true>(u, grad); }
+    __device__ __forceinline__ void hess_prod(const double *, const double *v, double *Hv) const { hess_prod_tape(v, Hv); }
+    __device__ __forceinline__ void update_multipliers(int) const {}
 
     /// psi(u) = sum_k l(x_k,u_k) + l_N(x_N); optionally stores the trajectory.
     template <bool STORE>
@@ -303,6 +313,7 @@ struct WaveProblem {
 
 struct IterateRef {
     int base; ///< first of 4 consecutive vector slots: x, xhat, grad, p
+    int yh;   ///< index of this iterate's yhat m-vector (problems with general constraints)
     double psi_x = __builtin_nan(""), psi_xh = __builtin_nan(""), gamma = __builtin_nan(""),
            L = __builtin_nan(""), pTp = __builtin_nan(""), gradTp = __builtin_nan("");
     __device__ __forceinline__ double fbe() const { return (psi_x + pTp / (2.0 * gamma)) + gradTp; }
@@ -317,55 +328,42 @@ __device__ __forceinline__ void swap_iter(IterateRef &a, IterateRef &b) {
 __device__ __forceinline__ bool is_finite(double v) { return fabs(v) < __builtin_huge_val(); }
 
 // ---------------------------------------------------------------------------------------
-// The solve kernel
+// The PANTR inner solver, generic over the wave-cooperative problem `PB`
 // ---------------------------------------------------------------------------------------
-template <class M>
-__global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
-    extern __shared__ double lds[];
+struct InnerResult {
+    int status, iterations;
+    double eps, gamma, psi, fbe, radius;
+};
+
+/// One inner solve: x_io (an LDS n-vector) holds the initial guess on entry and the solution on
+/// exit; multipliers/penalties live in the problem.  deadline_s counts from t_start.
+template <class PB>
+__device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P, double tolerance,
+                                                   double deadline_s, long long t_start, double *x_io,
+                                                   DeviceStats &st, double *trace, int trace_cap) {
     const int lane = threadIdx.x;
-    const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-    if (inst >= a.B)
-        return;
-    const long long t_start = wall_clock64(); // 100 MHz constant clock
-    const KernelParams &P   = a.prm;
-    typename M::Lane L(lane);
-
-    __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
-    __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
-    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
-    pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
-    pb.bind_workspace(a.ws, inst);
-    const int n = a.n, nj = a.nj;
-
-    // vector slots
+    const int n = pb.n, nj = pb.nj;
     enum { S_IT0 = 0, S_IT1 = 4, S_IT2 = 8, S_Q = 12, S_WORK = 13, S_RJ = 14, S_Z = 15, S_R = 16,
            S_D = 17, S_BD = 18, S_STEP = 19 };
-    for (int i = lane; i < NUM_VEC * a.npad; i += WAVE)
-        lds[i] = 0.0;
-    wave_sync();
-
-    IterateRef curr{S_IT0}, prox{S_IT1}, cand{S_IT2};
+    IterateRef curr{S_IT0, 0}, prox{S_IT1, 1}, cand{S_IT2, 2};
     auto X_  = [&](const IterateRef &it) { return pb.vec(it.base + 0); };
     auto XH_ = [&](const IterateRef &it) { return pb.vec(it.base + 1); };
     auto G_  = [&](const IterateRef &it) { return pb.vec(it.base + 2); };
     auto P_  = [&](const IterateRef &it) { return pb.vec(it.base + 3); };
 
-    DeviceStats st{};
-    st.eps = st.final_gamma = st.final_psi = st.final_fbe = st.final_radius = __builtin_nan("");
-    int status       = Busy;
-    double eps_k     = __builtin_nan("");
-    double radius    = __builtin_nan("");
-    const bool trace = a.trace != nullptr && inst < a.trace_instances;
+    int status    = Busy;
+    double eps_k  = __builtin_nan("");
+    double radius = __builtin_nan("");
 
     // ---- load the initial guess ----
     for (int j = 0; j < nj; ++j) {
         int i = j * WAVE + lane;
         if (i < n)
-            X_(curr)[i] = a.u[(size_t)inst * n + i];
+            X_(curr)[i] = x_io[i];
     }
 
     // ---- Lipschitz estimate: finite difference of the gradient along the gradient ----
-    curr.psi_x = pb.psi_grad(X_(curr), G_(curr));
+    curr.psi_x = pb.eval_psi_grad(X_(curr), G_(curr));
     ++st.n_psi_grad_psi;
     if (P.L_0 <= 0) {
         double *h = pb.vec(S_WORK);
@@ -379,7 +377,7 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
             }
         }
         double norm_h = __builtin_sqrt(pb.dot(h, h));
-        pb.psi_grad(XH_(curr), G_(cand));
+        pb.eval_psi_grad(XH_(curr), G_(cand));
         ++st.n_grad_psi;
         for (int j = 0; j < nj; ++j) {
             int i = j * WAVE + lane;
@@ -415,7 +413,7 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
             swap_iter(curr, prox);
         // ---- psi(xhat) + quadratic upper bound backtracking on the new current iterate ----
         while (true) {
-            curr.psi_xh = pb.template psi_forward<true>(XH_(curr)); // keeps X for grad_L(xhat) below
+            curr.psi_xh = pb.eval_psi_xhat(XH_(curr), curr.yh); // keeps the trajectory (and yhat) for grad_L(xhat)
             ++st.n_psi;
             double margin = (1.0 + fabs(curr.psi_x)) * P.quadratic_upperbound_tolerance_factor;
             bool violated = curr.psi_xh > ((curr.psi_x + curr.gradTp) + (0.5 * curr.L) * curr.pTp) + margin;
@@ -453,8 +451,8 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
             eps_k = __builtin_nan("");
         }
         double elapsed   = (double)(wall_clock64() - t_start) * 1e-8;
-        bool converged   = eps_k <= P.tolerance;
-        bool out_of_time = elapsed > P.max_time_s;
+        bool converged   = eps_k <= tolerance;
+        bool out_of_time = elapsed > deadline_s;
         bool out_of_iter = k == P.max_iter;
         bool not_finite  = !is_finite(eps_k);
         bool stalled     = no_progress > P.max_no_progress;
@@ -473,7 +471,7 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
         prox.psi_x = curr.psi_xh;
         // grad_L(xhat): xbar = xhat_k was the last point psi was evaluated at (trajectory X is still
         // in the workspace), so only the adjoint sweep runs; it records the tape at xbar
-        pb.template grad_reverse<true>(X_(prox), G_(prox));
+        pb.eval_grad_xhat(X_(prox), G_(prox), curr.yh);
         ++st.n_grad_L;
         prox.gamma = curr.gamma;
         prox.L     = curr.L;
@@ -533,7 +531,7 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
                     vin       = d;
                 }
                 // the one Hessian-vector product site: work = H(xbar) * vin (tape replay)
-                pb.hess_prod_tape(vin, work);
+                pb.hess_prod(X_(prox), vin, work);
                 ++st.n_hess_psi_prod;
                 if (state == KTERM) {
                     for (int j = 0; j < nj; ++j) {
@@ -657,7 +655,7 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
                     if (i < n)
                         X_(cand)[i] = X_(prox)[i] + q[i];
                 }
-                cand.psi_x = pb.psi_grad(X_(cand), G_(cand));
+                cand.psi_x = pb.eval_psi_grad(X_(cand), G_(cand));
                 ++st.n_psi_grad_psi;
                 cand.gamma = prox.gamma;
                 cand.L     = prox.L;
@@ -677,8 +675,8 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
                 radius = fmax(nr, P.min_radius);
             }
         }
-        if (trace && k < a.trace_cap && lane == 0) {
-            double *o = a.trace + ((size_t)inst * a.trace_cap + k) * TRACE_COLS;
+        if (trace && k < trace_cap && lane == 0) {
+            double *o = trace + (size_t)k * TRACE_COLS;
             o[0] = eps_k; o[1] = curr.psi_x; o[2] = __builtin_sqrt(curr.pTp); o[3] = curr.gamma;
             o[4] = radius; o[5] = rho; o[6] = q_model; o[7] = curr.fbe(); o[8] = nJ; o[9] = cg_its;
             o[10] = accept ? 1.0 : 0.0;
@@ -694,21 +692,66 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
 
     // ---- results ----
     if ((status == Converged || status == Interrupted || P.always_overwrite_results) && is_finite(curr.L)) {
+        pb.update_multipliers(curr.yh); // err_z = Sigma^{-1} (yhat - y), y <- yhat  (m > 0)
         for (int j = 0; j < nj; ++j) {
             int i = j * WAVE + lane;
             if (i < n)
-                a.u[(size_t)inst * n + i] = XH_(curr)[i];
+                x_io[i] = XH_(curr)[i];
         }
+        wave_sync();
+    }
+    return {status, k, eps_k, curr.gamma, curr.psi_xh, curr.fbe(), radius};
+}
+
+// ---------------------------------------------------------------------------------------
+// The solve kernel for problems without general constraints (m = 0: ALM = one inner solve)
+// ---------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if (inst >= a.B)
+        return;
+    const long long t_start = wall_clock64(); // 100 MHz constant clock
+    const KernelParams &P   = a.prm;
+    typename M::Lane L(lane);
+
+    __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
+    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
+    pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
+    pb.bind_workspace(a.ws, inst);
+    const int n = a.n, nj = a.nj;
+    for (int i = lane; i < NUM_VEC * a.npad; i += WAVE)
+        lds[i] = 0.0;
+    wave_sync();
+    double *x_io = pb.vec(S_XIO);
+    for (int j = 0; j < nj; ++j) {
+        int i = j * WAVE + lane;
+        if (i < n)
+            x_io[i] = a.u[(size_t)inst * n + i];
+    }
+    DeviceStats st{};
+    const bool trace = a.trace != nullptr && inst < a.trace_instances;
+    InnerResult r = pantr_inner(pb, P, P.tolerance, P.max_time_s, t_start, x_io, st,
+                                trace ? a.trace + (size_t)inst * a.trace_cap * TRACE_COLS : nullptr, a.trace_cap);
+    for (int j = 0; j < nj; ++j) { // solution (or the untouched guess when nothing was overwritten)
+        int i = j * WAVE + lane;
+        if (i < n)
+            a.u[(size_t)inst * n + i] = x_io[i];
     }
     if (lane == 0) {
-        st.status       = status;
-        st.iterations   = k;
-        st.eps          = eps_k;
-        st.final_gamma  = curr.gamma;
-        st.final_psi    = curr.psi_xh;
-        st.final_fbe    = curr.fbe();
-        st.final_radius = radius;
+        st.status       = r.status;
+        st.iterations   = r.iterations;
+        st.eps          = r.eps;
+        st.final_gamma  = r.gamma;
+        st.final_psi    = r.psi;
+        st.final_fbe    = r.fbe;
+        st.final_radius = r.radius;
         st.elapsed_s    = (double)(wall_clock64() - t_start) * 1e-8;
+        st.outer_iterations = 1;
+        st.inner_convergence_failures = r.status == Converged ? 0 : 1;
         a.stats[inst]   = st;
     }
 }

@@ -47,7 +47,9 @@ class PantrStats(C.Structure):
                [(k, _i32) for k in ("status", "iterations", "cg_iterations", "accepted",
                                     "rejected", "qub_backtracks", "n_psi", "n_grad_psi",
                                     "n_psi_grad_psi", "n_grad_L", "n_hess_psi_prod",
-                                    "n_prox_grad_step")]
+                                    "n_prox_grad_step", "outer_iterations",
+                                    "inner_convergence_failures")] + \
+               [(k, _dbl) for k in ("delta", "penalty_norm")]
 
 
 STATS_DTYPE = np.dtype([(k, np.float64) for k in ("eps", "final_gamma", "final_psi", "final_fbe",
@@ -55,7 +57,9 @@ STATS_DTYPE = np.dtype([(k, np.float64) for k in ("eps", "final_gamma", "final_p
                        [(k, np.int32) for k in ("status", "iterations", "cg_iterations",
                                                 "accepted", "rejected", "qub_backtracks", "n_psi",
                                                 "n_grad_psi", "n_psi_grad_psi", "n_grad_L",
-                                                "n_hess_psi_prod", "n_prox_grad_step")])
+                                                "n_hess_psi_prod", "n_prox_grad_step",
+                                                "outer_iterations", "inner_convergence_failures")] +
+                       [(k, np.float64) for k in ("delta", "penalty_norm")])
 assert STATS_DTYPE.itemsize == C.sizeof(PantrStats)
 
 # every symbol include/pantr_mi355x.h declares
