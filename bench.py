@@ -117,7 +117,7 @@ def main():
 
     def one_pass():
         u.copy_(guess)  # device-to-device reset of the in/out guesses
-        batch.solve_device(B, x0.data_ptr(), u.data_ptr(), stats_t.data_ptr(), stream.cuda_stream)
+        batch.solve_device(B, x0.data_ptr(), u.data_ptr(), stats_t.data_ptr(), stream.cuda_stream)  # m = 0: no y
 
     def barrier():
         if distributed:

@@ -78,7 +78,8 @@ int pantr_params_get(const pantr_params_t *p, const char *key, double *value);
 
 /* ---- problem: replaces load_benchmark_problem / load_benchmark_dl_problem ---------------
  * (drivers/casadi-dll-wrapper.cpp:25-67,69-129) for the problems this library carries as
- * compiled device code.  `problem` is the reference's problem name ("hanging_chain"),
+ * compiled device code.  `problem` is the reference's problem name ("hanging_chain",
+ * "quadcopter", "realistic_quadcopter"; a "dl:" prefix is accepted and dropped),
  * `horizon` the N of "<name>_<formulation>_<N>.so" (casadi-dll-wrapper.cpp:29-31).
  * `max_instances` sizes the device workspace; `device` is the HIP device ordinal. */
 int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instances,
@@ -90,6 +91,8 @@ int pantr_batch_dims(const pantr_batch_t *b, int32_t *n, int32_t *m, int32_t *nx
                      int32_t *nc, int32_t *nc_N);
 /* get_box_C() (mpc-driver.cpp:140; formulation.hpp:220-227): lb[n], ub[n] */
 int pantr_batch_get_box_C(const pantr_batch_t *b, double *lb, double *ub);
+/* get_box_D() (formulation.hpp:229-238): lb[m], ub[m] (nothing is written when m = 0) */
+int pantr_batch_get_box_D(const pantr_batch_t *b, double *lb, double *ub);
 /* "initial_guess" (casadi-dll-wrapper.cpp:100-106; hanging_chain.cpp:135): u[n] */
 int pantr_batch_get_initial_guess(const pantr_batch_t *b, double *u);
 /* "get_initial_state" (hanging_chain.cpp:154-155,121-124): x0[nx] */
@@ -108,8 +111,9 @@ int pantr_batch_get_param(const pantr_batch_t *b, const char *key, double *value
 int pantr_batch_solve(pantr_batch_t *b, int32_t B, const double *x0, double *u, double *y,
                       pantr_stats_t *stats);
 /* Same with device pointers (inputs already resident in HBM), asynchronous on `stream`
- * (a hipStream_t, NULL = default stream).  d_stats is device memory, B records. */
-int pantr_batch_solve_device(pantr_batch_t *b, int32_t B, const double *d_x0, double *d_u,
+ * (a hipStream_t, NULL = default stream).  d_y[B][m] may be NULL when m = 0; d_stats is device
+ * memory, B records. */
+int pantr_batch_solve_device(pantr_batch_t *b, int32_t B, const double *d_x0, double *d_u, double *d_y,
                              pantr_stats_t *d_stats, void *stream);
 /* Duration of the most recent solve kernel, measured with HIP events recorded on the stream
  * it was launched on (synchronises on the stop event). */
@@ -132,6 +136,14 @@ int pantr_batch_eval_psi_grad_psi(pantr_batch_t *b, int32_t B, const double *x0,
                                   double *psi, double *grad);
 int pantr_batch_eval_hess_psi_prod(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
                                    const double *v, double *Hv);
+/* The same functions for problems with general constraints (m > 0), with the arguments of
+ * eval_psi_grad_psi / eval_hess_psi_prod in formulation.hpp:145-168: multipliers y[B][m] and
+ * penalties Sigma[B][m]; yhat[B][m] (may be NULL) receives Sigma (zeta - clamp(zeta, D)). */
+int pantr_batch_eval_psi_grad_psi_al(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
+                                     const double *y, const double *Sigma, double *psi, double *grad,
+                                     double *yhat);
+int pantr_batch_eval_hess_psi_prod_al(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
+                                      const double *y, const double *Sigma, const double *v, double *Hv);
 /* scalars[B][4] = { p'p, grad'p, ||Pi_C(x-grad)-x||_inf, |J(gamma)| } */
 int pantr_batch_eval_prox_grad_step(pantr_batch_t *b, int32_t B, double gamma, const double *x,
                                     const double *grad, double *xhat, double *p, double *scalars);

@@ -5,6 +5,8 @@
 #include "../host/params.hpp"
 #include "chain_model.hip.h"
 #include "pantr_kernel.hip.h"
+#include "pantr_alm.hip.h"
+#include "quad_model.hip.h"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -36,7 +38,7 @@ int fail(int code, const std::string &msg) {
             return fail(PANTR_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
-enum class ProblemId { HangingChain };
+enum class ProblemId { HangingChain, Quadcopter, RealisticQuadcopter };
 
 } // namespace
 
@@ -55,6 +57,9 @@ struct pantr_batch {
     // device memory
     double *d_x0 = nullptr, *d_u = nullptr, *d_v = nullptr, *d_o1 = nullptr, *d_o2 = nullptr,
            *d_s = nullptr, *d_ws = nullptr, *d_trace = nullptr;
+    double *d_y = nullptr, *d_sig = nullptr, *d_om = nullptr, *d_uinit = nullptr; ///< m > 0 problems
+    int32_t mpad = 0, mj = 0;
+    bool al() const { return problem != ProblemId::HangingChain; }
     DeviceStats *d_stats = nullptr;
     int32_t *d_order     = nullptr;
     bool have_order      = false;
@@ -116,6 +121,26 @@ KernelParams to_kernel_params(const SolverOptions &o, int m) {
     return k;
 }
 
+AlmKernelParams to_alm_params(const SolverOptions &o) {
+    AlmKernelParams a{};
+    const auto &m = o.alm;
+    a.tolerance = m.tolerance; a.dual_tolerance = m.dual_tolerance; a.max_time_s = m.max_time;
+    a.initial_penalty = m.initial_penalty; a.penalty_update_factor = m.penalty_update_factor;
+    a.initial_tolerance = m.initial_tolerance; a.tolerance_update_factor = m.tolerance_update_factor;
+    a.rel_penalty_increase_threshold = m.rel_penalty_increase_threshold;
+    a.max_multiplier = m.max_multiplier; a.max_penalty = m.max_penalty;
+    a.max_iter = m.max_iter; a.single_penalty_factor = m.single_penalty_factor ? 1 : 0;
+    return a;
+}
+
+/// Runs f(Model{}) for the scalar-model problem of the handle.
+template <class F>
+int with_quad_model(const pantr_batch *b, F &&f) {
+    if (b->problem == ProblemId::RealisticQuadcopter)
+        return f(QuadModelT<true>{});
+    return f(QuadModelT<false>{});
+}
+
 int set_option(SolverOptions &o, const char *kv) {
     if (!kv)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null option string");
@@ -127,10 +152,33 @@ int set_option(SolverOptions &o, const char *kv) {
     }
 }
 
-int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, DeviceStats *d_stats,
-                 hipStream_t stream) {
+int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, double *d_y,
+                 DeviceStats *d_stats, hipStream_t stream) {
     if (int rc = check_supported(b->opts))
         return rc;
+    if (b->al()) {
+        if (b->opts.alm.initial_penalty <= 0)
+            return fail(PANTR_ERR_INVALID_ARGUMENT,
+                        "alm.initial_penalty must be > 0 (automatic penalty initialisation is not supported)");
+        AlmSolveArgs a{};
+        a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj; a.m = b->m; a.mpad = b->mpad; a.mj = b->mj;
+        a.trace_cap = b->trace_cap; a.trace_instances = b->trace_instances;
+        a.x0 = d_x0; a.u = d_u; a.y = d_y; a.stats = d_stats;
+        a.trace = b->trace_instances > 0 ? b->d_trace : nullptr;
+        a.order = b->have_order ? b->d_order : nullptr;
+        a.prm   = to_kernel_params(b->opts, b->m);
+        a.alm   = to_alm_params(b->opts);
+        HIP_TRY(hipEventRecord(b->ev_start, stream));
+        with_quad_model(b, [&](auto model) {
+            using M = decltype(model);
+            hipLaunchKernelGGL(pantr_alm_kernel<M>, dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+            return 0;
+        });
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(b->ev_stop, stream));
+        b->timed = true;
+        return PANTR_OK;
+    }
     SolveArgs a{};
     a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj;
     a.trace_cap = b->trace_cap; a.trace_instances = b->trace_instances;
@@ -159,6 +207,8 @@ int run_eval(pantr_batch *b, int32_t B, int mode, double gamma, const double *x0
              const double *v, double *out_s, double *out_v, double *out_v2) {
     if (int rc = check_batch(b, B))
         return rc;
+    if (b->al())
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "this problem has general constraints: use the *_al evaluation entry points");
     HIP_TRY(hipSetDevice(b->device));
     const size_t nb = (size_t)B * b->n * sizeof(double);
     if (x0)
@@ -229,8 +279,16 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
     std::string name = problem;
     while (name.rfind("dl:", 0) == 0) // casadi-dll-wrapper.cpp:74-76
         name = name.substr(3);
-    if (name != "hanging_chain")
-        return fail(PANTR_ERR_OUT_OF_RANGE, "unknown problem '" + name + "' (available: hanging_chain)");
+    ProblemId id;
+    if (name == "hanging_chain")
+        id = ProblemId::HangingChain;
+    else if (name == "quadcopter")
+        id = ProblemId::Quadcopter;
+    else if (name == "realistic_quadcopter")
+        id = ProblemId::RealisticQuadcopter;
+    else
+        return fail(PANTR_ERR_OUT_OF_RANGE, "unknown problem '" + name +
+                                                "' (available: hanging_chain, quadcopter, realistic_quadcopter)");
     if (horizon < 1)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "horizon must be >= 1");
     if (max_instances < 1)
@@ -243,32 +301,66 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
     HIP_TRY(hipSetDevice(device));
 
     auto b = std::make_unique<pantr_batch>();
-    b->name = name; b->device = device;
-    b->N = horizon; b->nx = ChainModel::nx; b->nu = ChainModel::nu;
-    b->n = b->nu * b->N; b->m = 0; b->nc = 0; b->nc_N = 0;
+    b->problem = id; b->name = name; b->device = device; b->N = horizon;
+    if (id == ProblemId::HangingChain) {
+        b->nx = ChainModel::nx; b->nu = ChainModel::nu; b->nc = 0; b->nc_N = 0;
+    } else {
+        b->nx = QuadModelT<false>::nx; b->nu = QuadModelT<false>::nu;
+        b->nc = b->nc_N = QuadModelT<false>::nc;
+    }
+    b->n = b->nu * b->N;
+    b->m = b->nc * b->N + b->nc_N; // ss.py:39-40
     b->nj   = (b->n + WAVE - 1) / WAVE;
     b->npad = b->nj * WAVE;
+    b->mj   = (b->m + WAVE - 1) / WAVE;
+    b->mpad = b->mj * WAVE;
     if (b->nj > 32)
         return fail(PANTR_ERR_OUT_OF_RANGE, "horizon too long: n = nu*N must be <= 2048");
-    b->maxB            = max_instances;
-    b->ws_per_instance = WaveProblem<ChainModel>::workspace_doubles(b->N);
-    b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double); // dynamic part (vectors)
-    if (b->lds_bytes + WaveProblem<ChainModel>::tape_lds_bytes() > 160 * 1024)
+    b->maxB = max_instances;
+    size_t static_lds = 0;
+    if (b->al()) {
+        b->ws_per_instance = 0; // trajectories and multipliers live in LDS
+        b->lds_bytes       = ScalarALProblem<QuadModelT<false>>::lds_doubles(b->N, b->npad, b->mpad) * sizeof(double);
+    } else {
+        b->ws_per_instance = WaveProblem<ChainModel>::workspace_doubles(b->N);
+        b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double); // dynamic part (vectors)
+        static_lds         = WaveProblem<ChainModel>::tape_lds_bytes();
+    }
+    if (b->lds_bytes + static_lds > 160 * 1024)
         return fail(PANTR_ERR_OUT_OF_RANGE, "decision vectors do not fit the 160 KiB LDS");
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_solve_kernel<ChainModel>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+    if (b->al()) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_alm_kernel<QuadModelT<false>>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_alm_kernel<QuadModelT<true>>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_alm_eval_kernel<QuadModelT<false>>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_alm_eval_kernel<QuadModelT<true>>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+    } else {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_solve_kernel<ChainModel>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+    }
     const size_t B  = b->maxB;
     const size_t nv = std::max(b->n, b->nx); // the vector buffers also carry nx-sized rows
+    const size_t mv = std::max<size_t>(b->m, 1);
     int rc;
     if ((rc = dev_alloc(b->d_x0, B * b->nx)) || (rc = dev_alloc(b->d_u, B * nv)) ||
         (rc = dev_alloc(b->d_v, B * nv)) || (rc = dev_alloc(b->d_o1, B * nv)) ||
         (rc = dev_alloc(b->d_o2, B * nv)) || (rc = dev_alloc(b->d_s, B * 4)) ||
-        (rc = dev_alloc(b->d_ws, B * b->ws_per_instance)) || (rc = dev_alloc(b->d_stats, B)) ||
-        (rc = dev_alloc(b->d_order, B))) {
+        (rc = dev_alloc(b->d_ws, std::max<size_t>(B * b->ws_per_instance, 1))) || (rc = dev_alloc(b->d_stats, B)) ||
+        (rc = dev_alloc(b->d_order, B)) || (rc = dev_alloc(b->d_y, B * mv)) || (rc = dev_alloc(b->d_sig, B * mv)) ||
+        (rc = dev_alloc(b->d_om, B * mv)) || (rc = dev_alloc(b->d_uinit, nv))) {
         pantr_batch_destroy(b.release());
         return rc;
     }
-    HIP_TRY(hipMemset(b->d_ws, 0, B * b->ws_per_instance * sizeof(double)));
+    {
+        std::vector<double> ui(b->n);
+        for (int i = 0; i < b->n; ++i)
+            ui[i] = b->al() ? QuadModelT<false>::initial_guess(i % b->nu) : 0.0;
+        HIP_TRY(hipMemcpy(b->d_uinit, ui.data(), ui.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemset(b->d_ws, 0, std::max<size_t>(B * b->ws_per_instance, 1) * sizeof(double)));
     HIP_TRY(hipEventCreate(&b->ev_start));
     HIP_TRY(hipEventCreate(&b->ev_stop));
     *out = b.release();
@@ -281,7 +373,7 @@ void pantr_batch_destroy(pantr_batch_t *b) {
     (void)hipSetDevice(b->device);
     for (void *p : {(void *)b->d_x0, (void *)b->d_u, (void *)b->d_v, (void *)b->d_o1, (void *)b->d_o2,
                     (void *)b->d_s, (void *)b->d_ws, (void *)b->d_trace, (void *)b->d_stats,
-                    (void *)b->d_order})
+                    (void *)b->d_order, (void *)b->d_y, (void *)b->d_sig, (void *)b->d_om, (void *)b->d_uinit})
         if (p)
             (void)hipFree(p);
     if (b->ev_start)
@@ -308,8 +400,18 @@ int pantr_batch_get_box_C(const pantr_batch_t *b, double *lb, double *ub) {
     if (!b || !lb || !ub)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
     for (int i = 0; i < b->n; ++i) { // formulation.hpp:220-227: U tiled N times
-        lb[i] = ChainModel::u_lb(i % b->nu);
-        ub[i] = ChainModel::u_ub(i % b->nu);
+        lb[i] = b->al() ? QuadModelT<false>::u_lb(i % b->nu) : ChainModel::u_lb(i % b->nu);
+        ub[i] = b->al() ? QuadModelT<false>::u_ub(i % b->nu) : ChainModel::u_ub(i % b->nu);
+    }
+    return PANTR_OK;
+}
+
+int pantr_batch_get_box_D(const pantr_batch_t *b, double *lb, double *ub) {
+    if (!b || (b->m > 0 && (!lb || !ub)))
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    for (int j = 0; j < b->m; ++j) { // formulation.hpp:229-238: D tiled N times, then D_N
+        lb[j] = QuadModelT<false>::d_lb(j % b->nc);
+        ub[j] = QuadModelT<false>::d_ub(j % b->nc);
     }
     return PANTR_OK;
 }
@@ -317,13 +419,18 @@ int pantr_batch_get_box_C(const pantr_batch_t *b, double *lb, double *ub) {
 int pantr_batch_get_initial_guess(const pantr_batch_t *b, double *u) {
     if (!b || !u)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
-    std::fill(u, u + b->n, 0.0); // hanging_chain.cpp:135
+    for (int i = 0; i < b->n; ++i) // hanging_chain.cpp:135 / quadcopter.py:111
+        u[i] = b->al() ? QuadModelT<false>::initial_guess(i % b->nu) : 0.0;
     return PANTR_OK;
 }
 
 int pantr_batch_get_initial_state(const pantr_batch_t *b, double *x0) {
     if (!b || !x0)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    if (b->al()) {
+        QuadModelT<false>::initial_state(x0); // quadcopter.py:80-88
+        return PANTR_OK;
+    }
     for (int l = 0; l < b->nx; ++l)
         x0[l] = ChainModel::initial_state(l);
     return PANTR_OK;
@@ -345,7 +452,7 @@ int pantr_batch_get_param(const pantr_batch_t *b, const char *key, double *value
 int pantr_batch_footprint(const pantr_batch_t *b, int64_t *lds_bytes, int64_t *ws_bytes_per_instance) {
     if (!b)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
-    if (lds_bytes) *lds_bytes = (int64_t)(b->lds_bytes + WaveProblem<ChainModel>::tape_lds_bytes());
+    if (lds_bytes) *lds_bytes = (int64_t)(b->lds_bytes + (b->al() ? 0 : WaveProblem<ChainModel>::tape_lds_bytes()));
     if (ws_bytes_per_instance) *ws_bytes_per_instance = (int64_t)(b->ws_per_instance * sizeof(double));
     return PANTR_OK;
 }
@@ -357,26 +464,32 @@ int pantr_batch_solve(pantr_batch_t *b, int32_t B, const double *x0, double *u, 
         return rc;
     if (!x0 || !u || !stats)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
-    (void)y; // m == 0: no multipliers
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemcpy(b->d_x0, x0, (size_t)B * b->nx * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_u, u, (size_t)B * b->n * sizeof(double), hipMemcpyHostToDevice));
-    if (int rc = launch_solve(b, B, b->d_x0, b->d_u, b->d_stats, nullptr))
+    if (b->al()) {
+        if (!y)
+            return fail(PANTR_ERR_INVALID_ARGUMENT, "this problem has general constraints: y[B][m] is required");
+        HIP_TRY(hipMemcpy(b->d_y, y, (size_t)B * b->m * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (int rc = launch_solve(b, B, b->d_x0, b->d_u, b->d_y, b->d_stats, nullptr))
         return rc;
     HIP_TRY(hipDeviceSynchronize());
+    if (b->al())
+        HIP_TRY(hipMemcpy(y, b->d_y, (size_t)B * b->m * sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(u, b->d_u, (size_t)B * b->n * sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(stats, b->d_stats, (size_t)B * sizeof(DeviceStats), hipMemcpyDeviceToHost));
     return PANTR_OK;
 }
 
-int pantr_batch_solve_device(pantr_batch_t *b, int32_t B, const double *d_x0, double *d_u,
+int pantr_batch_solve_device(pantr_batch_t *b, int32_t B, const double *d_x0, double *d_u, double *d_y,
                              pantr_stats_t *d_stats, void *stream) {
     if (int rc = check_batch(b, B))
         return rc;
-    if (!d_x0 || !d_u || !d_stats)
+    if (!d_x0 || !d_u || !d_stats || (b->al() && !d_y))
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(b->device));
-    return launch_solve(b, B, d_x0, d_u, reinterpret_cast<DeviceStats *>(d_stats),
+    return launch_solve(b, B, d_x0, d_u, d_y, reinterpret_cast<DeviceStats *>(d_stats),
                         static_cast<hipStream_t>(stream));
 }
 
@@ -501,12 +614,69 @@ int pantr_batch_simulate_dynamics(pantr_batch_t *b, int32_t B, const double *x, 
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemcpy(b->d_x0, x, (size_t)B * b->nx * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_v, u, (size_t)B * b->nu * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(pantr_simulate_kernel<ChainModel>, dim3(B), dim3(WAVE), 0, 0, B, b->d_x0, b->d_v,
-                       b->nu, b->d_o1);
+    if (b->al())
+        with_quad_model(b, [&](auto model) {
+            using M = decltype(model);
+            hipLaunchKernelGGL(pantr_scalar_simulate_kernel<M>, dim3((B + 63) / 64), dim3(64), 0, 0, B, b->d_x0, b->d_v,
+                               b->nu, b->d_o1);
+            return 0;
+        });
+    else
+        hipLaunchKernelGGL(pantr_simulate_kernel<ChainModel>, dim3(B), dim3(WAVE), 0, 0, B, b->d_x0, b->d_v,
+                           b->nu, b->d_o1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(x_next, b->d_o1, (size_t)B * b->nx * sizeof(double), hipMemcpyDeviceToHost));
     return PANTR_OK;
+}
+
+// ---- problem functions with multipliers (m > 0) --------------------------------------------------
+static int run_al_eval(pantr_batch *b, int32_t B, int mode, const double *x0, const double *u, const double *y,
+                       const double *Sigma, const double *v, double *psi, double *out_v, double *yhat) {
+    if (int rc = check_batch(b, B))
+        return rc;
+    if (!b->al())
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "this problem has no general constraints: use the plain evaluation entry points");
+    if (!x0 || !u || !y || !Sigma || !out_v)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t nb = (size_t)B * b->n * sizeof(double), mb = (size_t)B * b->m * sizeof(double);
+    HIP_TRY(hipMemcpy(b->d_x0, x0, (size_t)B * b->nx * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_u, u, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_y, y, mb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_sig, Sigma, mb, hipMemcpyHostToDevice));
+    if (v)
+        HIP_TRY(hipMemcpy(b->d_v, v, nb, hipMemcpyHostToDevice));
+    AlmEvalArgs a{};
+    a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj; a.m = b->m; a.mpad = b->mpad; a.mj = b->mj;
+    a.mode = mode; a.x0 = b->d_x0; a.u = b->d_u; a.v = v ? b->d_v : nullptr; a.y = b->d_y; a.Sig = b->d_sig;
+    a.out_s = b->d_s; a.out_v = b->d_o1; a.out_m = b->d_om;
+    with_quad_model(b, [&](auto model) {
+        using M = decltype(model);
+        hipLaunchKernelGGL(pantr_alm_eval_kernel<M>, dim3(B), dim3(WAVE), b->lds_bytes, 0, a);
+        return 0;
+    });
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (psi)
+        HIP_TRY(hipMemcpy(psi, b->d_s, (size_t)B * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_v, b->d_o1, nb, hipMemcpyDeviceToHost));
+    if (yhat)
+        HIP_TRY(hipMemcpy(yhat, b->d_om, mb, hipMemcpyDeviceToHost));
+    return PANTR_OK;
+}
+
+int pantr_batch_eval_psi_grad_psi_al(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
+                                     const double *y, const double *Sigma, double *psi, double *grad,
+                                     double *yhat) {
+    return run_al_eval(b, B, ALM_EVAL_PSI_GRAD, x0, u, y, Sigma, nullptr, psi, grad, yhat);
+}
+
+int pantr_batch_eval_hess_psi_prod_al(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
+                                      const double *y, const double *Sigma, const double *v, double *Hv) {
+    if (!v)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    return run_al_eval(b, B, ALM_EVAL_HESS_PROD, x0, u, y, Sigma, v, nullptr, Hv, nullptr);
 }
 
 // ---- closed loops on the device -------------------------------------------------------------
@@ -522,27 +692,40 @@ int pantr_batch_mpc(pantr_batch_t *b, int32_t B, int32_t num_sim, int32_t warm, 
     HIP_TRY(hipSetDevice(b->device));
     const size_t xb = (size_t)B * b->nx * sizeof(double), ub = (size_t)B * b->n * sizeof(double);
     // x0: the problem's initial state (or the caller's), u: the initial guess
-    std::vector<double> x0((size_t)B * b->nx);
+    std::vector<double> x0((size_t)B * b->nx), xi(b->nx);
+    pantr_batch_get_initial_state(b, xi.data());
     for (int i = 0; i < B; ++i)
         for (int l = 0; l < b->nx; ++l)
-            x0[(size_t)i * b->nx + l] = x_init ? x_init[(size_t)i * b->nx + l] : ChainModel::initial_state(l);
+            x0[(size_t)i * b->nx + l] = x_init ? x_init[(size_t)i * b->nx + l] : xi[l];
     HIP_TRY(hipMemcpy(b->d_x0, x0.data(), xb, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(b->d_u, 0, ub)); // hanging_chain.cpp:135
+    for (int i = 0; i < B; ++i) // u = initial guess (hanging_chain.cpp:135 / quadcopter.py:111)
+        HIP_TRY(hipMemcpy(b->d_u + (size_t)i * b->n, b->d_uinit, (size_t)b->n * sizeof(double), hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemset(b->d_y, 0, std::max<size_t>((size_t)B * b->m, 1) * sizeof(double)));
     HIP_TRY(hipMemcpy(b->d_v, u_dist, (size_t)B * b->nu * sizeof(double), hipMemcpyHostToDevice));
     auto simulate = [&](const double *u, int stride) {
-        hipLaunchKernelGGL(pantr_simulate_kernel<ChainModel>, dim3(B), dim3(WAVE), 0, 0, B, b->d_x0, u, stride,
-                           b->d_x0);
+        if (b->al())
+            with_quad_model(b, [&](auto model) {
+                using M = decltype(model);
+                hipLaunchKernelGGL(pantr_scalar_simulate_kernel<M>, dim3((B + 63) / 64), dim3(64), 0, 0, B, b->d_x0, u,
+                                   stride, b->d_x0);
+                return 0;
+            });
+        else
+            hipLaunchKernelGGL(pantr_simulate_kernel<ChainModel>, dim3(B), dim3(WAVE), 0, 0, B, b->d_x0, u, stride,
+                               b->d_x0);
     };
     for (int i = 0; i < num_dist; ++i) // initial disturbance (mpc-driver.cpp:153-154)
         simulate(b->d_v, b->nu);
-    if (int rc = launch_solve(b, B, b->d_x0, b->d_u, b->d_stats, nullptr)) // untimed first solve (:158)
+    if (int rc = launch_solve(b, B, b->d_x0, b->d_u, b->d_y, b->d_stats, nullptr)) // untimed first solve (:158)
         return rc;
     simulate(b->d_u, b->n); // :160-161
     for (int i = 0; i < num_sim; ++i) {
-        hipLaunchKernelGGL(pantr_shift_kernel, dim3(B), dim3(256), 0, 0, B, b->n, b->nu, warm, b->d_u);
+        // warm: shift u by nu and y by nc (:168-175) | cold: initial guess, y = 0 (:192-197)
+        hipLaunchKernelGGL(pantr_shift_uy_kernel, dim3(B), dim3(256), 0, 0, B, b->n, b->nu, b->m, b->nc, warm,
+                           b->d_uinit, b->d_u, b->d_y);
         // record the state this step is solved for, then solve, record, advance the plant
         HIP_TRY(hipMemcpyAsync(states + (size_t)i * B * b->nx, b->d_x0, xb, hipMemcpyDeviceToHost, nullptr));
-        if (int rc = launch_solve(b, B, b->d_x0, b->d_u, b->d_stats, nullptr))
+        if (int rc = launch_solve(b, B, b->d_x0, b->d_u, b->d_y, b->d_stats, nullptr))
             return rc;
         HIP_TRY(hipMemcpyAsync(inputs + (size_t)i * B * b->n, b->d_u, ub, hipMemcpyDeviceToHost, nullptr));
         HIP_TRY(hipMemcpyAsync(stats + (size_t)i * B, b->d_stats, (size_t)B * sizeof(DeviceStats),

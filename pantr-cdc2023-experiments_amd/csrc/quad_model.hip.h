@@ -1,0 +1,212 @@
+// Quadcopter and realistic_quadcopter stage models (gfx950), scalar form.
+//
+// What the reference computes (paths relative to /root/reference; `method=pantr` loads the CasADi
+// problem generated from the Python models, problems/generate_problem.py:26-61):
+//   quadcopter ............ python/alpaqa_mpc_benchmarks/problems/quadcopter.py:6-112
+//   realistic_quadcopter .. python/alpaqa_mpc_benchmarks/problems/realistic_quadcopter.py:6-118
+// With nine states there is no lane-level parallelism worth a cross-lane exchange: every lane
+// of the wavefront evaluates the same scalar stage (no shuffles); the decision-vector algebra of
+// the solver is still spread over the 64 lanes.  First derivatives are hand-written adjoints,
+// second-order information comes from running the same templates on dual numbers
+// (forward-over-reverse).  sin/cos is wave_math's deterministic routine.
+#pragma once
+#include "wave_math.hip.h"
+
+namespace pantr {
+
+template <bool REALISTIC>
+struct QuadModelT {
+    static constexpr int nx = 9, nu = 4, nc = 4;
+    static constexpr double Ts = 0.1, g_grav = 9.81, c6 = Ts / 6;
+    static constexpr double r2 = 0.1 * 0.1; ///< collision cylinder radius squared (quadcopter.py:70)
+    __host__ __device__ static constexpr double pf(int i) { return i == 2 ? 0.5 : 0.25; } // quadcopter.py:90
+    __host__ __device__ static const char *name() { return REALISTIC ? "realistic_quadcopter" : "quadcopter"; }
+
+    __host__ __device__ static double u_lb(int c) { return c == 0 ? 0.0 : -0.1; }          // quadcopter.py:55-58
+    __host__ __device__ static double u_ub(int c) { return c == 0 ? 9.81 * 5 : 0.1; }
+    __host__ __device__ static double d_lb(int i) { // quadcopter.py:72-75
+        return i < 2 ? -1.5707963267948966 : i == 2 ? 0.8525245220595057 /* cos(1.1/2) */ : -inf_();
+    }
+    __host__ __device__ static double d_ub(int i) { return i < 2 ? 1.5707963267948966 : i == 2 ? inf_() : 0.0; }
+    __host__ __device__ static constexpr double inf_() { return __builtin_huge_val(); }
+    __host__ __device__ static void initial_state(double *x0) { // quadcopter.py:80-88
+        const double v[9] = {-0.2, -0.25, 0.5, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 9; ++i)
+            x0[i] = v[i];
+    }
+    __host__ __device__ static double initial_guess(int c) { return c == 0 ? 9.81 : 0.0; } // quadcopter.py:111
+
+    /// Third column of the body-to-world rotation and, for the realistic model, the Euler-rate
+    /// map d_orient = Omega^{-1} omega, with the trigonometric values they are built from.
+    template <class T>
+    struct Trig {
+        T s0, c0, s1, c1, s2, c2;
+    };
+    template <class T>
+    __device__ static __forceinline__ Trig<T> trig(const T *s) {
+        Trig<T> t;
+        sincos_t(s[6], t.s0, t.c0);
+        sincos_t(s[7], t.s1, t.c1);
+        sincos_t(s[8], t.s2, t.c2);
+        return t;
+    }
+
+    /// f_c(state, input) (quadcopter.py:30-46, realistic_quadcopter.py:30-50)
+    template <class T>
+    __device__ static __forceinline__ void fc(const T *s, const T *u, T *ds) {
+        const Trig<T> t = trig(s);
+        T r0, r1, r2_;
+        if (!REALISTIC) { // (cr,sr)=(c0,s0) roll, (cp,sp)=(c1,s1) pitch, (cy,sy)=(c2,s2) yaw
+            r0  = ((t.c2 * t.s1) * t.c0) + (t.s2 * t.s0);
+            r1  = ((t.s2 * t.s1) * t.c0) - (t.c2 * t.s0);
+            r2_ = t.c1 * t.c0;
+        } else { // phi = s[6], theta = s[7], psi = s[8]
+            r0  = (t.c2 * t.s1) + ((t.c1 * t.s0) * t.s2);
+            r1  = (t.s2 * t.s1) - ((t.c2 * t.c1) * t.s0);
+            r2_ = t.c0 * t.c1;
+        }
+        ds[0] = s[3];
+        ds[1] = s[4];
+        ds[2] = s[5];
+        ds[3] = r0 * u[0];
+        ds[4] = r1 * u[0];
+        ds[5] = (r2_ * u[0]) - g_grav;
+        if (!REALISTIC) {
+            ds[6] = u[1];
+            ds[7] = u[2];
+            ds[8] = u[3];
+        } else { // Omega [a b c]' = omega, Omega = [[c1,0,-c0 s1],[0,1,s0],[s1,0,c0 c1]], det = c0
+            T a   = (t.c1 * u[1]) + (t.s1 * u[3]);
+            T cc  = ((t.c1 * u[3]) - (t.s1 * u[1])) / t.c0;
+            T b   = u[2] - (t.s0 * cc);
+            ds[6] = a;
+            ds[7] = b;
+            ds[8] = cc;
+        }
+    }
+
+    /// Adjoint of f_c: sb = (df/ds)' kb, ub = (df/du)' kb.
+    template <class T>
+    __device__ static __forceinline__ void fc_adj(const T *s, const T *u, const T *kb, T *sb, T *ub) {
+        const Trig<T> t = trig(s);
+        const T at = u[0];
+        T r0, r1, r2_, dr0[3], dr1[3], dr2[3]; // d r_i / d s[6+j]
+        if (!REALISTIC) {
+            r0     = ((t.c2 * t.s1) * t.c0) + (t.s2 * t.s0);
+            r1     = ((t.s2 * t.s1) * t.c0) - (t.c2 * t.s0);
+            r2_    = t.c1 * t.c0;
+            dr0[0] = (t.s2 * t.c0) - ((t.c2 * t.s1) * t.s0);
+            dr0[1] = (t.c2 * t.c1) * t.c0;
+            dr0[2] = (t.c2 * t.s0) - ((t.s2 * t.s1) * t.c0);
+            dr1[0] = -(((t.s2 * t.s1) * t.s0) + (t.c2 * t.c0));
+            dr1[1] = (t.s2 * t.c1) * t.c0;
+            dr1[2] = r0;
+            dr2[0] = -(t.c1 * t.s0);
+            dr2[1] = -(t.s1 * t.c0);
+            dr2[2] = T{} * t.c0; // 0
+        } else {
+            r0     = (t.c2 * t.s1) + ((t.c1 * t.s0) * t.s2);
+            r1     = (t.s2 * t.s1) - ((t.c2 * t.c1) * t.s0);
+            r2_    = t.c0 * t.c1;
+            dr0[0] = (t.c1 * t.c0) * t.s2;
+            dr0[1] = (t.c2 * t.c1) - ((t.s1 * t.s0) * t.s2);
+            dr0[2] = ((t.c1 * t.s0) * t.c2) - (t.s2 * t.s1);
+            dr1[0] = -((t.c2 * t.c1) * t.c0);
+            dr1[1] = (t.s2 * t.c1) + ((t.c2 * t.s1) * t.s0);
+            dr1[2] = r0;
+            dr2[0] = -(t.s0 * t.c1);
+            dr2[1] = -(t.c0 * t.s1);
+            dr2[2] = T{} * t.c0; // 0
+        }
+        const T a0 = kb[3], a1 = kb[4], a2 = kb[5];
+        sb[0] = T{} * at; // no dependence on p
+        sb[1] = sb[0];
+        sb[2] = sb[0];
+        sb[3] = kb[0];
+        sb[4] = kb[1];
+        sb[5] = kb[2];
+        ub[0] = ((r0 * a0) + (r1 * a1)) + (r2_ * a2);
+        const T w0 = at * a0, w1 = at * a1, w2 = at * a2;
+        for (int j = 0; j < 3; ++j)
+            sb[6 + j] = ((dr0[j] * w0) + (dr1[j] * w1)) + (dr2[j] * w2);
+        if (!REALISTIC) {
+            ub[1] = kb[6];
+            ub[2] = kb[7];
+            ub[3] = kb[8];
+        } else {
+            // a = c1 u1 + s1 u3 ; cc = (c1 u3 - s1 u1)/c0 ; b = u2 - s0 cc
+            const T ka = kb[6], kb_ = kb[7], kc = kb[8];
+            const T num = (t.c1 * u[3]) - (t.s1 * u[1]);
+            const T cc  = num / t.c0;
+            const T kcc = kc - (t.s0 * kb_);   // total adjoint of cc
+            const T q   = kcc / t.c0;          // adjoint of num
+            ub[1] = (t.c1 * ka) - (t.s1 * q);
+            ub[2] = kb_;
+            ub[3] = (t.s1 * ka) + (t.c1 * q);
+            // d/dphi (s[6]): b -> -c0 cc kb_ ; cc = num/c0 -> num s0/c0^2 = cc s0/c0
+            sb[6] = sb[6] + (((cc * t.s0) / t.c0) * kcc - ((t.c0 * cc) * kb_));
+            // d/dtheta (s[7]): a -> (-s1 u1 + c1 u3) ka = num ka ; num -> (-s1 u3 - c1 u1) q
+            sb[7] = sb[7] + ((num * ka) - (((t.s1 * u[3]) + (t.c1 * u[1])) * q));
+        }
+    }
+
+    /// l(x,u) (quadcopter.py:93-106): lu + lx
+    template <class T>
+    __device__ static __forceinline__ T stage_cost(const T *s, const T *u) {
+        T su  = (((u[0] * u[0]) + (u[1] * u[1])) + (u[2] * u[2])) + (u[3] * u[3]);
+        T so  = ((u[1] * u[1]) + (u[2] * u[2])) + (u[3] * u[3]);
+        T lu  = (1e-4 * su) + (10.0 * so);
+        return lu + state_cost(s, 1.0, 10.0, 1.0);
+    }
+    /// l_N(x) (quadcopter.py:107-112)
+    template <class T>
+    __device__ static __forceinline__ T term_cost(const T *s) { return state_cost(s, 25.0, 250.0, 10.0); }
+    template <class T>
+    __device__ static __forceinline__ T state_cost(const T *s, double qv, double qp, double qth) {
+        T d0 = s[0] - pf(0), d1 = s[1] - pf(1), d2 = s[2] - pf(2);
+        T sp = ((d0 * d0) + (d1 * d1)) + (d2 * d2);
+        T sv = ((s[3] * s[3]) + (s[4] * s[4])) + (s[5] * s[5]);
+        T st = ((s[6] * s[6]) + (s[7] * s[7])) + (s[8] * s[8]);
+        return ((qv * sv) + (qp * sp)) + (qth * st);
+    }
+    /// gs += dl/dx, gu = dl/du  (u == nullptr: terminal cost)
+    template <class T>
+    __device__ static __forceinline__ void cost_grad(const T *s, const T *u, T *gs, T *gu) {
+        const double qv = u ? 1.0 : 25.0, qp = u ? 10.0 : 250.0, qth = u ? 1.0 : 10.0;
+        for (int i = 0; i < 3; ++i) {
+            gs[i]     = gs[i] + (2.0 * qp) * (s[i] - pf(i));
+            gs[3 + i] = gs[3 + i] + (2.0 * qv) * s[3 + i];
+            gs[6 + i] = gs[6 + i] + (2.0 * qth) * s[6 + i];
+        }
+        if (u) {
+            gu[0] = 2e-4 * u[0];
+            for (int j = 1; j < 4; ++j)
+                gu[j] = (2e-4 * u[j]) + (20.0 * u[j]);
+        }
+    }
+
+    /// c(x) (quadcopter.py:62-71)
+    template <class T>
+    __device__ static __forceinline__ void constr(const T *s, T *c) {
+        T s0, c0, s1, c1;
+        sincos_t(s[6], s0, c0);
+        sincos_t(s[7], s1, c1);
+        c[0] = s[6];
+        c[1] = s[7];
+        c[2] = c0 * c1;
+        c[3] = (r2 - (s[0] * s[0])) - (s[1] * s[1]);
+    }
+    /// sb += (dc/dx)' yb
+    template <class T>
+    __device__ static __forceinline__ void constr_adj(const T *s, const T *yb, T *sb) {
+        T s0, c0, s1, c1;
+        sincos_t(s[6], s0, c0);
+        sincos_t(s[7], s1, c1);
+        sb[6] = sb[6] + (yb[0] - ((s0 * c1) * yb[2]));
+        sb[7] = sb[7] + (yb[1] - ((c0 * s1) * yb[2]));
+        sb[0] = sb[0] - ((2.0 * s[0]) * yb[3]);
+        sb[1] = sb[1] - ((2.0 * s[1]) * yb[3]);
+    }
+};
+
+} // namespace pantr

@@ -31,6 +31,50 @@ __device__ __forceinline__ dual operator/(double c, dual b) {
     double k = (-q) / b.v;
     return {q, b.t * k};
 }
+/// a / b = q with tangent (a.t - q b.t) / b.v
+__device__ __forceinline__ dual operator/(dual a, dual b) {
+    double q = a.v / b.v;
+    return {q, (a.t - q * b.t) / b.v};
+}
+__device__ __forceinline__ dual operator-(dual a) { return {-a.v, -a.t}; }
+/// clamp pieces with the tangent of the selected branch
+__device__ __forceinline__ double tmin(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double tmax(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ dual tmin(dual a, double b) { return a.v < b ? a : dual{b, 0.0}; }
+__device__ __forceinline__ dual tmax(dual a, double b) { return a.v > b ? a : dual{b, 0.0}; }
+
+/// Deterministic sin/cos: 2-term Cody-Waite reduction by pi/2 and the fdlibm kernel polynomials
+/// with explicit fma; the oracle runs the same operations, so trigonometric values agree bit for
+/// bit between CPU and GPU (the device math library and libm do not agree with each other).
+__device__ __forceinline__ void sincos_det(double x, double &s, double &c) {
+    const double kd = __builtin_rint(x * 6.36619772367581382433e-01); // x * 2/pi, ties to even
+    double r        = __builtin_fma(-kd, 1.57079632673412561417e+00, x);
+    r               = __builtin_fma(-kd, 6.07710050650619224932e-11, r);
+    const double z  = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps        = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps        = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps        = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps        = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = __builtin_fma(r * z, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc        = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc        = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc        = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc        = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+    const long long q = static_cast<long long>(kd) & 3;
+    s = q == 0 ? sr : q == 1 ? cr : q == 2 ? -sr : -cr;
+    c = q == 0 ? cr : q == 1 ? -sr : q == 2 ? -cr : sr;
+}
+__device__ __forceinline__ void sincos_t(double x, double &s, double &c) { sincos_det(x, s, c); }
+__device__ __forceinline__ void sincos_t(dual x, dual &s, dual &c) {
+    double sv, cv;
+    sincos_det(x.v, sv, cv);
+    s = {sv, cv * x.t};
+    c = {cv, -(sv * x.t)};
+}
+
 /// sqrt(a) = r with tangent a.t * h, h = 0.5 / r
 __device__ __forceinline__ dual wsqrt(dual a) {
     double r = __builtin_sqrt(a.v);

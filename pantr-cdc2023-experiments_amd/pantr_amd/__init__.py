@@ -66,6 +66,7 @@ assert STATS_DTYPE.itemsize == C.sizeof(PantrStats)
 EXPORTS = (
     "pantr_params_create", "pantr_params_destroy", "pantr_params_set", "pantr_params_get",
     "pantr_batch_create", "pantr_batch_destroy", "pantr_batch_dims", "pantr_batch_get_box_C",
+    "pantr_batch_get_box_D", "pantr_batch_eval_psi_grad_psi_al", "pantr_batch_eval_hess_psi_prod_al",
     "pantr_batch_get_initial_guess", "pantr_batch_get_initial_state", "pantr_batch_set_param",
     "pantr_batch_get_param", "pantr_batch_solve", "pantr_batch_solve_device",
     "pantr_batch_last_kernel_ms", "pantr_batch_set_launch_order", "pantr_batch_set_trace",
@@ -114,12 +115,15 @@ def lib():
         L.pantr_batch_destroy.restype = None
         L.pantr_batch_dims.argtypes = [vp] + [C.POINTER(_i32)] * 6
         L.pantr_batch_get_box_C.argtypes = [vp, vp, vp]
+        L.pantr_batch_get_box_D.argtypes = [vp, vp, vp]
+        L.pantr_batch_eval_psi_grad_psi_al.argtypes = [vp, _i32, vp, vp, vp, vp, vp, vp, vp]
+        L.pantr_batch_eval_hess_psi_prod_al.argtypes = [vp, _i32, vp, vp, vp, vp, vp, vp]
         L.pantr_batch_get_initial_guess.argtypes = [vp, vp]
         L.pantr_batch_get_initial_state.argtypes = [vp, vp]
         L.pantr_batch_set_param.argtypes = [vp, cp]
         L.pantr_batch_get_param.argtypes = [vp, cp, pd]
         L.pantr_batch_solve.argtypes = [vp, _i32, vp, vp, vp, vp]
-        L.pantr_batch_solve_device.argtypes = [vp, _i32, vp, vp, vp, vp]
+        L.pantr_batch_solve_device.argtypes = [vp, _i32, vp, vp, vp, vp, vp]
         L.pantr_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pantr_batch_set_launch_order.argtypes = [vp, _i32, vp]
         L.pantr_batch_set_trace.argtypes = [vp, _i32, _i32]
@@ -211,6 +215,11 @@ class PantrBatch:
         _check(lib().pantr_batch_get_box_C(self._h, _ptr(lb), _ptr(ub)))
         return lb, ub
 
+    def box_D(self):
+        lb, ub = np.zeros(self.m), np.zeros(self.m)
+        _check(lib().pantr_batch_get_box_D(self._h, _ptr(lb), _ptr(ub)))
+        return lb, ub
+
     def initial_guess(self):
         u = np.zeros(self.n)
         _check(lib().pantr_batch_get_initial_guess(self._h, _ptr(u)))
@@ -236,13 +245,30 @@ class PantrBatch:
         if u.shape != (B, self.n):
             raise ValueError(f"expected u0 shape {(B, self.n)}, got {u.shape}")
         stats = np.zeros(B, dtype=STATS_DTYPE)
+        if self.m > 0:
+            raise ValueError("this problem has general constraints: use solve_al(x0, u0, y0)")
         _check(lib().pantr_batch_solve(self._h, B, _ptr(x0), _ptr(u), None, _ptr(stats)))
         return u, stats
 
-    def solve_device(self, B, d_x0, d_u, d_stats, stream=None):
+    def solve_al(self, x0, u0, y0=None):
+        """ALM solve of B instances of a problem with general constraints.  y0: (B, m) initial
+        multipliers (zeros if None).  Returns (u, y, stats)."""
+        x0 = _f64(x0)
+        B = x0.shape[0]
+        x0 = _f64(x0, (B, self.nx))
+        u = np.array(u0, dtype=np.float64, order="C", copy=True)
+        y = np.zeros((B, self.m)) if y0 is None else np.array(y0, dtype=np.float64, order="C", copy=True)
+        if u.shape != (B, self.n) or y.shape != (B, self.m):
+            raise ValueError("u0 must be (B, n) and y0 (B, m)")
+        stats = np.zeros(B, dtype=STATS_DTYPE)
+        _check(lib().pantr_batch_solve(self._h, B, _ptr(x0), _ptr(u), _ptr(y), _ptr(stats)))
+        return u, y, stats
+
+    def solve_device(self, B, d_x0, d_u, d_stats, stream=None, d_y=None):
         """Device-pointer solve (ints = device addresses), asynchronous on `stream`."""
         _check(lib().pantr_batch_solve_device(self._h, B, C.c_void_p(d_x0), C.c_void_p(d_u),
-                                              C.c_void_p(d_stats), C.c_void_p(stream or 0)))
+                                              C.c_void_p(d_y or 0), C.c_void_p(d_stats),
+                                              C.c_void_p(stream or 0)))
 
     def last_kernel_ms(self):
         ms = C.c_float()
@@ -287,6 +313,23 @@ class PantrBatch:
         B = x0.shape[0]
         Hv = np.zeros((B, self.n))
         _check(lib().pantr_batch_eval_hess_psi_prod(self._h, B, _ptr(x0), _ptr(u), _ptr(v), _ptr(Hv)))
+        return Hv
+
+    def eval_psi_grad_psi_al(self, x0, u, y, Sigma):
+        """psi, grad psi and yhat with multipliers y and penalties Sigma (formulation.hpp:145-161)."""
+        x0, u, y, Sigma = _f64(x0), _f64(u), _f64(y), _f64(Sigma)
+        B = x0.shape[0]
+        psi, grad, yhat = np.zeros(B), np.zeros((B, self.n)), np.zeros((B, self.m))
+        _check(lib().pantr_batch_eval_psi_grad_psi_al(self._h, B, _ptr(x0), _ptr(u), _ptr(y), _ptr(Sigma),
+                                                      _ptr(psi), _ptr(grad), _ptr(yhat)))
+        return psi, grad, yhat
+
+    def eval_hess_psi_prod_al(self, x0, u, y, Sigma, v):
+        x0, u, y, Sigma, v = _f64(x0), _f64(u), _f64(y), _f64(Sigma), _f64(v)
+        B = x0.shape[0]
+        Hv = np.zeros((B, self.n))
+        _check(lib().pantr_batch_eval_hess_psi_prod_al(self._h, B, _ptr(x0), _ptr(u), _ptr(y), _ptr(Sigma),
+                                                       _ptr(v), _ptr(Hv)))
         return Hv
 
     def eval_prox_grad_step(self, gamma, x, grad):

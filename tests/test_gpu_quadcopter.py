@@ -1,0 +1,94 @@
+"""GPU parity tests of SURVEY.md section 8 row f1: problems with general constraints (quadcopter,
+realistic_quadcopter) and the ALM outer loop, against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import pantr_amd as pa
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10  # north star tolerance; the asserts below are exact where noted
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def rng():
+    return np.random.default_rng(2023)
+
+
+def quad_opts(problem):
+    """dodo.py:12-33 + :97-105"""
+    o = list(pa.DODO_PANTR_OPTS) + ["num_dist=0", "solver.max_iter=250"]
+    if problem == "realistic_quadcopter":
+        o += ["accel.tol_scale=1", "alm.initial_tolerance=1e-1"]
+    return o
+
+
+@pytest.mark.parametrize("problem", ["quadcopter", "realistic_quadcopter"])
+def test_problem_data(problem):
+    b = pa.PantrBatch(problem, 12, 1)
+    assert (b.n, b.m, b.nx, b.nu, b.nc, b.nc_N) == (48, 52, 9, 4, 4, 4)
+    lb, ub = b.box_C()
+    assert np.array_equal(lb[:4], [0, -0.1, -0.1, -0.1]) and np.array_equal(ub[:4], [9.81 * 5, 0.1, 0.1, 0.1])
+    dl, du = b.box_D()
+    assert np.allclose(dl[:4], [-np.pi / 2, -np.pi / 2, np.cos(0.55), -np.inf]) and du[3] == 0 and du[2] == np.inf
+    assert np.array_equal(b.initial_state(), ob.quad_initial_state())
+    assert np.array_equal(b.initial_guess(), ob.quad_initial_guess(12))
+    b.close()
+
+
+@pytest.mark.parametrize("problem", ["quadcopter", "realistic_quadcopter"])
+@pytest.mark.parametrize("N", [1, 7, 30])
+def test_psi_grad_hess_prod_match_oracle(rng, problem, N):
+    B, n, m = 3, 4 * N, 4 * N + 4
+    b = pa.PantrBatch(problem, N, B)
+    x0 = ob.quad_initial_state()[None, :] + 0.05 * rng.standard_normal((B, 9))
+    u = ob.quad_initial_guess(N)[None, :] + 0.3 * rng.standard_normal((B, n))
+    y, Sig = rng.standard_normal((B, m)), 10 ** rng.uniform(0, 3, (B, m))
+    v = rng.standard_normal((B, n))
+    psi, grad, yhat = b.eval_psi_grad_psi_al(x0, u, y, Sig)
+    Hv = b.eval_hess_psi_prod_al(x0, u, y, Sig, v)
+    xn = b.simulate_dynamics(x0, u[:, :4])
+    b.close()
+    for i in range(B):
+        p_o, g_o, yh_o = ob.quad_psi_grad(problem, N, x0[i], y[i], Sig[i], u[i])
+        assert psi[i] == p_o and np.array_equal(grad[i], g_o) and np.array_equal(yhat[i], yh_o)
+        Hv_o = ob.quad_hess_prod(problem, N, x0[i], y[i], Sig[i], u[i], v[i])
+        assert rel(Hv[i], Hv_o) <= RTOL and np.array_equal(Hv[i], Hv_o)
+        assert np.array_equal(xn[i], ob.quad_simulate(problem, x0[i], u[i, :4]))
+
+
+@pytest.mark.parametrize("problem,N", [("quadcopter", 12), ("realistic_quadcopter", 20)])
+def test_alm_solve_matches_oracle(rng, problem, N):
+    """BASELINE.json configs[0] (quadcopter horizon 12) and a realistic_quadcopter case."""
+    B, n = 3, 4 * N
+    b = pa.PantrBatch(problem, N, B, opts=quad_opts(problem))
+    x0 = np.vstack([ob.quad_initial_state(), ob.quad_initial_state() + 0.02 * rng.standard_normal((B - 1, 9))])
+    u0 = np.tile(ob.quad_initial_guess(N), (B, 1))
+    u, y, st = b.solve_al(x0, u0)
+    b.close()
+    for i in range(B):
+        u_o, y_o, st_o = ob.quad_solve(problem, N, x0[i], u0[i])
+        assert st["status"][i] == st_o["status"] == 1
+        for key in ("outer_iterations", "iterations", "cg_iterations", "n_hess_psi_prod", "n_psi",
+                    "n_psi_grad_psi", "n_grad_L", "inner_convergence_failures"):
+            assert st[key][i] == st_o[key], key
+        assert rel(u[i], u_o) <= RTOL and np.array_equal(u[i], u_o) and np.array_equal(y[i], y_o)
+        assert st["eps"][i] == st_o["eps"] and st["delta"][i] == st_o["delta"]
+        assert st["eps"][i] <= 1e-8 and st["delta"][i] <= 1e-8
+
+
+@pytest.mark.parametrize("warm", [True, False])
+def test_closed_loop_with_multipliers(warm):
+    """mpc-driver.cpp:123-210 incl. the multiplier shift (:173-175), on the device."""
+    problem, N, num_sim = "quadcopter", 10, 5
+    b = pa.PantrBatch(problem, N, 1, opts=quad_opts(problem))
+    states, inputs, stats = b.mpc(num_sim, warm, np.zeros((1, 4)), num_dist=0)
+    b.close()
+    st_o, in_o, stats_o = ob.quad_mpc(problem, N, num_sim, warm)
+    assert np.array_equal(states[:, 0], st_o) and np.array_equal(inputs[:, 0], in_o)
+    assert [s["iterations"] for s in stats_o] == stats["iterations"][:, 0].tolist()
