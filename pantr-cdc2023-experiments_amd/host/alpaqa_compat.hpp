@@ -197,13 +197,13 @@ class ALMSolver {
         return convert(s);
     }
 
-    /// Batched form: B independent instances (x0s[B][nx], xs[B][n] in/out).
+    /// Batched form: B independent instances (x0s[B][nx], xs[B][n] and ys[B][m] in/out).
     template <class Conf>
-    std::vector<Stats> solve_batch(TypeErasedProblem<Conf> &problem, length_t B, crvec x0s, rvec xs) {
+    std::vector<Stats> solve_batch(TypeErasedProblem<Conf> &problem, length_t B, crvec x0s, rvec xs, rvec ys = {}) {
         push_options(problem.get());
         std::vector<pantr_stats_t> s(B);
-        check(pantr_batch_solve(problem.get(), static_cast<int32_t>(B), x0s.data(), xs.data(), nullptr,
-                                s.data()));
+        check(pantr_batch_solve(problem.get(), static_cast<int32_t>(B), x0s.data(), xs.data(),
+                                ys.empty() ? nullptr : ys.data(), s.data()));
         std::vector<Stats> out;
         for (auto &e : s) {
             problem.evaluations->add(e);
@@ -220,8 +220,9 @@ class ALMSolver {
         Stats r;
         r.status           = static_cast<SolverStatus>(s.status);
         r.elapsed_time     = std::chrono::nanoseconds(static_cast<long long>(s.elapsed_s * 1e9));
-        r.outer_iterations = 1;
+        r.outer_iterations = static_cast<unsigned>(s.outer_iterations);
         r.eps              = s.eps;
+        r.delta            = s.delta;
         r.inner            = s;
         return r;
     }

@@ -68,7 +68,7 @@ auto make_solver(std::span<const std::string_view> extra_opts) {
 }
 
 struct MPCResults {
-    vec states, inputs, runtimes, guesses;
+    vec states, inputs, runtimes, guesses, y_guesses, multipliers;
 };
 
 /// mpc-driver.cpp:123-210 (single shooting)
@@ -122,6 +122,8 @@ MPCResults do_mpc_experiment(Problem &problem, Solver &solver, length_t N,
     res.states.resize(nx * (num_sim + 1));
     res.inputs.resize(n * num_sim);
     res.guesses.resize(n * num_sim);
+    res.y_guesses.resize(m * num_sim);
+    res.multipliers.resize(m * num_sim);
     for (length_t i = 0; i < num_sim; ++i) {
         if (warm_start) { // shift previous solution (:168-175)
             std::copy(u.begin() + nu, u.end(), u.begin());
@@ -134,7 +136,9 @@ MPCResults do_mpc_experiment(Problem &problem, Solver &solver, length_t N,
             std::fill(y.begin(), y.end(), 0.0);
         }
         std::copy(u.begin(), u.end(), res.guesses.begin() + i * n);
+        std::copy(y.begin(), y.end(), res.y_guesses.begin() + i * m);
         res.runtimes[i] = solve(u, y);
+        std::copy(y.begin(), y.end(), res.multipliers.begin() + i * m);
         std::copy(x0.begin(), x0.end(), res.states.begin() + i * nx);
         std::copy(u.begin(), u.end(), res.inputs.begin() + i * n);
         x0 = problem.simulate(x0, crvec{u}.first(nu));
@@ -216,9 +220,11 @@ int main(int argc, char *argv[]) try {
                  vec xs(mpc.guesses);
                  vec x0s(mpc.states.begin(), mpc.states.begin() + B * nx);
                  auto t0    = std::chrono::steady_clock::now();
-                 auto stats = solver.solve_batch(problem, B, x0s, xs);
+                 vec ys(mpc.y_guesses);
+                 auto stats = solver.solve_batch(problem, B, x0s, xs, ys);
                  auto dt    = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                 bool same  = std::equal(xs.begin(), xs.end(), mpc.inputs.begin());
+                 bool same  = std::equal(xs.begin(), xs.end(), mpc.inputs.begin()) &&
+                             std::equal(ys.begin(), ys.end(), mpc.multipliers.begin());
                  length_t conv = 0;
                  for (auto &s : stats)
                      conv += s.status == alpaqa::SolverStatus::Converged;

@@ -64,3 +64,22 @@ def test_driver_errors(tmp_path):
     r = subprocess.run([DRIVER, "hanging_chain", "10", "ss2p", "method=pantr", "u_dist=1,2"],
                        cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode != 0 and "Invalid u_dist size" in r.stderr
+
+
+@pytest.mark.parametrize("problem", ["quadcopter", "realistic_quadcopter"])
+def test_driver_quadcopter_closed_loop_matches_oracle(tmp_path, problem):
+    """The CLI clone on a problem with general constraints (ALM, multiplier shift)."""
+    N, num_sim = 12, 6
+    name = f"mpc-{problem}-{N},{num_sim}-warm-pantr"
+    opts = list(pa.DODO_PANTR_OPTS) + ["num_dist=0", "solver.max_iter=250"]
+    if problem == "realistic_quadcopter":
+        opts += ["accel.tol_scale=1", "alm.initial_tolerance=1e-1"]   # dodo.py:101-105
+    cmd = [DRIVER, problem, str(N), "ss2p", "method=pantr", f"num_sim={num_sim}",
+           f"results_name={name}", "warm=true", "replay=true"] + opts
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = load_results(str(tmp_path), name)
+    states, inputs, stats = ob.quad_mpc(problem, N, num_sim, True)
+    assert np.array_equal(res["states"].T, states) and np.array_equal(res["inputs"].T, inputs)
+    assert res["nvar"] == 4 * N and res["ncon"] == 4 * N + 4 and np.all(res["runtimes"] > 0)
+    assert res["evaluations"]["hess_ψ_prod"] == sum(s["n_hess_psi_prod"] for s in stats)
