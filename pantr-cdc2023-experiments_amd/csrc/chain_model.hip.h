@@ -56,6 +56,7 @@ struct ChainModel {
         int pc;         ///< point clamped to 0..9 (idle lanes read valid LDS)
         int e[DIM];     ///< upper-triangle indices of row c of a symmetric 3x3
         bool active, mass, end, first, lead, grav;
+        double inv_m_l; ///< 1/m on the masses' lanes, 0 elsewhere (keeps idle lanes' derivatives at 0)
         double xref;       ///< reference position of this component of the end point (1,0,0)
         __device__ explicit Lane(int lane) {
             l      = lane;
@@ -66,7 +67,8 @@ struct ChainModel {
             end    = active && p == NB;
             first  = p == 0;
             lead   = active && c == 0;
-            grav   = c == DIM - 1;
+            grav   = mass && c == DIM - 1;
+            inv_m_l = mass ? inv_m : 0.0;
             q      = active ? DIM * p + c : 31;
             pc     = p < NP ? p : NP - 1;
             int cc = c < DIM ? c : 0;
@@ -87,8 +89,8 @@ struct ChainModel {
     __device__ static __forceinline__ double qb(double v) {
         constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
         int lo = __double2loint(v), hi = __double2hiint(v);
-        lo     = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false);
-        hi     = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false);
+        lo     = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xF, 0xF, true);
+        hi     = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xF, 0xF, true);
         return __hiloint2double(hi, lo);
     }
     /// (v0 + v1) + v2 over the three components of this lane's point.
@@ -161,14 +163,21 @@ struct ChainModel {
         sp.r      = __builtin_sqrt(sp.n2);
         sp.c      = Dspring * (1.0 - Lspring / sp.r);
     }
-    /// ds = f_c(s, u).
-    __device__ static __forceinline__ State fc(const Lane &L, const State &s, double uc, Springs &sp) {
+    /// The end point has no velocity state: its lanes carry the stage input there instead, so the
+    /// time derivative of every position is just "the v slot" (with_input() once per stage; the
+    /// slot's own derivative is 0 off the masses, so the input stays put through the Runge-Kutta
+    /// combinations).
+    __device__ static __forceinline__ State with_input(const Lane &L, const State &s, double uc) {
+        return {s.x, L.end ? uc : s.v};
+    }
+    /// ds = f_c(s, u); s comes from with_input().
+    __device__ static __forceinline__ State fc(const Lane &L, const State &s, Springs &sp) {
         springs(L, s, sp);
         double F  = sp.d * sp.c;
         double Fn = next_point(L, F); // force of the spring towards point p+1
         double a  = inv_m * (Fn - F);
         a         = L.grav ? a - g_grav : a;
-        return {L.end ? uc : s.v, L.mass ? a : 0.0};
+        return {s.v, L.mass ? a : 0.0}; // a select, not inv_m_l: lanes beyond the chain hold 0 * inf
     }
     struct AdjAux {
         double lF, dt, w;
@@ -177,7 +186,7 @@ struct ChainModel {
     /// on the end point's lanes.
     __device__ static __forceinline__ State fc_adj(const Lane &L, const Springs &sp, const State &kbar, AdjAux &ax) {
         double A   = prev_point(L, kbar.v);   // adjoint of a_{p-1} (0 for point 0)
-        double B   = L.mass ? kbar.v : 0.0;   // adjoint of a_p (none for point 9)
+        double B   = kbar.v;                  // adjoint of a_p (stays 0 off the masses: see the return)
         ax.lF      = inv_m * (A - B);
         double pr  = sp.d * ax.lF;
         ax.dt      = quad_sum(pr);
@@ -190,12 +199,13 @@ struct ChainModel {
     }
 
     /// One RK4 step of the plant (formulation.hpp:21-28).
-    __device__ static __forceinline__ State rk4(const Lane &L, const State &s, double uc) {
+    __device__ static __forceinline__ State rk4(const Lane &L, const State &s_in, double uc) {
         Springs sp;
-        State k1 = fc(L, s, uc, sp);
-        State k2 = fc(L, {s.x + 0.5 * (Ts * k1.x), s.v + 0.5 * (Ts * k1.v)}, uc, sp);
-        State k3 = fc(L, {s.x + 0.5 * (Ts * k2.x), s.v + 0.5 * (Ts * k2.v)}, uc, sp);
-        State k4 = fc(L, {s.x + Ts * k3.x, s.v + Ts * k3.v}, uc, sp);
+        State s  = with_input(L, s_in, uc);
+        State k1 = fc(L, s, sp);
+        State k2 = fc(L, {s.x + 0.5 * (Ts * k1.x), s.v + 0.5 * (Ts * k1.v)}, sp);
+        State k3 = fc(L, {s.x + 0.5 * (Ts * k2.x), s.v + 0.5 * (Ts * k2.v)}, sp);
+        State k4 = fc(L, {s.x + Ts * k3.x, s.v + Ts * k3.v}, sp);
         return {s.x + c6 * (((k1.x + 2.0 * k2.x) + 2.0 * k3.x) + k4.x),
                 s.v + c6 * (((k1.v + 2.0 * k2.v) + 2.0 * k3.v) + k4.v)};
     }
@@ -276,7 +286,7 @@ struct ChainModel {
 
     // ---- tangent sweeps over the tape ---------------------------------------------------------------
     /// Tangent of f_c: F_t = K d_t.  Writes d_t to the tangent tape.
-    __device__ static __forceinline__ State fc_tan(const Lane &L, const TapeK &g, const State &s_t, double uc_t,
+    __device__ static __forceinline__ State fc_tan(const Lane &L, const TapeK &g, const State &s_t,
                                                    double4 *st_stage, int j) {
         double d_t = s_t.x - prev_point(L, s_t.x);
         reinterpret_cast<double *>(reinterpret_cast<char *>(st_stage) + j * 256)[L.q] = d_t; // idle lanes: slot 31
@@ -284,14 +294,12 @@ struct ChainModel {
         F         = __builtin_fma(g.K[1], qb<1>(d_t), F);
         F         = __builtin_fma(g.K[2], qb<2>(d_t), F);
         double Fn = next_point(L, F);
-        double a  = inv_m * (Fn - F);
-        return {L.end ? uc_t : s_t.v, L.mass ? a : 0.0};
+        return {s_t.v, L.inv_m_l * (Fn - F)};
     }
     /// Tangent of the f_c adjoint: ld_t = K lF_t + M d_t.
     __device__ static __forceinline__ State fc_adj_tan(const Lane &L, const TapeKM &g, const State &kbar_t) {
         double A   = prev_point(L, kbar_t.v);
-        double B   = L.mass ? kbar_t.v : 0.0;
-        double lF  = inv_m * (A - B);
+        double lF  = inv_m * (A - kbar_t.v); // kbar_t.v stays 0 off the masses (see the return)
         double ld  = g.K[0] * qb<0>(lF);
         ld         = __builtin_fma(g.K[1], qb<1>(lF), ld);
         ld         = __builtin_fma(g.K[2], qb<2>(lF), ld);
@@ -302,15 +310,16 @@ struct ChainModel {
         return {L.end ? ld : ld - ldn, L.mass ? kbar_t.x : 0.0};
     }
     /// Tangent of one RK4 step; the stage's K rows are in LDS at `buf`.
-    __device__ static __forceinline__ State rk4_tan(const Lane &L, const char *buf, const State &s_t, double uc_t,
+    __device__ static __forceinline__ State rk4_tan(const Lane &L, const char *buf, const State &s_in, double uc_t,
                                                     double4 *st_stage) {
-        State k1 = fc_tan(L, tape_fwd(L, buf, 0), s_t, uc_t, st_stage, 0);
+        State s_t = with_input(L, s_in, uc_t);
+        State k1  = fc_tan(L, tape_fwd(L, buf, 0), s_t, st_stage, 0);
         State k2 = fc_tan(L, tape_fwd(L, buf, 1),
-                          {__builtin_fma(hTs, k1.x, s_t.x), __builtin_fma(hTs, k1.v, s_t.v)}, uc_t, st_stage, 1);
+                          {__builtin_fma(hTs, k1.x, s_t.x), __builtin_fma(hTs, k1.v, s_t.v)}, st_stage, 1);
         State k3 = fc_tan(L, tape_fwd(L, buf, 2),
-                          {__builtin_fma(hTs, k2.x, s_t.x), __builtin_fma(hTs, k2.v, s_t.v)}, uc_t, st_stage, 2);
+                          {__builtin_fma(hTs, k2.x, s_t.x), __builtin_fma(hTs, k2.v, s_t.v)}, st_stage, 2);
         State k4 = fc_tan(L, tape_fwd(L, buf, 3),
-                          {__builtin_fma(Ts, k3.x, s_t.x), __builtin_fma(Ts, k3.v, s_t.v)}, uc_t, st_stage, 3);
+                          {__builtin_fma(Ts, k3.x, s_t.x), __builtin_fma(Ts, k3.v, s_t.v)}, st_stage, 3);
         double tx = __builtin_fma(2.0, k2.x, k1.x), tv = __builtin_fma(2.0, k2.v, k1.v);
         tx        = __builtin_fma(2.0, k3.x, tx);
         tv        = __builtin_fma(2.0, k3.v, tv);
@@ -341,13 +350,14 @@ struct ChainModel {
     /// Adjoint of one RK4 step.  mu = adjoint of x_next; sbar = adjoint of s; ubar (valid on the
     /// end point's lanes) = adjoint of u through the dynamics.  With tape_stage != nullptr the
     /// K and M rows of the four substages are recorded.
-    __device__ static __forceinline__ void rk4_adj(const Lane &L, const State &s, double uc, const State &mu,
+    __device__ static __forceinline__ void rk4_adj(const Lane &L, const State &s_in, double uc, const State &mu,
                                                    State &sbar, double &ubar, double4 *tape_stage = nullptr) {
         Springs sp1, sp2, sp3, sp4;
         AdjAux ax;
-        State k = fc(L, s, uc, sp1);
-        k       = fc(L, {s.x + 0.5 * (Ts * k.x), s.v + 0.5 * (Ts * k.v)}, uc, sp2);
-        k       = fc(L, {s.x + 0.5 * (Ts * k.x), s.v + 0.5 * (Ts * k.v)}, uc, sp3);
+        State s = with_input(L, s_in, uc);
+        State k = fc(L, s, sp1);
+        k       = fc(L, {s.x + 0.5 * (Ts * k.x), s.v + 0.5 * (Ts * k.v)}, sp2);
+        k       = fc(L, {s.x + 0.5 * (Ts * k.x), s.v + 0.5 * (Ts * k.v)}, sp3);
         springs(L, {s.x + Ts * k.x, s.v + Ts * k.v}, sp4);
 
         double sgx = c6 * mu.x, sgv = c6 * mu.v;
