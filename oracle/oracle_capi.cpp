@@ -319,6 +319,15 @@ void oracle_quad_hess_prod(int realistic, int N, const double *x0, const double 
         return 0;
     });
 }
+void oracle_quad_hess_prod_dual(int realistic, int N, const double *x0, const double *y, const double *Sig,
+                                const double *u, const double *v, double *Hv) {
+    with_quad(realistic, N, [&](auto &p) {
+        std::copy(x0, x0 + 9, p.x0.begin());
+        p.set_al(y, Sig);
+        p.eval_hess_psi_prod_dual(u, v, Hv);
+        return 0;
+    });
+}
 /// ALM solve of one instance: u (n) and y (m) in/out.
 int oracle_quad_solve(int realistic, int N, const OracleParams *prm, const double *x0, double *u, double *y,
                       OracleStats *st) {

@@ -272,7 +272,11 @@ struct SingleShootingAL {
     explicit SingleShootingAL(int N_) : N(N_), x0(nx) { Model::initial_state(x0.data()); }
     int n() const { return nu * N; }
     int m() const { return nc * N + nc; } // ss.py:39-40: c on x_0..x_{N-1}, c_N on x_N
-    void set_al(const double *y_, const double *Sig_) { y = y_; Sig = Sig_; }
+    void set_al(const double *y_, const double *Sig_) {
+        y           = y_;
+        Sig         = Sig_;
+        tape_valid_ = false;
+    }
     double lb(int i) const { return Model::u_lb(i % nu); }
     double ub(int i) const { return Model::u_ub(i % nu); }
     double d_lb(int i) const { return Model::d_lb(i % nc); } // formulation.hpp:229-238
@@ -392,6 +396,141 @@ struct SingleShootingAL {
         }
     }
 
+    // ---- the second-order tape ------------------------------------------------------------------
+    // Recorded by grad_L (the point PANTR's Hessian-vector products follow).  With z = (x_k, u_k)
+    // (nz = nx + nu directions) and the multiplier estimate yhat_k(x_k) of the stage:
+    //   J_k[d][i] = d x_{k+1,i} / d z_d                            (dual RK4 step seeded with e_d)
+    //   H_k[d][l] = d/d z_d of the stage's adjoint outputs [lam_k ; grad_k] at fixed lam_{k+1}
+    //             = column d of  sum_i lam_{k+1,i} hess F_i + hess l + d(dc' yhat)/dz
+    // One dual evaluation of the stage per direction (the kernels run the nz directions on nz lanes
+    // of one sweep); the value parts of that evaluation are the ordinary adjoint sweep.
+    static constexpr int nz = nx + nu;
+    struct StageTape {
+        double J[nz][nx];
+        double H[nz][nz];
+    };
+    mutable std::vector<StageTape> tape_;
+    mutable double HN_[nx][nx];
+    mutable std::vector<double> tape_u_;
+    mutable bool tape_valid_ = false;
+
+    template <class T>
+    void stage_multipliers(const T *s, int k, T *yk) const {
+        T c[nc];
+        Model::constr(s, c);
+        for (int i = 0; i < nc; ++i) {
+            int j  = nc * k + i;
+            T zeta = c[i] + (y[j] / Sig[j]);
+            T zhat = tmax(tmin(zeta, d_ub(j)), d_lb(j));
+            T d    = zeta - zhat;
+            yk[i]  = Sig[j] * d;
+        }
+    }
+    /// The adjoint sweep of reverse<double>() (same gradient, bit for bit) that also records the tape.
+    void reverse_record(const double *u, const double *X, double *grad) const {
+        tape_.resize(N);
+        tape_u_.assign(u, u + n());
+        tape_valid_ = true;
+        double lam[nx];
+        for (int d = 0; d < nx; ++d) {
+            Dual s[nx], yk[nc], lt[nx], gu[nu];
+            for (int l = 0; l < nx; ++l) {
+                s[l]  = {X[N * nx + l], l == d ? 1.0 : 0.0};
+                lt[l] = Dual{};
+            }
+            stage_multipliers(s, N, yk);
+            Model::cost_grad(s, static_cast<const Dual *>(nullptr), lt, gu);
+            Model::constr_adj(s, yk, lt);
+            for (int l = 0; l < nx; ++l) {
+                HN_[d][l] = lt[l].t;
+                lam[l]    = lt[l].v;
+            }
+        }
+        for (int k = N - 1; k >= 0; --k) {
+            double lam_k[nx];
+            for (int d = 0; d < nz; ++d) {
+                Dual s[nx], ud[nu], xn[nx], yk[nc], mu[nx], sbar[nx], ubar[nu], gu[nu];
+                for (int l = 0; l < nx; ++l) {
+                    s[l]  = {X[k * nx + l], l == d ? 1.0 : 0.0};
+                    mu[l] = {lam[l], 0.0};
+                }
+                for (int c = 0; c < nu; ++c)
+                    ud[c] = {u[nu * k + c], nx + c == d ? 1.0 : 0.0};
+                rk4(s, ud, xn);
+                for (int i = 0; i < nx; ++i)
+                    tape_[k].J[d][i] = xn[i].t;
+                stage_multipliers(s, k, yk);
+                rk4_adj(s, ud, mu, sbar, ubar);
+                Model::cost_grad(s, ud, sbar, gu);
+                for (int c = 0; c < nu; ++c) {
+                    Dual g               = ubar[c] + gu[c];
+                    tape_[k].H[d][nx + c] = g.t;
+                    grad[nu * k + c]      = g.v;
+                }
+                Model::constr_adj(s, yk, sbar);
+                for (int l = 0; l < nx; ++l) {
+                    tape_[k].H[d][l] = sbar[l].t;
+                    lam_k[l]         = sbar[l].v;
+                }
+            }
+            std::copy(lam_k, lam_k + nx, lam);
+        }
+    }
+    /// Sum of products the way the kernels accumulate it: four partial sums (term t goes to partial
+    /// t mod 4, each an fma chain starting from 0), combined as (p0 + p1) + (p2 + p3).
+    struct Dot4 {
+        double p[4] = {0.0, 0.0, 0.0, 0.0};
+        int t       = 0;
+        void add(double a, double b) {
+            p[t & 3] = std::fma(a, b, p[t & 3]);
+            ++t;
+        }
+        double sum() const { return (p[0] + p[1]) + (p[2] + p[3]); }
+    };
+    /// Hv over the tape: x_t' = J z_t forward, then [lam_t ; Hv_k] = H z_t + J' lam_t' backward, every
+    /// component one Dot4 over its terms in index order.  Component l of H z_t uses direction l's
+    /// column of H as the row (H is symmetric up to rounding).
+    void hess_prod_tape(const double *v, double *Hv) const {
+        std::vector<double> Xt((N + 1) * nx, 0.0);
+        double z[nz], w[nz];
+        for (int k = 0; k < N; ++k) {
+            for (int d = 0; d < nx; ++d)
+                z[d] = Xt[k * nx + d];
+            for (int c = 0; c < nu; ++c)
+                z[nx + c] = v[nu * k + c];
+            for (int i = 0; i < nx; ++i) {
+                Dot4 acc;
+                for (int d = 0; d < nz; ++d)
+                    acc.add(tape_[k].J[d][i], z[d]);
+                Xt[(k + 1) * nx + i] = acc.sum();
+            }
+        }
+        double lt[nx];
+        for (int l = 0; l < nx; ++l) {
+            Dot4 acc;
+            for (int d = 0; d < nx; ++d)
+                acc.add(HN_[l][d], Xt[N * nx + d]);
+            lt[l] = acc.sum();
+        }
+        for (int k = N - 1; k >= 0; --k) {
+            for (int d = 0; d < nx; ++d)
+                z[d] = Xt[k * nx + d];
+            for (int c = 0; c < nu; ++c)
+                z[nx + c] = v[nu * k + c];
+            for (int l = 0; l < nz; ++l) {
+                Dot4 acc;
+                for (int d = 0; d < nz; ++d)
+                    acc.add(tape_[k].H[l][d], z[d]);
+                for (int i = 0; i < nx; ++i)
+                    acc.add(tape_[k].J[l][i], lt[i]);
+                w[l] = acc.sum();
+            }
+            for (int c = 0; c < nu; ++c)
+                Hv[nu * k + c] = w[nx + c];
+            std::copy(w, w + nx, lt);
+        }
+    }
+
     double eval_psi(const double *u, double *yhat) const {
         ++cnt.psi;
         std::vector<double> X((N + 1) * nx);
@@ -412,14 +551,28 @@ struct SingleShootingAL {
         psi_grad_impl(u, grad);
     }
     /// grad_L(xhat, yhat(xhat)) = grad psi(xhat)  (formulation.hpp:98-99 with y = yhat)
+    /// (PANTR evaluates it at the point its Hessian-vector products follow, so this is where the
+    /// second-order tape is recorded, as in the kernels.)
     void eval_grad_L(const double *u, double *grad) const {
         ++cnt.grad_L;
-        psi_grad_impl(u, grad);
+        std::vector<double> X((N + 1) * nx), yh(m());
+        forward(u, X.data(), yh.data());
+        reverse_record(u, X.data(), grad);
     }
-    /// Hessian-vector product of psi by forward-over-reverse on dual numbers
-    /// (formulation.hpp:93-97: gradient(jtimes(aug_lagr, u, v), u)).
+    /// The Hessian-vector product of the problem (formulation.hpp:93-97), over the tape.
     void eval_hess_psi_prod(const double *u, const double *v, double *Hv) const {
         ++cnt.hess_psi_prod;
+        if (!tape_valid_ || tape_u_.size() != (size_t)n() || !std::equal(u, u + n(), tape_u_.begin())) {
+            std::vector<double> X((N + 1) * nx), yh(m()), g(n()); // tape is for another point
+            forward(u, X.data(), yh.data());
+            reverse_record(u, X.data(), g.data());
+        }
+        hess_prod_tape(v, Hv);
+    }
+    /// Hessian-vector product of psi by forward-over-reverse on dual numbers through the whole
+    /// horizon (formulation.hpp:93-97: gradient(jtimes(aug_lagr, u, v), u)).  Independent check of
+    /// eval_hess_psi_prod (agrees to rounding, not bit for bit).
+    void eval_hess_psi_prod_dual(const double *u, const double *v, double *Hv) const {
         std::vector<Dual> ud(n()), X((N + 1) * nx), yh(m()), g(n());
         for (int i = 0; i < n(); ++i)
             ud[i] = {u[i], v[i]};

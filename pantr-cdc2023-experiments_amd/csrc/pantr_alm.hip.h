@@ -7,8 +7,13 @@
 //   constraints on x_0..x_{N-1} and x_N                          python/.../formulations/ss.py:39-40
 //   alpaqa::ALMSolver::operator() (m > 0)                        drivers/mpc-driver.cpp:104-115,217
 //   ALM options                                                  new-benchmarks-paper/dodo.py:12-22,101-105
-// One wavefront per MPC instance as for the chain; the nine-state stage is evaluated identically by
-// every lane (no cross-lane traffic), trajectories and multipliers live in LDS.
+// One wavefront per MPC instance as for the chain.  The nine-state stage is small, so the first-order
+// sweeps evaluate it identically on every lane (no cross-lane traffic; trajectories and multipliers
+// live in LDS).  The second-order work is spread over lanes: the adjoint sweep of grad_L runs on dual
+// numbers with lane d seeding direction e_d of z = (x_k, u_k), which yields the stage Jacobian J_k
+// and the stage Hessian H_k of the Lagrangian-like recursion column by column in ONE sweep; each
+// Hessian-vector product of the CG iterations is then 13x13 / 13x9 matrix-vector work per stage,
+// lane l owning component l, streamed from the HBM tape one stage ahead of the arithmetic.
 #pragma once
 #include "pantr_kernel.hip.h"
 
@@ -28,6 +33,7 @@ struct AlmSolveArgs {
     const double *x0; ///< [B][nx]
     double *u;        ///< [B][n] in/out
     double *y;        ///< [B][m] in/out
+    double *ws;       ///< [B][ScalarALProblem::workspace_doubles(N)] second-order tape
     DeviceStats *stats;
     double *trace;
     const int32_t *order;
@@ -46,7 +52,17 @@ struct ScalarALProblem {
     double *mv;  ///< m-vectors: y, Sigma, e1, e2, yh0, yh1, yh2, yh_t (tangent of yhat), mpad doubles each
     double *X;   ///< LDS: primal trajectory (N+1) x nx
     double *Xt;  ///< LDS: tangent trajectory (N+1) x nx
-    enum { MV_Y = 0, MV_SIG = 1, MV_E1 = 2, MV_E2 = 3, MV_YH = 4, MV_YHT = 7, MV_COUNT = 8 };
+    double *tape; ///< HBM: this instance's second-order tape (see workspace_doubles)
+    enum { MV_Y = 0, MV_SIG = 1, MV_E1 = 2, MV_E2 = 3, MV_YH = 4, MV_COUNT = 7 };
+
+    // Second-order tape, per stage three blocks of 16 rows x 16 doubles: JT row i = (dx+_i/dz_d)_d,
+    // JC row d = (dx+_i/dz_d)_i, HC row l = column l of H_k.  After the N stages one block with the
+    // terminal Hessian (row l = column l).  Lane r < 16 reads row r; a block stores element e of
+    // row r at elem(r, e) = pair-major [e/2][r][e%2], so that one 16-byte load per lane covers 256
+    // contiguous bytes across the 16 reading lanes.
+    static constexpr int nz = nx + nu, ROW = 16, BLOCK = 16 * ROW, STAGE = 3 * BLOCK;
+    __host__ __device__ static size_t workspace_doubles(int N) { return (size_t)N * STAGE + BLOCK; }
+    __device__ static __forceinline__ int elem(int r, int e) { return ((e >> 1) * ROW + r) * 2 + (e & 1); }
 
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
     __device__ __forceinline__ double *mvec(int slot) const { return mv + slot * mpad; }
@@ -54,16 +70,10 @@ struct ScalarALProblem {
         return (size_t)NUM_VEC * npad + (size_t)MV_COUNT * mpad + (size_t)2 * (N + 1) * nx;
     }
 
-    // typed views of the inputs / trajectory for T = double (primal sweep) and T = dual (Hv sweep)
     __device__ __forceinline__ void load_u(const double *u, const double *, int k, double (&uk)[nu]) const {
 #pragma unroll
         for (int c = 0; c < nu; ++c)
             uk[c] = u[nu * k + c];
-    }
-    __device__ __forceinline__ void load_u(const double *u, const double *v, int k, dual (&uk)[nu]) const {
-#pragma unroll
-        for (int c = 0; c < nu; ++c)
-            uk[c] = {u[nu * k + c], v[nu * k + c]};
     }
     __device__ __forceinline__ void store_x(int k, const double (&s)[nx]) const {
         if (lane == 0)
@@ -71,81 +81,82 @@ struct ScalarALProblem {
             for (int l = 0; l < nx; ++l)
                 X[k * nx + l] = s[l];
     }
-    __device__ __forceinline__ void store_x(int k, const dual (&s)[nx]) const {
-        if (lane == 0)
-#pragma unroll
-            for (int l = 0; l < nx; ++l) {
-                X[k * nx + l]  = s[l].v;
-                Xt[k * nx + l] = s[l].t;
-            }
-    }
     __device__ __forceinline__ void load_x(int k, double (&s)[nx]) const {
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             s[l] = X[k * nx + l];
     }
-    __device__ __forceinline__ void load_x(int k, dual (&s)[nx]) const {
-#pragma unroll
-        for (int l = 0; l < nx; ++l)
-            s[l] = {X[k * nx + l], Xt[k * nx + l]};
-    }
     __device__ __forceinline__ void store_yh(double *yh, int j, double v) const {
         if (lane == 0)
             yh[j] = v;
-    }
-    __device__ __forceinline__ void store_yh(double *yh, int j, dual v) const {
-        if (lane == 0) {
-            yh[j]            = v.v;
-            mvec(MV_YHT)[j]  = v.t;
-        }
     }
     __device__ __forceinline__ void load_yh(const double *yh, int k, double (&o)[nc]) const {
 #pragma unroll
         for (int i = 0; i < nc; ++i)
             o[i] = yh[nc * k + i];
     }
-    __device__ __forceinline__ void load_yh(const double *yh, int k, dual (&o)[nc]) const {
-#pragma unroll
-        for (int i = 0; i < nc; ++i)
-            o[i] = {yh[nc * k + i], mvec(MV_YHT)[nc * k + i]};
-    }
 
-    template <class T>
-    __device__ __forceinline__ void rk4(const T (&s)[nx], const T (&u)[nu], T (&xn)[nx]) const {
+    /// One RK4 step.  UNIFORM: the state's values are the same on every lane (Trig by trig_uniform);
+    /// t1 = Trig of s, which the caller usually needs as well.
+    template <bool UNIFORM, class T>
+    __device__ __forceinline__ void rk4(const typename M::template Trig<T> &t1, const T (&s)[nx], const T (&u)[nu],
+                                        T (&xn)[nx]) const {
         T k1[nx], k2[nx], k3[nx], k4[nx], w[nx];
-        M::fc(s, u, k1);
+        M::fc(t1, s, u, k1);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             w[l] = s[l] + 0.5 * (M::Ts * k1[l]);
-        M::fc(w, u, k2);
+        M::fc(M::template trig_of<UNIFORM>(w), w, u, k2);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             w[l] = s[l] + 0.5 * (M::Ts * k2[l]);
-        M::fc(w, u, k3);
+        M::fc(M::template trig_of<UNIFORM>(w), w, u, k3);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             w[l] = s[l] + M::Ts * k3[l];
-        M::fc(w, u, k4);
+        M::fc(M::template trig_of<UNIFORM>(w), w, u, k4);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             xn[l] = s[l] + M::c6 * (((k1[l] + 2.0 * k2[l]) + 2.0 * k3[l]) + k4[l]);
     }
-    template <class T>
-    __device__ __forceinline__ void rk4_adj(const T (&s)[nx], const T (&u)[nu], const T (&mu)[nx], T (&sbar)[nx],
-                                            T (&ubar)[nu]) const {
-        T k[nx], w2[nx], w3[nx], w4[nx];
-        M::fc(s, u, k);
+    /// Adjoint of one RK4 step (wave-uniform values).  The Trig of each substage state is evaluated
+    /// once and serves the recomputed forward pass and the adjoint.  WITH_XN: also returns the
+    /// step itself (x_next), whose tangent parts are a column of the stage Jacobian.
+    template <bool WITH_XN, class T>
+    __device__ __forceinline__ void rk4_adj(const typename M::template Trig<T> &t1, const T (&s)[nx],
+                                            const T (&u)[nu], const T (&mu)[nx], T (&sbar)[nx], T (&ubar)[nu],
+                                            T (&xn)[nx]) const {
+        T k[nx], w2[nx], w3[nx], w4[nx], ksum[nx];
+        M::fc(t1, s, u, k);
 #pragma unroll
-        for (int l = 0; l < nx; ++l)
+        for (int l = 0; l < nx; ++l) {
             w2[l] = s[l] + 0.5 * (M::Ts * k[l]);
-        M::fc(w2, u, k);
+            if (WITH_XN)
+                ksum[l] = k[l];
+        }
+        const auto t2 = M::trig_uniform(w2);
+        M::fc(t2, w2, u, k);
 #pragma unroll
-        for (int l = 0; l < nx; ++l)
+        for (int l = 0; l < nx; ++l) {
             w3[l] = s[l] + 0.5 * (M::Ts * k[l]);
-        M::fc(w3, u, k);
+            if (WITH_XN)
+                ksum[l] = ksum[l] + 2.0 * k[l];
+        }
+        const auto t3 = M::trig_uniform(w3);
+        M::fc(t3, w3, u, k);
 #pragma unroll
-        for (int l = 0; l < nx; ++l)
+        for (int l = 0; l < nx; ++l) {
             w4[l] = s[l] + M::Ts * k[l];
+            if (WITH_XN)
+                ksum[l] = ksum[l] + 2.0 * k[l];
+        }
+        const auto t4 = M::trig_uniform(w4);
+        if (WITH_XN) {
+            M::fc(t4, w4, u, k);
+#pragma unroll
+            for (int l = 0; l < nx; ++l)
+                xn[l] = s[l] + M::c6 * (ksum[l] + k[l]);
+        }
         T kb1[nx], kb2[nx], kb3[nx], kb4[nx], a[nx], ua[nu];
 #pragma unroll
         for (int l = 0; l < nx; ++l) {
@@ -156,13 +167,13 @@ struct ScalarALProblem {
             kb4[l]  = sg;
             sbar[l] = mu[l];
         }
-        M::fc_adj(w4, u, kb4, a, ubar);
+        M::fc_adj(t4, u, kb4, a, ubar);
 #pragma unroll
         for (int l = 0; l < nx; ++l) {
             sbar[l] = sbar[l] + a[l];
             kb3[l]  = kb3[l] + M::Ts * a[l];
         }
-        M::fc_adj(w3, u, kb3, a, ua);
+        M::fc_adj(t3, u, kb3, a, ua);
 #pragma unroll
         for (int c = 0; c < nu; ++c)
             ubar[c] = ubar[c] + ua[c];
@@ -171,7 +182,7 @@ struct ScalarALProblem {
             sbar[l] = sbar[l] + a[l];
             kb2[l]  = kb2[l] + 0.5 * (M::Ts * a[l]);
         }
-        M::fc_adj(w2, u, kb2, a, ua);
+        M::fc_adj(t2, u, kb2, a, ua);
 #pragma unroll
         for (int c = 0; c < nu; ++c)
             ubar[c] = ubar[c] + ua[c];
@@ -180,7 +191,7 @@ struct ScalarALProblem {
             sbar[l] = sbar[l] + a[l];
             kb1[l]  = kb1[l] + 0.5 * (M::Ts * a[l]);
         }
-        M::fc_adj(s, u, kb1, a, ua);
+        M::fc_adj(t1, u, kb1, a, ua);
 #pragma unroll
         for (int c = 0; c < nu; ++c)
             ubar[c] = ubar[c] + ua[c];
@@ -189,7 +200,7 @@ struct ScalarALProblem {
             sbar[l] = sbar[l] + a[l];
     }
 
-    /// Forward sweep: psi, trajectory, yhat.  T = dual carries the tangent v of u.
+    /// Forward sweep: psi, trajectory, yhat.
     template <class T>
     __device__ __forceinline__ T forward(const double *u, const double *v, double *yh) const {
         wave_sync();
@@ -201,7 +212,8 @@ struct ScalarALProblem {
         T accf = T{}, accal = T{};
         for (int k = 0; k <= N; ++k) {
             store_x(k, s);
-            M::constr(s, c);
+            const auto t1 = M::trig_uniform(s);
+            M::constr(t1, s, c);
 #pragma unroll
             for (int i = 0; i < nc; ++i) {
                 int j  = nc * k + i;
@@ -216,7 +228,7 @@ struct ScalarALProblem {
                 break;
             load_u(u, v, k, uk);
             accf = accf + M::stage_cost(s, uk);
-            rk4(s, uk, xn);
+            rk4<true>(t1, s, uk, xn);
 #pragma unroll
             for (int l = 0; l < nx; ++l)
                 s[l] = xn[l];
@@ -229,18 +241,19 @@ struct ScalarALProblem {
     template <class T, class OUT>
     __device__ __forceinline__ void reverse(const double *u, const double *v, const double *yh, OUT &&out) const {
         wave_sync();
-        T lam[nx], sbar[nx], ubar[nu], gu[nu], s[nx], uk[nu], yk[nc];
+        T lam[nx], sbar[nx], ubar[nu], gu[nu], s[nx], uk[nu], yk[nc], xn[nx];
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             lam[l] = T{};
         load_x(N, s);
         M::cost_grad(s, static_cast<const T *>(nullptr), lam, gu);
         load_yh(yh, N, yk);
-        M::constr_adj(s, yk, lam);
+        M::constr_adj(M::trig_uniform(s), s, yk, lam);
         for (int k = N - 1; k >= 0; --k) {
             load_x(k, s);
             load_u(u, v, k, uk);
-            rk4_adj(s, uk, lam, sbar, ubar);
+            const auto t1 = M::trig_uniform(s);
+            rk4_adj<false>(t1, s, uk, lam, sbar, ubar, xn);
 #pragma unroll
             for (int l = 0; l < nx; ++l)
                 lam[l] = sbar[l];
@@ -249,7 +262,7 @@ struct ScalarALProblem {
             for (int c = 0; c < nu; ++c)
                 out(nu * k + c, ubar[c] + gu[c]);
             load_yh(yh, k, yk);
-            M::constr_adj(s, yk, lam);
+            M::constr_adj(t1, s, yk, lam);
         }
         wave_sync();
     }
@@ -267,21 +280,231 @@ struct ScalarALProblem {
     __device__ __forceinline__ double eval_psi_xhat(const double *u, int yh_slot) const {
         return forward<double>(u, nullptr, mvec(MV_YH + yh_slot));
     }
-    /// grad psi at the point eval_psi_xhat() was last called at (trajectory and yhat still stored).
-    __device__ __forceinline__ void eval_grad_xhat(const double *u, double *grad, int yh_slot) const {
-        reverse<double>(u, nullptr, mvec(MV_YH + yh_slot), [&](int i, double g) {
-            if (lane == 0)
-                grad[i] = g;
-        });
+    /// yhat_k(x_k) on dual numbers (the value part repeats forward()'s arithmetic).
+    __device__ __forceinline__ void stage_multipliers(const typename M::template Trig<dual> &t1,
+                                                      const dual (&s)[nx], int k, dual (&yk)[nc]) const {
+        const double *y = mvec(MV_Y), *Sig = mvec(MV_SIG);
+        dual c[nc];
+        M::constr(t1, s, c);
+#pragma unroll
+        for (int i = 0; i < nc; ++i) {
+            int j     = nc * k + i;
+            dual zeta = c[i] + (y[j] / Sig[j]);
+            dual zhat = tmax(tmin(zeta, M::d_ub(i)), M::d_lb(i));
+            dual d    = zeta - zhat;
+            yk[i]     = Sig[j] * d;
+        }
     }
-    /// Hessian-vector product of psi at u: forward-over-reverse on dual numbers.
-    __device__ __forceinline__ void hess_prod(const double *u, const double *v, double *Hv) const {
-        double *yh = mvec(MV_E2); // scratch (e2 is rewritten at the end of the inner solve)
-        forward<dual>(u, v, yh);
-        reverse<dual>(u, v, yh, [&](int i, dual g) {
-            if (lane == 0)
-                Hv[i] = g.t;
-        });
+    /// grad psi at the point eval_psi_xhat() was last called at (trajectory still stored), and the
+    /// second-order tape there.  The adjoint sweep runs on dual numbers; lane d < nz seeds direction
+    /// e_d of (x_k, u_k), so its tangent parts are column d of J_k and H_k; the value parts are the
+    /// ordinary adjoint sweep on every lane.
+    __device__ __forceinline__ void eval_grad_xhat(const double *u, double *grad, int) const {
+        wave_sync();
+        const bool owner = lane < nz;
+        const int r      = lane & (ROW - 1);
+        double lam[nx];
+        {
+            dual s[nx], yk[nc], lt[nx], gu[nu];
+#pragma unroll
+            for (int l = 0; l < nx; ++l) {
+                s[l]  = {X[N * nx + l], lane == l ? 1.0 : 0.0};
+                lt[l] = dual{};
+            }
+            const auto tN = M::trig_uniform(s);
+            stage_multipliers(tN, s, N, yk);
+            M::cost_grad(s, static_cast<const dual *>(nullptr), lt, gu);
+            M::constr_adj(tN, s, yk, lt);
+            double *HN = tape + (size_t)N * STAGE;
+#pragma unroll
+            for (int l = 0; l < nx; ++l) {
+                if (lane < nx)
+                    HN[elem(r, l)] = lt[l].t;
+                lam[l] = lt[l].v;
+            }
+        }
+        for (int k = N - 1; k >= 0; --k) {
+            dual s[nx], uk[nu], xn[nx], yk[nc], mu[nx], sbar[nx], ubar[nu], gu[nu];
+#pragma unroll
+            for (int l = 0; l < nx; ++l) {
+                s[l]  = {X[k * nx + l], lane == l ? 1.0 : 0.0};
+                mu[l] = {lam[l], 0.0};
+            }
+#pragma unroll
+            for (int c = 0; c < nu; ++c)
+                uk[c] = {u[nu * k + c], lane == nx + c ? 1.0 : 0.0};
+            double *stage = tape + (size_t)k * STAGE;
+            const auto t1 = M::trig_uniform(s);
+            stage_multipliers(t1, s, k, yk);
+            rk4_adj<true>(t1, s, uk, mu, sbar, ubar, xn);
+            if (owner) {
+#pragma unroll
+                for (int i = 0; i < nx; ++i) {
+                    stage[elem(i, lane)]      = xn[i].t; // JT
+                    stage[BLOCK + elem(r, i)] = xn[i].t; // JC
+                }
+            }
+            M::cost_grad(s, uk, sbar, gu);
+            double *HC = stage + 2 * BLOCK;
+#pragma unroll
+            for (int c = 0; c < nu; ++c) {
+                dual g = ubar[c] + gu[c];
+                if (owner)
+                    HC[elem(r, nx + c)] = g.t;
+                if (lane == 0)
+                    grad[nu * k + c] = g.v;
+            }
+            M::constr_adj(t1, s, yk, sbar);
+#pragma unroll
+            for (int l = 0; l < nx; ++l) {
+                if (owner)
+                    HC[elem(r, l)] = sbar[l].t;
+                lam[l] = sbar[l].v;
+            }
+        }
+        wave_sync();
+        wait_vmem(); // the products read the tape back through global loads
+    }
+
+    /// The first CNT elements of this lane's row (lane & 15) of a tape block.  Only lanes 0..15
+    /// issue the loads (the other lanes own nothing and would fetch the same bytes again).
+    template <int CNT>
+    __device__ __forceinline__ void load_row(const double *block, double (&o)[CNT]) const {
+        const double2 *p = reinterpret_cast<const double2 *>(block) + (lane & (ROW - 1));
+        if (lane < ROW) {
+#pragma unroll
+            for (int i = 0; i < (CNT + 1) / 2; ++i) {
+                double2 t = p[i * ROW];
+                o[2 * i]  = t.x;
+                if (2 * i + 1 < CNT)
+                    o[2 * i + 1] = t.y;
+            }
+        }
+    }
+    /// Sum of products in four partial sums (term t goes to partial t mod 4, each an fma chain from
+    /// 0), combined as (p0 + p1) + (p2 + p3): four independent chains keep a lone wavefront's fp64
+    /// pipe busy (a dependent v_fma_f64 costs ~12 cycles, independent ones ~5).
+    struct Dot4 {
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        template <int T>
+        __device__ __forceinline__ double &part() {
+            return (T & 3) == 0 ? p0 : (T & 3) == 1 ? p1 : (T & 3) == 2 ? p2 : p3;
+        }
+        /// term T: a * b
+        template <int T>
+        __device__ __forceinline__ void add(double a, double b) {
+            part<T>() = __builtin_fma(a, b, part<T>());
+        }
+        /// term T: coef * (the value lane SRC of this 16-lane row holds in `own`), the broadcast
+        /// fused into the fma (v_fmac_f64 with a row_newbcast DPP source; the only DPP form the
+        /// fp64 ALU has).  FIRST: `own` was written by the instruction just before (DPP reads need
+        /// two wait states after a VALU write; inline asm is outside the compiler's hazard pass).
+        template <int T, int SRC, bool FIRST = false>
+        __device__ __forceinline__ void add_bcast(double coef, double own) {
+#ifdef PANTR_NO_DPP_FMAC // A/B build: the same sum with v_readlane broadcasts
+            part<T>() = __builtin_fma(read_lane<SRC>(own), coef, part<T>());
+            return;
+#endif
+            if (FIRST)
+                asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                             : "+v"(part<T>())
+                             : "v"(own), "v"(coef), "n"(SRC));
+            else
+                asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                             : "+v"(part<T>())
+                             : "v"(own), "v"(coef), "n"(SRC));
+        }
+        __device__ __forceinline__ double sum() const { return (p0 + p1) + (p2 + p3); }
+    };
+    /// acc.add_bcast<T0 + i, i>(coef[i], own) for i = 0..nx-1
+    template <int T0, int I = 0>
+    __device__ static __forceinline__ void add_bcast_all(Dot4 &acc, const double *coef, double own) {
+        if constexpr (I < nx) {
+            acc.template add_bcast<T0 + I, I, I == 0>(coef[I], own);
+            add_bcast_all<T0, I + 1>(acc, coef, own);
+        }
+    }
+    template <int T0, int CNT, int I = 0>
+    __device__ static __forceinline__ void add_all(Dot4 &acc, const double *a, const double *b) {
+        if constexpr (I < CNT) {
+            acc.template add<T0 + I>(a[I], b[I]);
+            add_all<T0, CNT, I + 1>(acc, a, b);
+        }
+    }
+    /// Hessian-vector product over the tape recorded by eval_grad_xhat(): x_t' = J z forward, then
+    /// [lam_t ; Hv_k] = H z + J' lam_t' backward; lane l (of the first 16-lane row) owns component l,
+    /// every component is one Dot4 over its terms in index order.  The quantity each stage hands to
+    /// the next (x_t, lam_t: one component per lane) enters the next stage's fmas as a DPP row
+    /// broadcast; everything else a stage needs does not depend on the previous stage and is
+    /// loaded ahead: v_k and the stored x_t from LDS, the tape rows of the next DEPTH stages from
+    /// HBM (DEPTH register sets, the stage loops unrolled by DEPTH so that no set is ever copied: a
+    /// copy would make the wavefront wait for the youngest load every stage).
+    static constexpr int DEPTH = 4;
+    __device__ __forceinline__ const double *stage_block(int k, int block) const {
+        k = k < 0 ? 0 : (k >= N ? N - 1 : k); // clamped: the prefetch runs past the ends
+        return tape + (size_t)k * STAGE + block * BLOCK;
+    }
+    __device__ __forceinline__ void hess_prod(const double *, const double *v, double *Hv) const {
+        wave_sync();
+        // ---- forward: lane i < nx owns x_t[i] ----
+        {
+            double xt = 0.0, A[DEPTH][nz];
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j)
+                load_row(stage_block(j, 0), A[j]);
+            for (int k0 = 0; k0 < N; k0 += DEPTH) {
+#pragma unroll
+                for (int j = 0; j < DEPTH; ++j) {
+                    const int k = k0 + j;
+                    if (k < N) {
+                        if (lane < nx)
+                            Xt[k * nx + lane] = xt; // for the backward sweep
+                        Dot4 acc;
+                        add_bcast_all<0>(acc, A[j], xt);
+                        add_all<nx, nu>(acc, A[j] + nx, v + nu * k);
+                        xt = acc.sum();
+                    }
+                    load_row(stage_block(k + DEPTH, 0), A[j]);
+                }
+            }
+            if (lane < nx)
+                Xt[N * nx + lane] = xt;
+            wave_sync();
+        }
+        // ---- backward: lane l < nz owns component l of [lam_t ; Hv_k] ----
+        double lt, C[DEPTH][nz], Bc[DEPTH][nx];
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            load_row(stage_block(N - 1 - j, 2), C[j]);
+            load_row(stage_block(N - 1 - j, 1), Bc[j]);
+        }
+        {
+            double HN[nx];
+            load_row(tape + (size_t)N * STAGE, HN);
+            Dot4 acc;
+            add_all<0, nx>(acc, HN, Xt + N * nx);
+            lt = acc.sum();
+        }
+        for (int k0 = N - 1; k0 >= 0; k0 -= DEPTH) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                const int k = k0 - j;
+                if (k >= 0) {
+                    Dot4 acc;
+                    add_all<0, nx>(acc, C[j], Xt + k * nx);
+                    add_all<nx, nu>(acc, C[j] + nx, v + nu * k);
+                    add_bcast_all<nz>(acc, Bc[j], lt);
+                    double w = acc.sum();
+                    if (lane >= nx && lane < nz)
+                        Hv[nu * k + (lane - nx)] = w;
+                    lt = w;
+                }
+                load_row(stage_block(k - DEPTH, 2), C[j]);
+                load_row(stage_block(k - DEPTH, 1), Bc[j]);
+            }
+        }
+        wait_vmem(); // the clamped prefetches past the first stage
+        wave_sync();
     }
     /// err_z = Sigma^{-1} (yhat - y) into e2, then y <- yhat.
     __device__ __forceinline__ void update_multipliers(int yh_slot) const {
@@ -396,6 +619,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
     pb.mv = lds + (size_t)NUM_VEC * a.npad;
     pb.X  = pb.mv + (size_t)PB::MV_COUNT * a.mpad;
     pb.Xt = pb.X + (size_t)(a.N + 1) * M::nx;
+    pb.tape = a.ws + (size_t)inst * PB::workspace_doubles(a.N);
 #pragma unroll
     for (int l = 0; l < M::nx; ++l)
         pb.x0[l] = a.x0[(size_t)inst * M::nx + l];
@@ -483,10 +707,12 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
         st.status       = status == Busy ? (int)MaxIter : status;
         st.iterations   = total_inner;
         st.eps          = r.eps;
+#ifndef PANTR_PHASE_TIMING
         st.final_gamma  = r.gamma;
         st.final_psi    = r.psi;
         st.final_fbe    = r.fbe;
         st.final_radius = r.radius;
+#endif
         st.elapsed_s    = (double)(wall_clock64() - t_start) * 1e-8;
         st.outer_iterations           = outer;
         st.inner_convergence_failures = failures;
@@ -506,7 +732,7 @@ namespace pantr {
 enum AlmEvalMode : int32_t { ALM_EVAL_PSI_GRAD = 0, ALM_EVAL_HESS_PROD = 1 };
 
 struct AlmEvalArgs {
-    int32_t B, N, n, npad, nj, m, mpad, mj, mode, pad0;
+    int32_t B, N, n, npad, nj, m, mpad, mj, mode, reps; ///< reps: development aid (timing), normally 1
     const double *x0;  ///< [B][nx]
     const double *u;   ///< [B][n]
     const double *v;   ///< [B][n] (HESS_PROD)
@@ -515,6 +741,7 @@ struct AlmEvalArgs {
     double *out_s;     ///< [B] psi
     double *out_v;     ///< [B][n] grad | Hv
     double *out_m;     ///< [B][m] yhat
+    double *ws;        ///< [B][ScalarALProblem::workspace_doubles(N)]
 };
 
 template <class M>
@@ -530,6 +757,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
     pb.mv = lds + (size_t)NUM_VEC * a.npad;
     pb.X  = pb.mv + (size_t)PB::MV_COUNT * a.mpad;
     pb.Xt = pb.X + (size_t)(a.N + 1) * M::nx;
+    pb.tape = a.ws + (size_t)inst * PB::workspace_doubles(a.N);
 #pragma unroll
     for (int l = 0; l < M::nx; ++l)
         pb.x0[l] = a.x0[(size_t)inst * M::nx + l];
@@ -555,7 +783,10 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
         for (int j = lane; j < a.m; j += WAVE)
             a.out_m[(size_t)inst * a.m + j] = pb.mvec(PB::MV_YH)[j];
     } else {
-        pb.hess_prod(u, v, o);
+        pb.eval_psi_xhat(u, 0);
+        pb.eval_grad_xhat(u, pb.vec(3), 0); // records the tape at u
+        for (int rep = 0; rep < a.reps; ++rep)
+            pb.hess_prod(u, v, o);
     }
     wave_sync();
     for (int i = lane; i < a.n; i += WAVE)
@@ -576,7 +807,7 @@ __global__ void pantr_scalar_simulate_kernel(int B, const double *x, const doubl
         s[l] = x[(size_t)inst * M::nx + l];
     for (int c = 0; c < M::nu; ++c)
         uk[c] = u[(size_t)inst * u_stride + c];
-    pb.rk4(s, uk, r);
+    pb.template rk4<false>(M::trig(s), s, uk, r); // one instance per lane: no wave-uniform shortcuts
     for (int l = 0; l < M::nx; ++l)
         xn[(size_t)inst * M::nx + l] = r[l];
 }

@@ -163,7 +163,7 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
         AlmSolveArgs a{};
         a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj; a.m = b->m; a.mpad = b->mpad; a.mj = b->mj;
         a.trace_cap = b->trace_cap; a.trace_instances = b->trace_instances;
-        a.x0 = d_x0; a.u = d_u; a.y = d_y; a.stats = d_stats;
+        a.x0 = d_x0; a.u = d_u; a.y = d_y; a.ws = b->d_ws; a.stats = d_stats;
         a.trace = b->trace_instances > 0 ? b->d_trace : nullptr;
         a.order = b->have_order ? b->d_order : nullptr;
         a.prm   = to_kernel_params(b->opts, b->m);
@@ -319,7 +319,8 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
     b->maxB = max_instances;
     size_t static_lds = 0;
     if (b->al()) {
-        b->ws_per_instance = 0; // trajectories and multipliers live in LDS
+        // trajectories and multipliers live in LDS; the second-order tape streams from HBM
+        b->ws_per_instance = ScalarALProblem<QuadModelT<false>>::workspace_doubles(b->N);
         b->lds_bytes       = ScalarALProblem<QuadModelT<false>>::lds_doubles(b->N, b->npad, b->mpad) * sizeof(double);
     } else {
         b->ws_per_instance = WaveProblem<ChainModel>::workspace_doubles(b->N);
@@ -650,7 +651,7 @@ static int run_al_eval(pantr_batch *b, int32_t B, int mode, const double *x0, co
     AlmEvalArgs a{};
     a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj; a.m = b->m; a.mpad = b->mpad; a.mj = b->mj;
     a.mode = mode; a.x0 = b->d_x0; a.u = b->d_u; a.v = v ? b->d_v : nullptr; a.y = b->d_y; a.Sig = b->d_sig;
-    a.out_s = b->d_s; a.out_v = b->d_o1; a.out_m = b->d_om;
+    a.out_s = b->d_s; a.out_v = b->d_o1; a.out_m = b->d_om; a.ws = b->d_ws; a.reps = g_eval_reps;
     with_quad_model(b, [&](auto model) {
         using M = decltype(model);
         hipLaunchKernelGGL(pantr_alm_eval_kernel<M>, dim3(B), dim3(WAVE), b->lds_bytes, 0, a);

@@ -327,6 +327,23 @@ __device__ __forceinline__ void swap_iter(IterateRef &a, IterateRef &b) {
 
 __device__ __forceinline__ bool is_finite(double v) { return fabs(v) < __builtin_huge_val(); }
 
+// Profiling build (-DPANTR_PHASE_TIMING): the stats fields final_gamma / final_psi / final_fbe /
+// final_radius return the seconds spent in hess_prod / psi_grad(candidate) / psi(xhat) /
+// grad_L(xhat) instead of their documented values (scripts/phase_timing.sh).
+#ifdef PANTR_PHASE_TIMING
+#define PANTR_PHASE(field, ...)                                                                    \
+    do {                                                                                           \
+        long long t0_ = wall_clock64();                                                            \
+        __VA_ARGS__;                                                                               \
+        st.field += (double)(wall_clock64() - t0_) * 1e-8;                                         \
+    } while (0)
+#else
+#define PANTR_PHASE(field, ...)                                                                    \
+    do {                                                                                           \
+        __VA_ARGS__;                                                                               \
+    } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------
 // The PANTR inner solver, generic over the wave-cooperative problem `PB`
 // ---------------------------------------------------------------------------------------
@@ -413,7 +430,8 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
             swap_iter(curr, prox);
         // ---- psi(xhat) + quadratic upper bound backtracking on the new current iterate ----
         while (true) {
-            curr.psi_xh = pb.eval_psi_xhat(XH_(curr), curr.yh); // keeps the trajectory (and yhat) for grad_L(xhat)
+            // keeps the trajectory (and yhat) for grad_L(xhat)
+            PANTR_PHASE(final_fbe, curr.psi_xh = pb.eval_psi_xhat(XH_(curr), curr.yh));
             ++st.n_psi;
             double margin = (1.0 + fabs(curr.psi_x)) * P.quadratic_upperbound_tolerance_factor;
             bool violated = curr.psi_xh > ((curr.psi_x + curr.gradTp) + (0.5 * curr.L) * curr.pTp) + margin;
@@ -471,7 +489,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
         prox.psi_x = curr.psi_xh;
         // grad_L(xhat): xbar = xhat_k was the last point psi was evaluated at (trajectory X is still
         // in the workspace), so only the adjoint sweep runs; it records the tape at xbar
-        pb.eval_grad_xhat(X_(prox), G_(prox), curr.yh);
+        PANTR_PHASE(final_radius, pb.eval_grad_xhat(X_(prox), G_(prox), curr.yh));
         ++st.n_grad_L;
         prox.gamma = curr.gamma;
         prox.L     = curr.L;
@@ -531,7 +549,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                     vin       = d;
                 }
                 // the one Hessian-vector product site: work = H(xbar) * vin (tape replay)
-                pb.hess_prod(X_(prox), vin, work);
+                PANTR_PHASE(final_gamma, pb.hess_prod(X_(prox), vin, work));
                 ++st.n_hess_psi_prod;
                 if (state == KTERM) {
                     for (int j = 0; j < nj; ++j) {
@@ -655,7 +673,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                     if (i < n)
                         X_(cand)[i] = X_(prox)[i] + q[i];
                 }
-                cand.psi_x = pb.eval_psi_grad(X_(cand), G_(cand));
+                PANTR_PHASE(final_psi, cand.psi_x = pb.eval_psi_grad(X_(cand), G_(cand)));
                 ++st.n_psi_grad_psi;
                 cand.gamma = prox.gamma;
                 cand.L     = prox.L;
@@ -745,10 +763,12 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
         st.status       = r.status;
         st.iterations   = r.iterations;
         st.eps          = r.eps;
+#ifndef PANTR_PHASE_TIMING
         st.final_gamma  = r.gamma;
         st.final_psi    = r.psi;
         st.final_fbe    = r.fbe;
         st.final_radius = r.radius;
+#endif
         st.elapsed_s    = (double)(wall_clock64() - t_start) * 1e-8;
         st.outer_iterations = 1;
         st.inner_convergence_failures = r.status == Converged ? 0 : 1;

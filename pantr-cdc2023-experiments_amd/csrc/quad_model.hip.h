@@ -4,11 +4,13 @@
 // problem generated from the Python models, problems/generate_problem.py:26-61):
 //   quadcopter ............ python/alpaqa_mpc_benchmarks/problems/quadcopter.py:6-112
 //   realistic_quadcopter .. python/alpaqa_mpc_benchmarks/problems/realistic_quadcopter.py:6-118
-// With nine states there is no lane-level parallelism worth a cross-lane exchange: every lane
-// of the wavefront evaluates the same scalar stage (no shuffles); the decision-vector algebra of
-// the solver is still spread over the 64 lanes.  First derivatives are hand-written adjoints,
-// second-order information comes from running the same templates on dual numbers
-// (forward-over-reverse).  sin/cos is wave_math's deterministic routine.
+// The nine-state stage is evaluated in scalar form by every lane of the wavefront (the
+// decision-vector algebra of the solver is still spread over the 64 lanes).  Its expensive part is
+// sin/cos of the three angles (wave_math's deterministic routine): with a wave-uniform state,
+// trig_uniform() evaluates one angle per lane and broadcasts (v_readlane), and callers hand the
+// Trig of a state to every function that needs it instead of recomputing it.  First derivatives
+// are hand-written adjoints; second-order information comes from running the same templates on
+// dual numbers whose tangent parts differ per lane (pantr_alm.hip.h).
 #pragma once
 #include "wave_math.hip.h"
 
@@ -42,6 +44,7 @@ struct QuadModelT {
     struct Trig {
         T s0, c0, s1, c1, s2, c2;
     };
+    /// Every lane holds its own state (one instance per lane).
     template <class T>
     __device__ static __forceinline__ Trig<T> trig(const T *s) {
         Trig<T> t;
@@ -50,11 +53,35 @@ struct QuadModelT {
         sincos_t(s[8], t.s2, t.c2);
         return t;
     }
+    /// The state's values are the same on all 64 lanes (all active): lane j < 3 evaluates angle j,
+    /// the six results are broadcast.  Same routine, same inputs: bit-identical to trig().
+    __device__ static __forceinline__ Trig<double> trig_uniform(double a0, double a1, double a2) {
+        const int lane = threadIdx.x & 63;
+        double sv, cv;
+        sincos_det(lane == 1 ? a1 : lane == 2 ? a2 : a0, sv, cv);
+        return {read_lane<0>(sv), read_lane<0>(cv), read_lane<1>(sv), read_lane<1>(cv), read_lane<2>(sv),
+                read_lane<2>(cv)};
+    }
+    __device__ static __forceinline__ Trig<double> trig_uniform(const double *s) {
+        return trig_uniform(s[6], s[7], s[8]);
+    }
+    /// Dual numbers with wave-uniform values and per-lane tangents.
+    __device__ static __forceinline__ Trig<dual> trig_uniform(const dual *s) {
+        const Trig<double> v = trig_uniform(s[6].v, s[7].v, s[8].v);
+        return {{v.s0, v.c0 * s[6].t}, {v.c0, -(v.s0 * s[6].t)}, {v.s1, v.c1 * s[7].t},
+                {v.c1, -(v.s1 * s[7].t)}, {v.s2, v.c2 * s[8].t}, {v.c2, -(v.s2 * s[8].t)}};
+    }
+    template <bool UNIFORM, class T>
+    __device__ static __forceinline__ Trig<T> trig_of(const T *s) {
+        if constexpr (UNIFORM)
+            return trig_uniform(s);
+        else
+            return trig(s);
+    }
 
     /// f_c(state, input) (quadcopter.py:30-46, realistic_quadcopter.py:30-50)
     template <class T>
-    __device__ static __forceinline__ void fc(const T *s, const T *u, T *ds) {
-        const Trig<T> t = trig(s);
+    __device__ static __forceinline__ void fc(const Trig<T> &t, const T *s, const T *u, T *ds) {
         T r0, r1, r2_;
         if (!REALISTIC) { // (cr,sr)=(c0,s0) roll, (cp,sp)=(c1,s1) pitch, (cy,sy)=(c2,s2) yaw
             r0  = ((t.c2 * t.s1) * t.c0) + (t.s2 * t.s0);
@@ -87,8 +114,7 @@ struct QuadModelT {
 
     /// Adjoint of f_c: sb = (df/ds)' kb, ub = (df/du)' kb.
     template <class T>
-    __device__ static __forceinline__ void fc_adj(const T *s, const T *u, const T *kb, T *sb, T *ub) {
-        const Trig<T> t = trig(s);
+    __device__ static __forceinline__ void fc_adj(const Trig<T> &t, const T *u, const T *kb, T *sb, T *ub) {
         const T at = u[0];
         T r0, r1, r2_, dr0[3], dr1[3], dr2[3]; // d r_i / d s[6+j]
         if (!REALISTIC) {
@@ -187,23 +213,17 @@ struct QuadModelT {
 
     /// c(x) (quadcopter.py:62-71)
     template <class T>
-    __device__ static __forceinline__ void constr(const T *s, T *c) {
-        T s0, c0, s1, c1;
-        sincos_t(s[6], s0, c0);
-        sincos_t(s[7], s1, c1);
+    __device__ static __forceinline__ void constr(const Trig<T> &t, const T *s, T *c) {
         c[0] = s[6];
         c[1] = s[7];
-        c[2] = c0 * c1;
+        c[2] = t.c0 * t.c1;
         c[3] = (r2 - (s[0] * s[0])) - (s[1] * s[1]);
     }
     /// sb += (dc/dx)' yb
     template <class T>
-    __device__ static __forceinline__ void constr_adj(const T *s, const T *yb, T *sb) {
-        T s0, c0, s1, c1;
-        sincos_t(s[6], s0, c0);
-        sincos_t(s[7], s1, c1);
-        sb[6] = sb[6] + (yb[0] - ((s0 * c1) * yb[2]));
-        sb[7] = sb[7] + (yb[1] - ((c0 * s1) * yb[2]));
+    __device__ static __forceinline__ void constr_adj(const Trig<T> &t, const T *s, const T *yb, T *sb) {
+        sb[6] = sb[6] + (yb[0] - ((t.s0 * t.c1) * yb[2]));
+        sb[7] = sb[7] + (yb[1] - ((t.c0 * t.s1) * yb[2]));
         sb[0] = sb[0] - ((2.0 * s[0]) * yb[3]);
         sb[1] = sb[1] - ((2.0 * s[1]) * yb[3]);
     }

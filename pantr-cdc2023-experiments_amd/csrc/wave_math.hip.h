@@ -176,6 +176,14 @@ __device__ __forceinline__ void wait_vmem() {
 #endif
 }
 
+/// The value lane SRC holds, as a wave-uniform (scalar-register) double: two v_readlane_b32.
+template <int SRC>
+__device__ __forceinline__ double read_lane(double v) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
+    return __hiloint2double(hi, lo);
+}
+
 /// Move a wave-uniform double into scalar registers (lets the compiler branch on SCC).
 __device__ __forceinline__ double uniform(double v) {
     int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-phase solve time from a -DPANTR_PHASE_TIMING build (run through scripts/phase_timing.sh)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pantr-cdc2023-experiments_amd"))
+import pantr_amd as pa
+from pantr_amd import workloads
+
+
+def report(name, st):
+    st = st.ravel()
+    el = st["elapsed_s"].sum()
+    it = st["iterations"].sum()
+    print(f"{name}: {len(st)} solves, mean {el/len(st)*1e3:.2f} ms, {it/len(st):.1f} iterations, "
+          f"{st['n_hess_psi_prod'].sum()/len(st):.1f} Hv")
+    rest = el
+    for label, field, cnt in (("hess_prod", "final_gamma", "n_hess_psi_prod"), ("psi_grad(cand)", "final_psi", "n_psi_grad_psi"),
+                              ("psi(xhat)", "final_fbe", "n_psi"), ("grad_L(xhat)+tape", "final_radius", "n_grad_L")):
+        t, c = st[field].sum(), st[cnt].sum()
+        rest -= t
+        print(f"   {label:18s} {100*t/el:5.1f} %   {t/max(c,1)*1e6:8.1f} us per call ({c/len(st):.1f} calls)")
+    print(f"   {'everything else':18s} {100*rest/el:5.1f} %   {rest/max(it,1)*1e6:8.1f} us per iteration")
+
+
+which = sys.argv[1:] or ["hanging_chain", "quadcopter", "realistic_quadcopter"]
+if "hanging_chain" in which:
+    d = np.load(os.path.join(ROOT, "tests/golden/mpc_hanging_chain_N60_warm300.npz"))
+    x0 = np.vstack([d["x0"], d["x0"]]); u0 = np.vstack([d["guess"], np.zeros_like(d["guess"])])
+    b = pa.PantrBatch("hanging_chain", 60, len(x0), opts=pa.DODO_PANTR_OPTS + ("alm.max_time=3s",))
+    report("hanging_chain N=60 replay (600)", b.solve(x0, u0)[1])
+    b.close()
+for problem in which:
+    if problem == "hanging_chain":
+        continue
+    for N in (20, 60):
+        task = [t for t in workloads.dodo_pantr_tasks(problem) if t["horizon"] == N and not t["warm"]][0]
+        b = pa.PantrBatch(problem, N, 1, opts=tuple(o for o in task["argv"][3:] if o.startswith(("solver.", "alm.", "dir.", "accel."))))
+        _, _, st = b.mpc(60, False, np.zeros((1, 4)), num_dist=0)
+        report(f"{problem} N={N} cold closed loop", st)
+        b.close()

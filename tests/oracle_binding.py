@@ -108,6 +108,7 @@ def lib():
         L.oracle_quad_psi_grad.argtypes = [C.c_int, C.c_int, _pd, _pd, _pd, _pd, _pd, _pd]
         L.oracle_quad_psi_grad.restype = _dbl
         L.oracle_quad_hess_prod.argtypes = [C.c_int, C.c_int, _pd, _pd, _pd, _pd, _pd, _pd]
+        L.oracle_quad_hess_prod_dual.argtypes = [C.c_int, C.c_int, _pd, _pd, _pd, _pd, _pd, _pd]
         L.oracle_quad_solve.argtypes = [C.c_int, C.c_int, C.POINTER(OracleParams), _pd, _pd, _pd,
                                         C.POINTER(OracleStats)]
         L.oracle_quad_solve.restype = C.c_int
@@ -286,9 +287,12 @@ def quad_psi_grad(problem, N, x0, y, Sig, u):
     return psi, grad, yhat
 
 
-def quad_hess_prod(problem, N, x0, y, Sig, u, v):
+def quad_hess_prod(problem, N, x0, y, Sig, u, v, dual=False):
+    """Hv over the stage-matrix tape (the product the solvers use); dual=True: dual numbers through
+    the whole horizon (independent check)."""
     Hv = np.zeros(4 * N)
-    lib().oracle_quad_hess_prod(QUAD[problem], N, *[np.ascontiguousarray(a, float) for a in (x0, y, Sig, u, v)], Hv)
+    f = lib().oracle_quad_hess_prod_dual if dual else lib().oracle_quad_hess_prod
+    f(QUAD[problem], N, *[np.ascontiguousarray(a, float) for a in (x0, y, Sig, u, v)], Hv)
     return Hv
 
 

@@ -305,6 +305,10 @@ def test_quadcopter_dynamics_and_derivatives(rng, problem):
           ob.quad_psi_grad(problem, N, x0, y, Sig, u - h * v)[1]) / (2 * h)
     assert np.abs(Hv - fd).max() <= 1e-6 * np.abs(Hv).max()
     assert abs(w @ Hv - v @ Hw) <= 1e-11 * abs(w @ Hv)
+    # the stage-matrix tape against dual numbers through the whole horizon
+    Hd = ob.quad_hess_prod(problem, N, x0, y, Sig, u, v, dual=True)
+    assert np.abs(Hv - Hd).max() <= 1e-12 * np.abs(Hd).max()
+    assert np.array_equal(ob.quad_hess_prod(problem, N, x0, y, Sig, u, np.zeros(n)), np.zeros(n))
 
 
 @pytest.mark.parametrize("problem,N", [("quadcopter", 12), ("realistic_quadcopter", 20)])
