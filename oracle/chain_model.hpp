@@ -622,9 +622,9 @@ struct SingleShooting {
     /// grad_L(x, y) with m = 0 is the gradient of f (formulation.hpp:98-99).
     /// (PANTR evaluates it at the point its Hessian-vector products follow, so this is where
     /// the second-order tape is recorded, as in the kernels.)
-    void eval_grad_L(const double *u, double *grad) const {
+    void eval_grad_L(const double *u, double *grad, bool record = true) const {
         ++cnt.grad_L;
-        psi_grad_impl(u, grad, /*record=*/true);
+        psi_grad_impl(u, grad, record);
     }
 
     /// Hv = d/du (grad psi(u)^T v): forward-over-reverse with dual numbers

@@ -4,7 +4,7 @@
 // chain_model.hpp / pantr_oracle.hpp, plus the closed-loop MPC experiment of
 // drivers/mpc-driver.cpp:123-210 and a threaded batch driver used as the CPU
 // baseline ("port") by bench.py.
-#include "pantr_oracle.hpp"
+#include "panoc_oracle.hpp"
 #include "quad_models.hpp"
 #include <atomic>
 #include <thread>
@@ -27,9 +27,15 @@ struct OracleParams {
     double alm_tolerance, alm_max_time_s;
     double alm_dual_tolerance, alm_initial_penalty, alm_penalty_update_factor, alm_initial_tolerance,
         alm_tolerance_update_factor;
+    // solver.* of PANOCParams that PANTRParams lacks, accel.* of LBFGSParams (method = panoc, strucpanoc)
+    double min_linesearch_coefficient, linesearch_strictness_factor, linesearch_tolerance_factor,
+        lbfgs_min_div_fac, lbfgs_min_abs_s, cbfgs_alpha, cbfgs_eps;
     int32_t max_iter, stop_crit, max_no_progress, disable_acceleration;
-    int32_t alm_max_iter, pad0;
+    int32_t alm_max_iter;
+    int32_t method; ///< 0 = pantr, 1 = panoc, 2 = strucpanoc (mpc-driver.cpp:364-384)
+    int32_t force_linesearch, lbfgs_memory, lbfgs_force_pos_def, pad0;
 };
+enum Method : int32_t { MethodPANTR = 0, MethodPANOC = 1, MethodStrucPANOC = 2 };
 
 struct OracleStats {
     double eps, final_gamma, final_psi, final_fbe, final_radius, elapsed_s;
@@ -37,6 +43,9 @@ struct OracleStats {
     int32_t n_psi, n_grad_psi, n_psi_grad_psi, n_grad_L, n_hess_psi_prod, n_prox_grad_step;
     int32_t outer_iterations, inner_convergence_failures;
     double delta, penalty_norm;
+    int32_t linesearch_failures, linesearch_backtracks, lbfgs_failures, lbfgs_rejected, tau_1_accepted,
+        count_tau;
+    double sum_tau;
 };
 
 /// Defaults = alpaqa defaults + mpc-driver.cpp:51-53,109-111.
@@ -65,6 +74,15 @@ void oracle_default_params(OracleParams *p) {
     p->alm_initial_tolerance = alm.initial_tolerance;
     p->alm_tolerance_update_factor = alm.tolerance_update_factor;
     p->alm_max_iter = alm.max_iter; p->pad0 = 0;
+    PANOCParams pn;
+    LBFGSParams lb;
+    p->min_linesearch_coefficient = pn.min_linesearch_coefficient;
+    p->linesearch_strictness_factor = pn.linesearch_strictness_factor;
+    p->linesearch_tolerance_factor = pn.linesearch_tolerance_factor;
+    p->lbfgs_min_div_fac = lb.min_div_fac; p->lbfgs_min_abs_s = lb.min_abs_s;
+    p->cbfgs_alpha = lb.cbfgs_alpha; p->cbfgs_eps = lb.cbfgs_eps;
+    p->method = MethodPANTR; p->force_linesearch = pn.force_linesearch; p->lbfgs_memory = lb.memory;
+    p->lbfgs_force_pos_def = lb.force_pos_def;
     p->max_iter = 50000;          // mpc-driver.cpp:51
     p->stop_crit = FPRNorm;       // mpc-driver.cpp:53
     p->max_no_progress = a.max_no_progress;
@@ -90,6 +108,13 @@ void oracle_dodo_params(OracleParams *p) {
     p->ratio_threshold_good = 0.5;
     p->hessian_vec_factor = 1;
     p->tol_scale = 1e-2;
+}
+/// dodo.py:34-40: the comparators' option sets (OPT_ALM + accel.memory=50 [+ dir.hessian_vec=0]).
+void oracle_dodo_params_method(OracleParams *p, int method) {
+    oracle_dodo_params(p);
+    p->method = method;
+    if (method != MethodPANTR)
+        p->lbfgs_memory = 50;
 }
 
 static ALMParams make_alm(const OracleParams &p) {
@@ -124,6 +149,33 @@ static PANTRSolver<P> make_solver(const OracleParams &p) {
     s.accel_params.tol_max = p.tol_max; s.accel_params.max_iter_factor = p.max_iter_factor;
     return s;
 }
+template <class P, class Dir>
+static PANOCSolver<P, Dir> make_panoc(const OracleParams &p) {
+    PANOCSolver<P, Dir> s;
+    auto &a = s.params;
+    a.L_0 = p.L_0; a.lip_eps = p.lip_eps; a.lip_delta = p.lip_delta;
+    a.Lgamma_factor = p.Lgamma_factor; a.max_time_s = p.max_time_s;
+    a.L_min = p.L_min; a.L_max = p.L_max;
+    a.quadratic_upperbound_tolerance_factor = p.quadratic_upperbound_tolerance_factor;
+    a.max_iter = p.max_iter; a.stop_crit = p.stop_crit; a.max_no_progress = p.max_no_progress;
+    a.min_linesearch_coefficient = p.min_linesearch_coefficient;
+    a.linesearch_strictness_factor = p.linesearch_strictness_factor;
+    a.linesearch_tolerance_factor = p.linesearch_tolerance_factor;
+    a.force_linesearch = p.force_linesearch;
+    auto &l = s.direction.lbfgs.params;
+    l.memory = p.lbfgs_memory; l.min_div_fac = p.lbfgs_min_div_fac; l.min_abs_s = p.lbfgs_min_abs_s;
+    l.cbfgs_alpha = p.cbfgs_alpha; l.cbfgs_eps = p.cbfgs_eps; l.force_pos_def = p.lbfgs_force_pos_def;
+    return s;
+}
+/// f(inner solver) with the solver `method` names (mpc-driver.cpp:364-384).
+template <class P, class F>
+static auto with_solver(const OracleParams &p, F &&f) {
+    if (p.method == MethodPANOC)
+        return f(make_panoc<P, LBFGSDirection>(p));
+    if (p.method == MethodStrucPANOC)
+        return f(make_panoc<P, StructuredLBFGSDirection>(p));
+    return f(make_solver<P>(p));
+}
 } // extern "C++"
 
 static void export_stats(const Stats &s, OracleStats *o) {
@@ -137,6 +189,9 @@ static void export_stats(const Stats &s, OracleStats *o) {
     o->n_prox_grad_step = (int32_t)s.n_prox_grad_step;
     o->outer_iterations = s.outer_iterations; o->inner_convergence_failures = s.inner_convergence_failures;
     o->delta = s.delta; o->penalty_norm = s.penalty_norm;
+    o->linesearch_failures = s.linesearch_failures; o->linesearch_backtracks = s.linesearch_backtracks;
+    o->lbfgs_failures = s.lbfgs_failures; o->lbfgs_rejected = s.lbfgs_rejected;
+    o->tau_1_accepted = s.tau_1_accepted; o->count_tau = s.count_tau; o->sum_tau = s.sum_tau;
 }
 
 // ---- problem functions --------------------------------------------------------------------
@@ -190,6 +245,28 @@ int oracle_chain_solve(int N, const OracleParams *prm, const double *x0, double 
                        OracleStats *st, double *trace /*cap x 11*/, int trace_cap, int *trace_len) {
     Prob p(N);
     std::copy(x0, x0 + Chain::nx, p.x0.begin());
+    if (prm->method != MethodPANTR) { // trace columns: eps psi |p| gamma tau fbe lbfgs-pairs
+        std::vector<PanocTraceRow> ptr;
+        Stats s = with_solver<Prob>(*prm, [&](auto solver) {
+            if constexpr (requires { solver.direction; })
+                if (trace)
+                    solver.trace = &ptr;
+            return solver(p, prm->alm_tolerance, prm->alm_max_time_s, true, u);
+        });
+        export_stats(s, st);
+        if (trace) {
+            int len = std::min<int>((int)ptr.size(), trace_cap);
+            for (int i = 0; i < len; ++i) {
+                const PanocTraceRow &r = ptr[i];
+                double *o = trace + 11 * i;
+                std::fill(o, o + 11, NaN);
+                o[0] = r.eps; o[1] = r.psi; o[2] = r.pnorm; o[3] = r.gamma; o[4] = r.tau; o[5] = r.fbe;
+                o[6] = r.lbfgs_idx;
+            }
+            *trace_len = (int)ptr.size();
+        }
+        return s.status;
+    }
     auto solver = make_solver(*prm);
     std::vector<TraceRow> tr;
     if (trace)
@@ -216,13 +293,15 @@ void oracle_chain_solve_batch(int N, const OracleParams *prm, int B, const doubl
     const int n = Chain::nu * N;
     std::atomic<int> next{0};
     auto worker = [&] {
-        auto solver = make_solver(*prm);
-        for (int b; (b = next.fetch_add(1)) < B;) {
-            Prob p(N);
-            std::copy(x0s + b * Chain::nx, x0s + (b + 1) * Chain::nx, p.x0.begin());
-            Stats s = solver(p, prm->alm_tolerance, prm->alm_max_time_s, true, us + (size_t)b * n);
-            export_stats(s, &stats[b]);
-        }
+        with_solver<Prob>(*prm, [&](auto solver) {
+            for (int b; (b = next.fetch_add(1)) < B;) {
+                Prob p(N);
+                std::copy(x0s + b * Chain::nx, x0s + (b + 1) * Chain::nx, p.x0.begin());
+                Stats s = solver(p, prm->alm_tolerance, prm->alm_max_time_s, true, us + (size_t)b * n);
+                export_stats(s, &stats[b]);
+            }
+            return 0;
+        });
     };
     std::vector<std::thread> th;
     for (int t = 1; t < nthreads; ++t)
@@ -240,7 +319,7 @@ void oracle_chain_mpc(int N, const OracleParams *prm, int num_sim, int warm, int
                       OracleStats *stats) {
     const int nx = Chain::nx, nu = Chain::nu, n = nu * N;
     Prob p(N);
-    auto solver = make_solver(*prm);
+    with_solver<Prob>(*prm, [&](auto solver) {
     std::vector<double> x0(nx), xn(nx), u(n, 0.0), u_initial(n, 0.0); // hanging_chain.cpp:135
     Chain::initial_state(x0.data());
     for (int i = 0; i < num_dist; ++i) { // mpc-driver.cpp:153-154
@@ -266,6 +345,8 @@ void oracle_chain_mpc(int N, const OracleParams *prm, int num_sim, int warm, int
         x0 = xn;
     }
     std::copy(x0.begin(), x0.end(), states + (size_t)num_sim * nx);
+    return 0;
+    });
 }
 
 // ---- quadcopter problems (general constraints, ALM) -------------------------------------------
@@ -334,8 +415,7 @@ int oracle_quad_solve(int realistic, int N, const OracleParams *prm, const doubl
     return with_quad(realistic, N, [&](auto &p) {
         using P = std::decay_t<decltype(p)>;
         std::copy(x0, x0 + 9, p.x0.begin());
-        auto solver = make_solver<P>(*prm);
-        Stats s     = alm_solve(make_alm(*prm), solver, p, u, y);
+        Stats s = with_solver<P>(*prm, [&](auto solver) { return alm_solve(make_alm(*prm), solver, p, u, y); });
         export_stats(s, st);
         return s.status;
     });
@@ -346,8 +426,8 @@ void oracle_quad_mpc(int realistic, int N, const OracleParams *prm, int num_sim,
     with_quad(realistic, N, [&](auto &p) {
         using P = std::decay_t<decltype(p)>;
         const int nx = P::nx, nu = P::nu, nc = P::nc, n = p.n(), m = p.m();
-        auto solver = make_solver<P>(*prm);
         ALMParams alm = make_alm(*prm);
+        return with_solver<P>(*prm, [&](auto solver) {
         std::vector<double> x0(nx), xn(nx), u(n), u_initial(n), y(m, 0.0);
         Quadcopter::initial_state(x0.data());
         for (int i = 0; i < n; ++i)
@@ -379,6 +459,7 @@ void oracle_quad_mpc(int realistic, int N, const OracleParams *prm, int num_sim,
         }
         std::copy(x0.begin(), x0.end(), states + (size_t)num_sim * nx);
         return 0;
+        });
     });
 }
 

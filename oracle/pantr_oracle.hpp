@@ -75,6 +75,10 @@ struct Stats {
     // ALM
     int outer_iterations = 1, inner_convergence_failures = 0;
     double delta = 0, penalty_norm = 0;
+    // PANOC (panoc_oracle.hpp)
+    int linesearch_failures = 0, linesearch_backtracks = 0, lbfgs_failures = 0, lbfgs_rejected = 0,
+        tau_1_accepted = 0, count_tau = 0;
+    double sum_tau = 0;
 };
 
 /// One record per PANTR iteration, used by the iterate-parity tests.
@@ -418,9 +422,8 @@ struct ALMParams {
 /// converged with eps <= tolerance and ||err||_inf <= dual_tolerance; otherwise raise the
 /// penalty of the components whose violation did not shrink by the threshold factor,
 /// Sigma_i <- min(max_penalty, max(Delta |e_i| / ||e||_inf, 1) Sigma_i), and tighten eps.
-template <class Problem>
-Stats alm_solve(const ALMParams &alm, const PANTRSolver<Problem> &inner, Problem &problem, double *x,
-                double *y = nullptr) {
+template <class Inner, class Problem>
+Stats alm_solve(const ALMParams &alm, const Inner &inner, Problem &problem, double *x, double *y = nullptr) {
     using clk = std::chrono::steady_clock;
     auto t0   = clk::now();
     const int m = problem.m();
@@ -449,6 +452,9 @@ Stats alm_solve(const ALMParams &alm, const PANTRSolver<Problem> &inner, Problem
         total.n_psi += ps.n_psi; total.n_grad_psi += ps.n_grad_psi; total.n_psi_grad_psi += ps.n_psi_grad_psi;
         total.n_grad_L += ps.n_grad_L; total.n_hess_psi_prod += ps.n_hess_psi_prod;
         total.n_prox_grad_step += ps.n_prox_grad_step;
+        total.linesearch_failures += ps.linesearch_failures; total.linesearch_backtracks += ps.linesearch_backtracks;
+        total.lbfgs_failures += ps.lbfgs_failures; total.lbfgs_rejected += ps.lbfgs_rejected;
+        total.tau_1_accepted += ps.tau_1_accepted; total.count_tau += ps.count_tau; total.sum_tau += ps.sum_tau;
         total.inner_convergence_failures += inner_converged ? 0 : 1;
         double norm_e2 = norm_inf(e2.data(), m);
         elapsed        = std::chrono::duration<double>(clk::now() - t0).count();

@@ -553,11 +553,14 @@ struct SingleShootingAL {
     /// grad_L(xhat, yhat(xhat)) = grad psi(xhat)  (formulation.hpp:98-99 with y = yhat)
     /// (PANTR evaluates it at the point its Hessian-vector products follow, so this is where the
     /// second-order tape is recorded, as in the kernels.)
-    void eval_grad_L(const double *u, double *grad) const {
+    void eval_grad_L(const double *u, double *grad, bool record = true) const {
         ++cnt.grad_L;
         std::vector<double> X((N + 1) * nx), yh(m());
         forward(u, X.data(), yh.data());
-        reverse_record(u, X.data(), grad);
+        if (record)
+            reverse_record(u, X.data(), grad);
+        else
+            reverse(u, X.data(), yh.data(), grad);
     }
     /// The Hessian-vector product of the problem (formulation.hpp:93-97), over the tape.
     void eval_hess_psi_prod(const double *u, const double *v, double *Hv) const {

@@ -25,8 +25,12 @@ PARAM_DOUBLES = [
     "hessian_vec_factor", "tol_scale", "tol_scale_root", "tol_max", "max_iter_factor",
     "alm_tolerance", "alm_max_time_s", "alm_dual_tolerance", "alm_initial_penalty",
     "alm_penalty_update_factor", "alm_initial_tolerance", "alm_tolerance_update_factor",
+    "min_linesearch_coefficient", "linesearch_strictness_factor", "linesearch_tolerance_factor",
+    "lbfgs_min_div_fac", "lbfgs_min_abs_s", "cbfgs_alpha", "cbfgs_eps",
 ]
-PARAM_INTS = ["max_iter", "stop_crit", "max_no_progress", "disable_acceleration", "alm_max_iter", "pad0"]
+PARAM_INTS = ["max_iter", "stop_crit", "max_no_progress", "disable_acceleration", "alm_max_iter", "method",
+              "force_linesearch", "lbfgs_memory", "lbfgs_force_pos_def", "pad0"]
+METHOD = {"pantr": 0, "panoc": 1, "strucpanoc": 2}  # mpc-driver.cpp:364-384
 
 STOP_CRIT = {"ApproxKKT": 0, "ApproxKKT2": 1, "ProjGradNorm": 2, "ProjGradNorm2": 3,
              "ProjGradUnitNorm": 4, "ProjGradUnitNorm2": 5, "FPRNorm": 6, "FPRNorm2": 7}
@@ -46,12 +50,16 @@ class OracleStats(C.Structure):
                                     "n_psi_grad_psi", "n_grad_L", "n_hess_psi_prod",
                                     "n_prox_grad_step", "outer_iterations",
                                     "inner_convergence_failures")] + \
-               [(k, _dbl) for k in ("delta", "penalty_norm")]
+               [(k, _dbl) for k in ("delta", "penalty_norm")] + \
+               [(k, _i32) for k in ("linesearch_failures", "linesearch_backtracks", "lbfgs_failures",
+                                    "lbfgs_rejected", "tau_1_accepted", "count_tau")] + \
+               [("sum_tau", _dbl)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+PANOC_TRACE_COLS = ("eps", "psi", "pnorm", "gamma", "tau", "fbe", "lbfgs_pairs")  # method != pantr
 TRACE_COLS = ("eps", "psi", "pnorm", "gamma", "radius", "rho", "q_model", "fbe", "nJ",
               "cg_its", "accepted")
 
@@ -74,6 +82,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.oracle_default_params.argtypes = [C.POINTER(OracleParams)]
         L.oracle_dodo_params.argtypes = [C.POINTER(OracleParams)]
+        L.oracle_dodo_params_method.argtypes = [C.POINTER(OracleParams), C.c_int]
         L.oracle_chain_nx.restype = C.c_int
         L.oracle_chain_nu.restype = C.c_int
         L.oracle_chain_initial_state.argtypes = [_pd]
@@ -130,10 +139,10 @@ def default_params():
     return p
 
 
-def dodo_params(**over):
-    """new-benchmarks-paper/dodo.py:12-33 PANTR options (+ keyword overrides)."""
+def dodo_params(method="pantr", **over):
+    """new-benchmarks-paper/dodo.py:12-40 options of `method` (+ keyword overrides)."""
     p = OracleParams()
-    lib().oracle_dodo_params(C.byref(p))
+    lib().oracle_dodo_params_method(C.byref(p), METHOD[method])
     for k, v in over.items():
         setattr(p, k, v)
     return p
@@ -235,11 +244,12 @@ def steihaug_dense(H, g, radius, tol_scale=1.0, tol_scale_root=0.5, max_iter_fac
 QUAD = {"quadcopter": 0, "realistic_quadcopter": 1}
 
 
-def quad_dodo_params(problem, **over):
-    """dodo.py:12-33 + the per-problem overrides of dodo.py:97-105."""
-    p = dodo_params(max_iter=250)                      # solver.max_iter=250
+def quad_dodo_params(problem, method="pantr", **over):
+    """dodo.py:12-40 + the per-problem overrides of dodo.py:97-105."""
+    p = dodo_params(method, max_iter=250)              # solver.max_iter=250
     if problem == "realistic_quadcopter":
-        p.tol_scale = 1.0                              # accel.tol_scale=1
+        if method == "pantr":
+            p.tol_scale = 1.0                          # accel.tol_scale=1
         p.alm_initial_tolerance = 1e-1                 # alm.initial_tolerance=1e-1
     for k, v in over.items():
         setattr(p, k, v)
