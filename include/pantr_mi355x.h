@@ -57,15 +57,21 @@ typedef struct pantr_stats {
     int32_t inner_convergence_failures; /* inner solves that did not reach their tolerance */
     double delta;                       /* ||Sigma^{-1}(yhat - y)||_inf at exit (0 when m = 0) */
     double penalty_norm;                /* ||Sigma||_2 / sqrt(m) at exit */
+    /* method=panoc, strucpanoc (alpaqa::PANOCStats; qub_backtracks above = stepsize_backtracks) */
+    int32_t linesearch_failures, linesearch_backtracks, lbfgs_failures, lbfgs_rejected;
+    int32_t tau_1_accepted, count_tau;
+    double sum_tau;
 } pantr_stats_t;
 
 typedef struct pantr_params pantr_params_t; /* solver option set */
 typedef struct pantr_batch pantr_batch_t;   /* problem + device resources */
 
 /* ---- options: replaces alpaqa::params::set_params(obj, prefix, opts) ---------------------
- * (call sites mpc-driver.cpp:54,61,62,113).  `kv` is one "prefix.key=value" string with
- * prefix solver. (PANTRParams), dir. (NewtonTRDirectionParams), accel. (SteihaugCGParams)
- * or alm. (ALMParams).  Strings with another prefix or without a '.' are ignored, as
+ * (call sites mpc-driver.cpp:54,61,62,113) and the solver selection "method=<name>"
+ * (mpc-driver.cpp:360-384: pantr, panoc, strucpanoc).  `kv` is one "prefix.key=value" string
+ * with prefix solver. (PANTRParams / PANOCParams), dir. (NewtonTRDirectionParams /
+ * [Structured]LBFGSDirectionParams), accel. (SteihaugCGParams / LBFGSParams) or alm.
+ * (ALMParams).  Strings with another prefix or without a '.' are ignored, as
  * set_params ignores options addressed to other objects; an unknown key under a known
  * prefix or an unparsable value is PANTR_ERR_INVALID_ARGUMENT.  Durations accept "30s",
  * "500ms", "2min"; enums their alpaqa names ("ProjGradUnitNorm").
@@ -122,7 +128,8 @@ int pantr_batch_last_kernel_ms(pantr_batch_t *b, float *ms);
  * (longest-expected-first); NULL restores identity.  Used by the next solve calls. */
 int pantr_batch_set_launch_order(pantr_batch_t *b, int32_t B, const int32_t *order);
 /* Per-iteration trace of the first `instances` instances (cap rows of 11 doubles each:
- * eps, psi, ||p||, gamma, radius, rho, q_model, fbe, |J|, cg_its, accepted) — what
+ * eps, psi, ||p||, gamma, radius, rho, q_model, fbe, |J|, cg_its, accepted; with method=panoc,
+ * strucpanoc: eps, psi, ||p||, gamma, tau, fbe, stored L-BFGS pairs, 4 unused) — what
  * solver.print_interval would print in the reference (mpc-driver.cpp:52). */
 int pantr_batch_set_trace(pantr_batch_t *b, int32_t instances, int32_t cap);
 int pantr_batch_get_trace(pantr_batch_t *b, double *out /* [instances][cap][11] */);

@@ -222,7 +222,7 @@ struct StructuredLBFGSDirection {
         int nJ = 0;
         for (int i = 0; i < n; ++i) {
             double gd = x[i] - gamma * grad[i];
-            bool in   = !(gd <= problem.lb(i)) && !(problem.ub(i) <= gd);
+            bool in   = problem.lb(i) < gd && gd < problem.ub(i);
             mask[i]   = in;
             nJ += in;
             q[i] = in ? -grad[i] : p[i];

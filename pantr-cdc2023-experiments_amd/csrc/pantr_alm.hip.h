@@ -34,6 +34,7 @@ struct AlmSolveArgs {
     double *u;        ///< [B][n] in/out
     double *y;        ///< [B][m] in/out
     double *ws;       ///< [B][ScalarALProblem::workspace_doubles(N)] second-order tape
+    double *lbfgs;    ///< [B][2 * lbfgs_memory * npad] L-BFGS rings (method != pantr) or nullptr
     DeviceStats *stats;
     double *trace;
     const int32_t *order;
@@ -601,8 +602,8 @@ struct ScalarALProblem {
     }
 };
 
-/// ALM outer loop (m > 0) around pantr_inner(), one wavefront per instance.
-template <class M>
+/// ALM outer loop (m > 0) around the inner solver METHOD names, one wavefront per instance.
+template <class M, int METHOD>
 __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -652,8 +653,10 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
             y[j]       = fmin(fmax(y[j], ylb), yub);
         }
         wave_sync();
-        r = pantr_inner(pb, P, eps, A.max_time_s, t_start, x_io, st,
-                        trace && i == 0 ? a.trace + (size_t)inst * a.trace_cap * TRACE_COLS : nullptr, a.trace_cap);
+        r = inner_solve<METHOD>(
+            pb, P, eps, A.max_time_s, t_start, x_io, st,
+            trace && i == 0 ? a.trace + (size_t)inst * a.trace_cap * TRACE_COLS : nullptr, a.trace_cap,
+            a.lbfgs ? a.lbfgs + (size_t)inst * 2 * P.lbfgs_memory * a.npad : nullptr);
         total_inner += r.iterations;
         bool inner_converged = r.status == Converged;
         failures += inner_converged ? 0 : 1;

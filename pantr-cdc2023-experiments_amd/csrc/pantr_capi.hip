@@ -6,6 +6,7 @@
 #include "chain_model.hip.h"
 #include "pantr_kernel.hip.h"
 #include "pantr_alm.hip.h"
+#include "panoc_kernel.hip.h"
 #include "quad_model.hip.h"
 
 #include <hip/hip_runtime.h>
@@ -57,6 +58,8 @@ struct pantr_batch {
     // device memory
     double *d_x0 = nullptr, *d_u = nullptr, *d_v = nullptr, *d_o1 = nullptr, *d_o2 = nullptr,
            *d_s = nullptr, *d_ws = nullptr, *d_trace = nullptr;
+    double *d_lbfgs = nullptr; ///< L-BFGS rings of method=panoc/strucpanoc, allocated at the first such solve
+    size_t lbfgs_doubles = 0;
     double *d_y = nullptr, *d_sig = nullptr, *d_om = nullptr, *d_uinit = nullptr; ///< m > 0 problems
     int32_t mpad = 0, mj = 0;
     bool al() const { return problem != ProblemId::HangingChain; }
@@ -78,6 +81,23 @@ int dev_alloc(T *&p, size_t count) {
 
 int check_supported(const SolverOptions &o) {
     // Options whose non-default value would select a code path the device solver does not have.
+    if (o.method != host::Method::PANTR) {
+        if (o.lbfgs.memory < 1 || o.lbfgs.memory > 32 * 1024)
+            return fail(PANTR_ERR_OUT_OF_RANGE, "accel.memory must be in [1, 32768]");
+        if (o.lbfgs.cbfgs_epsilon != 0)
+            return fail(PANTR_ERR_INVALID_ARGUMENT, "accel.cbfgs.ε != 0 is not supported by the device solver");
+        if (o.ldir.rescale_on_step_size_changes)
+            return fail(PANTR_ERR_INVALID_ARGUMENT,
+                        "dir.rescale_on_step_size_changes=true is not supported by the device solver");
+        if (o.method == host::Method::StrucPANOC && o.ldir.hessian_vec)
+            return fail(PANTR_ERR_INVALID_ARGUMENT,
+                        "method=strucpanoc needs dir.hessian_vec=0 (new-benchmarks-paper/dodo.py:39): the "
+                        "Hessian-vector term of the structured direction is not supported by the device solver");
+        if (o.panoc.update_direction_in_candidate || o.panoc.recompute_last_prox_step_after_stepsize_change)
+            return fail(PANTR_ERR_INVALID_ARGUMENT,
+                        "solver.update_direction_in_candidate / recompute_last_prox_step_after_stepsize_change "
+                        "are not supported by the device solver");
+    }
     if (o.dir.finite_diff)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "dir.finite_diff=true is not supported by the device solver");
     if (o.solver.compute_ratio_using_new_stepsize)
@@ -117,6 +137,12 @@ KernelParams to_kernel_params(const SolverOptions &o, int m) {
     k.max_iter = s.max_iter; k.stop_crit = static_cast<int32_t>(s.stop_crit);
     k.max_no_progress = s.max_no_progress; k.disable_acceleration = s.disable_acceleration ? 1 : 0;
     k.always_overwrite_results = 1;
+    k.min_linesearch_coefficient = o.panoc.min_linesearch_coefficient;
+    k.linesearch_strictness_factor = o.panoc.linesearch_strictness_factor;
+    k.linesearch_tolerance_factor = o.panoc.linesearch_tolerance_factor;
+    k.force_linesearch = o.panoc.force_linesearch ? 1 : 0;
+    k.lbfgs_min_div_fac = o.lbfgs.min_div_fac; k.lbfgs_min_abs_s = o.lbfgs.min_abs_s;
+    k.lbfgs_memory = o.lbfgs.memory; k.lbfgs_force_pos_def = o.lbfgs.force_pos_def ? 1 : 0;
     (void)m;
     return k;
 }
@@ -156,6 +182,24 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
                  DeviceStats *d_stats, hipStream_t stream) {
     if (int rc = check_supported(b->opts))
         return rc;
+    const int method = static_cast<int>(b->opts.method);
+    double *d_lbfgs  = nullptr;
+    if (method != 0) { // L-BFGS rings in HBM; rho and alpha in the ten spare LDS vector slots
+        const size_t mem = b->opts.lbfgs.memory;
+        if (2 * mem > (size_t)10 * b->npad)
+            return fail(PANTR_ERR_OUT_OF_RANGE, "accel.memory too large for the LDS of this horizon (2 memory <= 10 n_pad)");
+        const size_t need = (size_t)b->maxB * 2 * mem * b->npad;
+        if (need > b->lbfgs_doubles) {
+            if (b->d_lbfgs)
+                HIP_TRY(hipFree(b->d_lbfgs));
+            b->d_lbfgs       = nullptr;
+            b->lbfgs_doubles = 0;
+            if (int rc = dev_alloc(b->d_lbfgs, need))
+                return rc;
+            b->lbfgs_doubles = need;
+        }
+        d_lbfgs = b->d_lbfgs;
+    }
     if (b->al()) {
         if (b->opts.alm.initial_penalty <= 0)
             return fail(PANTR_ERR_INVALID_ARGUMENT,
@@ -163,7 +207,7 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
         AlmSolveArgs a{};
         a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj; a.m = b->m; a.mpad = b->mpad; a.mj = b->mj;
         a.trace_cap = b->trace_cap; a.trace_instances = b->trace_instances;
-        a.x0 = d_x0; a.u = d_u; a.y = d_y; a.ws = b->d_ws; a.stats = d_stats;
+        a.x0 = d_x0; a.u = d_u; a.y = d_y; a.ws = b->d_ws; a.lbfgs = d_lbfgs; a.stats = d_stats;
         a.trace = b->trace_instances > 0 ? b->d_trace : nullptr;
         a.order = b->have_order ? b->d_order : nullptr;
         a.prm   = to_kernel_params(b->opts, b->m);
@@ -171,7 +215,12 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
         HIP_TRY(hipEventRecord(b->ev_start, stream));
         with_quad_model(b, [&](auto model) {
             using M = decltype(model);
-            hipLaunchKernelGGL(pantr_alm_kernel<M>, dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+            if (method == 0)
+                hipLaunchKernelGGL((pantr_alm_kernel<M, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+            else if (method == 1)
+                hipLaunchKernelGGL((pantr_alm_kernel<M, 1>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+            else
+                hipLaunchKernelGGL((pantr_alm_kernel<M, 2>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
             return 0;
         });
         HIP_TRY(hipGetLastError());
@@ -182,12 +231,17 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
     SolveArgs a{};
     a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj;
     a.trace_cap = b->trace_cap; a.trace_instances = b->trace_instances;
-    a.x0 = d_x0; a.u = d_u; a.ws = b->d_ws; a.stats = d_stats;
+    a.x0 = d_x0; a.u = d_u; a.ws = b->d_ws; a.lbfgs = d_lbfgs; a.stats = d_stats;
     a.trace = b->trace_instances > 0 ? b->d_trace : nullptr;
     a.order = b->have_order ? b->d_order : nullptr;
     a.prm   = to_kernel_params(b->opts, b->m);
     HIP_TRY(hipEventRecord(b->ev_start, stream));
-    hipLaunchKernelGGL(pantr_solve_kernel<ChainModel>, dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+    if (method == 0)
+        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+    else if (method == 1)
+        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 1>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+    else
+        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 2>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev_stop, stream));
     b->timed = true;
@@ -330,17 +384,22 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
     if (b->lds_bytes + static_lds > 160 * 1024)
         return fail(PANTR_ERR_OUT_OF_RANGE, "decision vectors do not fit the 160 KiB LDS");
     if (b->al()) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_alm_kernel<QuadModelT<false>>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_alm_kernel<QuadModelT<true>>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+        for (const void *k : {(const void *)&pantr_alm_kernel<QuadModelT<false>, 0>,
+                              (const void *)&pantr_alm_kernel<QuadModelT<false>, 1>,
+                              (const void *)&pantr_alm_kernel<QuadModelT<false>, 2>,
+                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 0>,
+                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 1>,
+                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 2>})
+            HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_alm_eval_kernel<QuadModelT<false>>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_alm_eval_kernel<QuadModelT<true>>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
     } else {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_solve_kernel<ChainModel>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+        for (const void *k : {(const void *)&pantr_solve_kernel<ChainModel, 0>,
+                              (const void *)&pantr_solve_kernel<ChainModel, 1>,
+                              (const void *)&pantr_solve_kernel<ChainModel, 2>})
+            HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
     }
     const size_t B  = b->maxB;
     const size_t nv = std::max(b->n, b->nx); // the vector buffers also carry nx-sized rows
@@ -374,7 +433,8 @@ void pantr_batch_destroy(pantr_batch_t *b) {
     (void)hipSetDevice(b->device);
     for (void *p : {(void *)b->d_x0, (void *)b->d_u, (void *)b->d_v, (void *)b->d_o1, (void *)b->d_o2,
                     (void *)b->d_s, (void *)b->d_ws, (void *)b->d_trace, (void *)b->d_stats,
-                    (void *)b->d_order, (void *)b->d_y, (void *)b->d_sig, (void *)b->d_om, (void *)b->d_uinit})
+                    (void *)b->d_order, (void *)b->d_y, (void *)b->d_sig, (void *)b->d_om, (void *)b->d_uinit,
+                    (void *)b->d_lbfgs})
         if (p)
             (void)hipFree(p);
     if (b->ev_start)

@@ -41,8 +41,11 @@ struct KernelParams {
     double initial_radius, min_radius;
     double hessian_vec_factor, tol_scale, tol_scale_root, tol_max, max_iter_factor;
     double tolerance;
+    // PANOC line search and L-BFGS (method = panoc, strucpanoc; panoc_kernel.hip.h)
+    double min_linesearch_coefficient, linesearch_strictness_factor, linesearch_tolerance_factor;
+    double lbfgs_min_div_fac, lbfgs_min_abs_s;
     int32_t max_iter, stop_crit, max_no_progress, disable_acceleration;
-    int32_t always_overwrite_results, pad0;
+    int32_t always_overwrite_results, force_linesearch, lbfgs_memory, lbfgs_force_pos_def;
 };
 
 /// Per-instance result record (mirrors pantr_stats_t in include/pantr_mi355x.h).
@@ -52,6 +55,9 @@ struct DeviceStats {
     int32_t n_psi, n_grad_psi, n_psi_grad_psi, n_grad_L, n_hess_psi_prod, n_prox_grad_step;
     int32_t outer_iterations, inner_convergence_failures; ///< ALM
     double delta, penalty_norm;                           ///< ||Sigma^{-1}(yhat - y)||_inf, ||Sigma|| / sqrt(m)
+    int32_t linesearch_failures, linesearch_backtracks, lbfgs_failures, lbfgs_rejected, tau_1_accepted,
+        count_tau; ///< PANOC
+    double sum_tau;
 };
 
 constexpr int TRACE_COLS = 11;
@@ -64,6 +70,7 @@ struct SolveArgs {
     const double *x0;      ///< [B][nx] initial states (the problem parameter)
     double *u;             ///< [B][n]  in: initial guess, out: solution
     double *ws;            ///< [B][WaveProblem::workspace_doubles(N)] trajectories + tape
+    double *lbfgs;         ///< [B][2 * lbfgs_memory * npad] L-BFGS rings (method != pantr) or nullptr
     DeviceStats *stats;    ///< [B]
     double *trace;         ///< [trace_instances][trace_cap][TRACE_COLS] or nullptr
     const int32_t *order;  ///< optional launch order (instance index per workgroup) or nullptr
@@ -721,10 +728,18 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
     return {status, k, eps_k, curr.gamma, curr.psi_xh, curr.fbe(), radius};
 }
 
+/// The inner solver `method` names: 0 = pantr_inner() above, 1 = PANOC with L-BFGS, 2 = PANOC with
+/// structured L-BFGS (panoc_kernel.hip.h).
+template <int METHOD, class PB>
+__device__ __forceinline__ InnerResult inner_solve(PB &pb, const KernelParams &P, double tolerance,
+                                                   double deadline_s, long long t_start, double *x_io,
+                                                   DeviceStats &st, double *trace, int trace_cap,
+                                                   double *lbfgs_ws);
+
 // ---------------------------------------------------------------------------------------
 // The solve kernel for problems without general constraints (m = 0: ALM = one inner solve)
 // ---------------------------------------------------------------------------------------
-template <class M>
+template <class M, int METHOD>
 __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -752,8 +767,10 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
     }
     DeviceStats st{};
     const bool trace = a.trace != nullptr && inst < a.trace_instances;
-    InnerResult r = pantr_inner(pb, P, P.tolerance, P.max_time_s, t_start, x_io, st,
-                                trace ? a.trace + (size_t)inst * a.trace_cap * TRACE_COLS : nullptr, a.trace_cap);
+    InnerResult r = inner_solve<METHOD>(
+        pb, P, P.tolerance, P.max_time_s, t_start, x_io, st,
+        trace ? a.trace + (size_t)inst * a.trace_cap * TRACE_COLS : nullptr, a.trace_cap,
+        a.lbfgs ? a.lbfgs + (size_t)inst * 2 * P.lbfgs_memory * a.npad : nullptr);
     for (int j = 0; j < nj; ++j) { // solution (or the untouched guess when nothing was overwritten)
         int i = j * WAVE + lane;
         if (i < n)

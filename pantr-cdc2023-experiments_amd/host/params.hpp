@@ -1,6 +1,8 @@
 // Solver option structs and the "prefix.key=value" parser.
 //
-// Mirrors the part of alpaqa's option surface the reference exercises:
+// Mirrors the part of alpaqa's option surface the reference exercises (the "solver", "dir" and
+// "accel" prefixes accept the union of the keys of the three methods' parameter structs; a key of
+// another method is stored and has no effect):
 //   alpaqa::params::set_params(obj, prefix, opts)  drivers/mpc-driver.cpp:54,61,62,113
 //   PANTRParams / NewtonTRDirectionParams / SteihaugCGParams / ALMParams
 //       values set in new-benchmarks-paper/dodo.py:12-33,98-105 and
@@ -84,6 +86,37 @@ struct SteihaugCGParams {
     double tol_scale = 1, tol_scale_root = 0.5, tol_max = kInf, max_iter_factor = 1;
 };
 
+/// The solver `method=` selects (mpc-driver.cpp:360-384; default there: fbetrust, not available).
+enum class Method : int32_t { PANTR = 0, PANOC = 1, StrucPANOC = 2 };
+inline const char *enum_name(Method m) {
+    static const char *names[] = {"pantr", "panoc", "strucpanoc"};
+    return names[static_cast<int>(m)];
+}
+
+/// The fields of alpaqa::PANOCParams that PANTRParams does not have ("solver.*" with method=panoc,
+/// strucpanoc; the shared ones are read from PANTRParams).
+struct PANOCExtraParams {
+    double min_linesearch_coefficient   = 1.0 / 256;
+    bool force_linesearch               = false;
+    double linesearch_strictness_factor = 0.95;
+    double linesearch_tolerance_factor  = 10 * kEps;
+    bool update_direction_in_candidate                    = false;
+    bool recompute_last_prox_step_after_stepsize_change   = false;
+};
+/// alpaqa::LBFGSParams ("accel.*" with method=panoc, strucpanoc; dodo.py:35,38 set memory=50)
+struct LBFGSParams {
+    int32_t memory     = 10;
+    double min_div_fac = 1e-10, min_abs_s = 1e-32;
+    double cbfgs_alpha = 1, cbfgs_epsilon = 0;
+    bool force_pos_def = true;
+};
+/// alpaqa::LBFGSDirectionParams / StructuredLBFGSDirectionParams ("dir.*" with method=panoc,
+/// strucpanoc; dodo.py:39 sets hessian_vec=0)
+struct LBFGSDirectionParams {
+    bool rescale_on_step_size_changes = false;
+    bool hessian_vec                  = true; ///< structured direction: Hessian-vector term for the active set
+};
+
 struct ALMParams {
     double tolerance = 1e-5, dual_tolerance = 1e-5;
     double penalty_update_factor = 10, initial_penalty = 1, initial_penalty_factor = 20;
@@ -98,9 +131,13 @@ struct ALMParams {
 
 /// Everything one solver instance is configured by.
 struct SolverOptions {
+    Method method = Method::PANTR;
     PANTRParams solver;
     NewtonTRDirectionParams dir;
     SteihaugCGParams accel;
+    PANOCExtraParams panoc;   ///< "solver.*" keys of PANOCParams
+    LBFGSDirectionParams ldir; ///< "dir.*" keys of the L-BFGS directions
+    LBFGSParams lbfgs;        ///< "accel.*" keys of LBFGSParams
     ALMParams alm;
     /// make_inner_solver / make_solver defaults of the reference driver
     /// (mpc-driver.cpp:51-53 and :109-111), applied before the CLI options.
@@ -243,6 +280,14 @@ inline bool find_field(SolverOptions &o, std::string_view full_key, FieldRef &re
                     s.recompute_last_prox_step_after_direction_reset)
         PANTR_FIELD("disable_acceleration", Bool, s.disable_acceleration)
         PANTR_FIELD("ratio_approx_fbe_quadratic_model", Bool, s.ratio_approx_fbe_quadratic_model)
+        auto &pn = o.panoc; // PANOCParams
+        PANTR_FIELD("min_linesearch_coefficient", Double, pn.min_linesearch_coefficient)
+        PANTR_FIELD("force_linesearch", Bool, pn.force_linesearch)
+        PANTR_FIELD("linesearch_strictness_factor", Double, pn.linesearch_strictness_factor)
+        PANTR_FIELD("linesearch_tolerance_factor", Double, pn.linesearch_tolerance_factor)
+        PANTR_FIELD("update_direction_in_candidate", Bool, pn.update_direction_in_candidate)
+        PANTR_FIELD("recompute_last_prox_step_after_stepsize_change", Bool,
+                    pn.recompute_last_prox_step_after_stepsize_change)
         return false;
     }
     if (prefix == "dir") {
@@ -251,6 +296,9 @@ inline bool find_field(SolverOptions &o, std::string_view full_key, FieldRef &re
         PANTR_FIELD("hessian_vec_factor", Double, d.hessian_vec_factor)
         PANTR_FIELD("finite_diff", Bool, d.finite_diff)
         PANTR_FIELD("finite_diff_stepsize", Double, d.finite_diff_stepsize)
+        auto &ld = o.ldir; // L-BFGS directions
+        PANTR_FIELD("rescale_on_step_size_changes", Bool, ld.rescale_on_step_size_changes)
+        PANTR_FIELD("hessian_vec", Bool, ld.hessian_vec)
         return false;
     }
     if (prefix == "accel") {
@@ -260,6 +308,15 @@ inline bool find_field(SolverOptions &o, std::string_view full_key, FieldRef &re
         PANTR_FIELD("tol_scale_root", Double, c.tol_scale_root)
         PANTR_FIELD("tol_max", Double, c.tol_max)
         PANTR_FIELD("max_iter_factor", Double, c.max_iter_factor)
+        auto &l = o.lbfgs; // LBFGSParams
+        PANTR_FIELD("memory", Int, l.memory)
+        PANTR_FIELD("min_div_fac", Double, l.min_div_fac)
+        PANTR_FIELD("min_abs_s", Double, l.min_abs_s)
+        PANTR_FIELD("cbfgs.α", Double, l.cbfgs_alpha)
+        PANTR_FIELD("cbfgs.alpha", Double, l.cbfgs_alpha)
+        PANTR_FIELD("cbfgs.ε", Double, l.cbfgs_epsilon)
+        PANTR_FIELD("cbfgs.epsilon", Double, l.cbfgs_epsilon)
+        PANTR_FIELD("force_pos_def", Bool, l.force_pos_def)
         return false;
     }
     if (prefix == "alm") {
@@ -292,6 +349,16 @@ enum class SetResult { Ok, Ignored, UnknownKey, BadValue, Malformed };
 /// Apply one "prefix.key=value" option.  Options for other objects are ignored, as
 /// alpaqa::params::set_params ignores keys whose prefix is not the one it was given.
 inline SetResult set_option(SolverOptions &o, std::string_view kv, std::string &err) {
+    if (kv.substr(0, 7) == "method=") { // mpc-driver.cpp:360-361
+        std::string_view v = kv.substr(7);
+        for (Method m : {Method::PANTR, Method::PANOC, Method::StrucPANOC})
+            if (v == enum_name(m)) {
+                o.method = m;
+                return SetResult::Ok;
+            }
+        err = "Unknown solver '" + std::string(v) + "' (available: pantr, panoc, strucpanoc)";
+        return SetResult::BadValue;
+    }
     auto eq = kv.find('=');
     if (eq == std::string_view::npos) {
         auto dot = kv.find('.');
@@ -328,6 +395,10 @@ inline SetResult set_option(SolverOptions &o, std::string_view kv, std::string &
 
 /// Read a field back as a double (enums/bools/ints converted); false if unknown.
 inline bool get_option(const SolverOptions &o, std::string_view key, double &out) {
+    if (key == "method") {
+        out = static_cast<int>(o.method);
+        return true;
+    }
     FieldRef ref{};
     bool known = false;
     if (!find_field(const_cast<SolverOptions &>(o), key, ref, known))

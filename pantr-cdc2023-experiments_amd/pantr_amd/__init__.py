@@ -9,6 +9,7 @@ The Python-level names follow the reference's driver surface:
   PantrBatch.solve        <->  stats = solver(problem, u, y)       drivers/mpc-driver.cpp:217
   PantrBatch.set_params   <->  alpaqa::params::set_params          drivers/mpc-driver.cpp:54,61,62,113
   DODO_PANTR_OPTS         <->  SOLVER_OPT["pantr"]                 new-benchmarks-paper/dodo.py:12-33
+  DODO_OPTS[method]       <->  SOLVER_OPT[method] + method=        new-benchmarks-paper/dodo.py:24-40
 """
 import ctypes as C
 import os
@@ -36,6 +37,13 @@ DODO_PANTR_OPTS = (
     "solver.radius_factor_good=10", "solver.ratio_threshold_acceptable=0.3",
     "solver.ratio_threshold_good=0.5", "dir.hessian_vec_factor=1", "accel.tol_scale=1e-2",
 )
+# new-benchmarks-paper/dodo.py:12-22 (OPT_ALM); :34-36 SOLVER_OPT["panoc"]; :37-40 SOLVER_OPT["strucpanoc"]
+DODO_ALM_OPTS = DODO_PANTR_OPTS[:9]
+DODO_PANOC_OPTS = ("method=panoc",) + DODO_ALM_OPTS + ("accel.memory=50",)
+DODO_STRUCPANOC_OPTS = ("method=strucpanoc",) + DODO_ALM_OPTS + ("accel.memory=50", "dir.hessian_vec=0")
+DODO_OPTS = {"pantr": ("method=pantr",) + DODO_PANTR_OPTS, "panoc": DODO_PANOC_OPTS,
+             "strucpanoc": DODO_STRUCPANOC_OPTS}
+PANOC_TRACE_COLS = ("eps", "psi", "pnorm", "gamma", "tau", "fbe", "lbfgs_pairs")
 # new-benchmarks-paper/dodo.py:94-95
 DODO_HANGING_CHAIN_OPTS = ("num_dist=5", "u_dist=-1,1,1")
 
@@ -49,7 +57,10 @@ class PantrStats(C.Structure):
                                     "n_psi_grad_psi", "n_grad_L", "n_hess_psi_prod",
                                     "n_prox_grad_step", "outer_iterations",
                                     "inner_convergence_failures")] + \
-               [(k, _dbl) for k in ("delta", "penalty_norm")]
+               [(k, _dbl) for k in ("delta", "penalty_norm")] + \
+               [(k, _i32) for k in ("linesearch_failures", "linesearch_backtracks", "lbfgs_failures",
+                                    "lbfgs_rejected", "tau_1_accepted", "count_tau")] + \
+               [("sum_tau", _dbl)]
 
 
 STATS_DTYPE = np.dtype([(k, np.float64) for k in ("eps", "final_gamma", "final_psi", "final_fbe",
@@ -59,7 +70,11 @@ STATS_DTYPE = np.dtype([(k, np.float64) for k in ("eps", "final_gamma", "final_p
                                                 "n_grad_psi", "n_psi_grad_psi", "n_grad_L",
                                                 "n_hess_psi_prod", "n_prox_grad_step",
                                                 "outer_iterations", "inner_convergence_failures")] +
-                       [(k, np.float64) for k in ("delta", "penalty_norm")])
+                       [(k, np.float64) for k in ("delta", "penalty_norm")] +
+                       [(k, np.int32) for k in ("linesearch_failures", "linesearch_backtracks",
+                                                "lbfgs_failures", "lbfgs_rejected", "tau_1_accepted",
+                                                "count_tau")] +
+                       [("sum_tau", np.float64)])
 assert STATS_DTYPE.itemsize == C.sizeof(PantrStats)
 
 # every symbol include/pantr_mi355x.h declares

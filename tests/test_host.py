@@ -38,7 +38,7 @@ def test_stats_struct_layout():
         if decl:
             names += [x.strip() for x in decl.split(None, 1)[1].split(",")]
     assert tuple(names) == pa.STATS_DTYPE.names
-    assert pa.STATS_DTYPE.itemsize == 6 * 8 + 14 * 4 + 2 * 8
+    assert pa.STATS_DTYPE.itemsize == 6 * 8 + 14 * 4 + 2 * 8 + 6 * 4 + 8
 
 
 def test_driver_defaults_and_dodo_options():
