@@ -463,6 +463,25 @@ void oracle_quad_mpc(int realistic, int N, const OracleParams *prm, int num_sim,
     });
 }
 
+/// L-BFGS two-loop recursion on given pairs (cross-check against the dense BFGS recursion):
+/// pairs[i] = (S[i], Y[i]), oldest first; mask == nullptr: all indices.  Returns 0 when the
+/// application failed (no usable pair).
+int oracle_lbfgs_apply(int n, int memory, int count, const double *S, const double *Y, double *q,
+                       const unsigned char *mask) {
+    LBFGS l;
+    l.params.memory = memory;
+    l.resize(n);
+    std::vector<double> zero(n, 0.0), s(n), y(n);
+    for (int i = 0; i < count; ++i) // update(x, xn, p, pn, positive, forced): s = xn - x, y = pn - p
+        l.update(zero.data(), S + (size_t)i * n, zero.data(), Y + (size_t)i * n, true, true);
+    if (!mask)
+        return l.apply(q);
+    int nJ = 0;
+    for (int i = 0; i < n; ++i)
+        nJ += mask[i] != 0;
+    return l.apply_masked(q, mask, nJ);
+}
+
 /// Steihaug CG on a dense symmetric matrix (cross-check against SciPy).
 double oracle_steihaug_dense(int n, const double *H /*n x n row-major*/, const double *g,
                              double radius, double tol_scale, double tol_scale_root,

@@ -1,4 +1,5 @@
-// The slice of alpaqa's C++ surface that drivers/mpc-driver.cpp's "pantr" branch uses,
+// The slice of alpaqa's C++ surface that drivers/mpc-driver.cpp's "pantr", "panoc" and "strucpanoc"
+// branches (mpc-driver.cpp:364-384) use,
 // re-implemented over the C ABI of include/pantr_mi355x.h.  Same names, argument meaning and
 // error behaviour, so a driver written against alpaqa's types reads the same against these:
 //
@@ -36,7 +37,10 @@ using crvec    = std::span<const real_t>;
 struct DefaultConfig {};
 
 using pantr::host::ALMParams;
+using pantr::host::LBFGSDirectionParams;
+using pantr::host::LBFGSParams;
 using pantr::host::NewtonTRDirectionParams;
+using pantr::host::PANOCParams;
 using pantr::host::PANOCStopCrit;
 using pantr::host::PANTRParams;
 using pantr::host::SolverStatus;
@@ -164,6 +168,59 @@ class PANTRSolver {
     using Direction = DirectionT;
     PANTRSolver(const Params &p, Direction d = {}) : params(p), direction(std::move(d)) {}
     std::string get_name() const { return "PANTRSolver<" + direction.get_name() + ">"; }
+    /// The typed parameter structs as one option set (what crosses the C ABI as strings).
+    void to_options(pantr::host::SolverOptions &o) const {
+        o.method = pantr::host::Method::PANTR;
+        o.solver = params;
+        o.dir    = direction.params.direction;
+        o.accel  = direction.params.accelerator;
+    }
+    Params params;
+    Direction direction;
+};
+
+/// alpaqa::LBFGSDirection / alpaqa::StructuredLBFGSDirection (mpc-driver.cpp:373,380)
+template <class Conf = DefaultConfig>
+struct LBFGSDirection {
+    using DirectionParams   = LBFGSDirectionParams;
+    using AcceleratorParams = LBFGSParams;
+    static constexpr auto method = pantr::host::Method::PANOC;
+    struct Params {
+        AcceleratorParams accelerator{};
+        DirectionParams direction{};
+    } params;
+    LBFGSDirection() = default;
+    LBFGSDirection(const Params &p) : params(p) {}
+    std::string get_name() const { return "LBFGSDirection"; }
+};
+template <class Conf = DefaultConfig>
+struct StructuredLBFGSDirection {
+    using DirectionParams   = LBFGSDirectionParams;
+    using AcceleratorParams = LBFGSParams;
+    static constexpr auto method = pantr::host::Method::StrucPANOC;
+    struct Params {
+        AcceleratorParams accelerator{};
+        DirectionParams direction{};
+    } params;
+    StructuredLBFGSDirection() = default;
+    StructuredLBFGSDirection(const Params &p) : params(p) {}
+    std::string get_name() const { return "StructuredLBFGSDirection"; }
+};
+
+/// alpaqa::PANOCSolver<Direction> (mpc-driver.cpp:374,381)
+template <class DirectionT>
+class PANOCSolver {
+  public:
+    using Params    = PANOCParams;
+    using Direction = DirectionT;
+    PANOCSolver(const Params &p, Direction d = {}) : params(p), direction(std::move(d)) {}
+    std::string get_name() const { return "PANOCSolver<" + direction.get_name() + ">"; }
+    void to_options(pantr::host::SolverOptions &o) const {
+        o.method = Direction::method;
+        params.split(o.solver, o.panoc);
+        o.ldir  = direction.params.direction;
+        o.lbfgs = direction.params.accelerator;
+    }
     Params params;
     Direction direction;
 };
@@ -229,55 +286,11 @@ class ALMSolver {
     /// Hand the typed parameter structs to the handle through the string interface of the ABI.
     void push_options(pantr_batch_t *b) const {
         pantr::host::SolverOptions o;
-        o.solver = inner_solver.params;
-        o.dir    = inner_solver.direction.params.direction;
-        o.accel  = inner_solver.direction.params.accelerator;
-        o.alm    = params;
-        auto set = [&](const char *key, double v) {
-            char buf[128];
-            std::snprintf(buf, sizeof buf, "%s=%.17g", key, v);
-            check(pantr_batch_set_param(b, buf));
-        };
-        auto setb = [&](const char *key, bool v) {
-            check(pantr_batch_set_param(b, (std::string(key) + (v ? "=true" : "=false")).c_str()));
-        };
-        const auto &s = o.solver;
-        set("solver.Lipschitz.L_0", s.Lipschitz.L_0);
-        set("solver.Lipschitz.epsilon", s.Lipschitz.epsilon);
-        set("solver.Lipschitz.delta", s.Lipschitz.delta);
-        set("solver.Lipschitz.Lgamma_factor", s.Lipschitz.Lgamma_factor);
-        set("solver.max_iter", s.max_iter);
-        set("solver.max_time", s.max_time);
-        set("solver.L_min", s.L_min);
-        set("solver.L_max", s.L_max);
-        check(pantr_batch_set_param(b, (std::string("solver.stop_crit=") + enum_name(s.stop_crit)).c_str()));
-        set("solver.max_no_progress", s.max_no_progress);
-        set("solver.quadratic_upperbound_tolerance_factor", s.quadratic_upperbound_tolerance_factor);
-        set("solver.TR_tolerance_factor", s.TR_tolerance_factor);
-        set("solver.ratio_threshold_acceptable", s.ratio_threshold_acceptable);
-        set("solver.ratio_threshold_good", s.ratio_threshold_good);
-        set("solver.radius_factor_rejected", s.radius_factor_rejected);
-        set("solver.radius_factor_acceptable", s.radius_factor_acceptable);
-        set("solver.radius_factor_good", s.radius_factor_good);
-        set("solver.initial_radius", s.initial_radius);
-        set("solver.min_radius", s.min_radius);
-        setb("solver.compute_ratio_using_new_stepsize", s.compute_ratio_using_new_stepsize);
-        setb("solver.disable_acceleration", s.disable_acceleration);
-        setb("solver.ratio_approx_fbe_quadratic_model", s.ratio_approx_fbe_quadratic_model);
-        set("dir.hessian_vec_factor", o.dir.hessian_vec_factor);
-        setb("dir.finite_diff", o.dir.finite_diff);
-        set("accel.tol_scale", o.accel.tol_scale);
-        set("accel.tol_scale_root", o.accel.tol_scale_root);
-        set("accel.tol_max", o.accel.tol_max);
-        set("accel.max_iter_factor", o.accel.max_iter_factor);
-        set("alm.tolerance", o.alm.tolerance);
-        set("alm.dual_tolerance", o.alm.dual_tolerance);
-        set("alm.max_iter", o.alm.max_iter);
-        set("alm.max_time", o.alm.max_time);
-        set("alm.initial_penalty", o.alm.initial_penalty);
-        set("alm.penalty_update_factor", o.alm.penalty_update_factor);
-        set("alm.initial_tolerance", o.alm.initial_tolerance);
-        set("alm.tolerance_update_factor", o.alm.tolerance_update_factor);
+        inner_solver.to_options(o);
+        o.alm = params;
+        check(pantr_batch_set_param(b, (std::string("method=") + enum_name(o.method)).c_str()));
+        for (const char *key : pantr::host::kOptionKeys)
+            check(pantr_batch_set_param(b, pantr::host::format_option(o, key).c_str()));
     }
 };
 
@@ -317,6 +330,26 @@ inline void set_params(SteihaugCGParams &p, std::string_view prefix, std::span<c
 }
 inline void set_params(ALMParams &p, std::string_view prefix, std::span<const std::string_view> opts) {
     detail::set_struct(p, &pantr::host::SolverOptions::alm, "alm", prefix, opts);
+}
+inline void set_params(LBFGSDirectionParams &p, std::string_view prefix, std::span<const std::string_view> opts) {
+    detail::set_struct(p, &pantr::host::SolverOptions::ldir, "dir", prefix, opts);
+}
+inline void set_params(LBFGSParams &p, std::string_view prefix, std::span<const std::string_view> opts) {
+    detail::set_struct(p, &pantr::host::SolverOptions::lbfgs, "accel", prefix, opts);
+}
+inline void set_params(PANOCParams &p, std::string_view prefix, std::span<const std::string_view> opts) {
+    pantr::host::SolverOptions o;
+    p.split(o.solver, o.panoc);
+    const std::string pfx = std::string(prefix) + ".";
+    for (std::string_view kv : opts) {
+        if (kv.substr(0, pfx.size()) != pfx)
+            continue;
+        std::string err;
+        if (pantr::host::set_option(o, "solver." + std::string(kv.substr(pfx.size())), err) !=
+            pantr::host::SetResult::Ok)
+            throw std::invalid_argument(err);
+    }
+    p.join(o.solver, o.panoc);
 }
 
 /// Scalars, strings and vectors the driver itself reads ("num_sim=60", "u_dist=-1,1,1", ...):

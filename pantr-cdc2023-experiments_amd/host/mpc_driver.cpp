@@ -1,7 +1,7 @@
 // benchmark-mpc-driver: the reference's MPC benchmark CLI (drivers/mpc-driver.cpp), "pantr"
 // method, over the MI355X batched solver.
 //
-//   benchmark-mpc-driver [<path>/]<name> <horizon> <formulation> method=pantr [<key>=<value>...]
+//   benchmark-mpc-driver [<path>/]<name> <horizon> <formulation> method=pantr|panoc|strucpanoc [<key>=<value>...]
 //
 // Same positional arguments, options and output as the reference (mpc-driver.cpp:39-43,
 // 326-343): num_sim, num_dist, u_dist, warm, results_name, and the solver./dir./accel./alm.
@@ -185,11 +185,8 @@ int main(int argc, char *argv[]) try {
     std::string_view solver_name = "fbetrust"; // mpc-driver.cpp:359
     alpaqa::params::set_params(solver_name, "method", extra_opts);
 
-    std::map<std::string_view, std::function<void()>> solvers{
-        {"pantr", [&] {
-             using Accelerator = alpaqa::NewtonTRDirection<config_t>;
-             using InnerSolver = alpaqa::PANTRSolver<Accelerator>;
-             auto solver       = make_solver<InnerSolver>(extra_opts);
+    // do_experiment (mpc-driver.cpp:280-326) + the optional batched replay
+    auto run = [&](auto solver) {
              MPCResults mpc    = do_mpc_experiment(problem, solver, horizon, extra_opts);
 
              using namespace pantr::host;
@@ -245,6 +242,22 @@ int main(int argc, char *argv[]) try {
                  write_results(res_file, results);
              else
                  std::cerr << "Unable to open results file " << std::quoted(results_name + ".py") << std::endl;
+    };
+    std::map<std::string_view, std::function<void()>> solvers{
+        {"pantr", [&] { // mpc-driver.cpp:364-370
+             using Accelerator = alpaqa::NewtonTRDirection<config_t>;
+             using InnerSolver = alpaqa::PANTRSolver<Accelerator>;
+             run(make_solver<InnerSolver>(extra_opts));
+         }},
+        {"strucpanoc", [&] { // mpc-driver.cpp:371-377
+             using Accelerator = alpaqa::StructuredLBFGSDirection<config_t>;
+             using InnerSolver = alpaqa::PANOCSolver<Accelerator>;
+             run(make_solver<InnerSolver>(extra_opts));
+         }},
+        {"panoc", [&] { // mpc-driver.cpp:378-384
+             using Accelerator = alpaqa::LBFGSDirection<config_t>;
+             using InnerSolver = alpaqa::PANOCSolver<Accelerator>;
+             run(make_solver<InnerSolver>(extra_opts));
          }},
     };
 
@@ -253,7 +266,7 @@ int main(int argc, char *argv[]) try {
         solver_it->second();
     else
         throw std::invalid_argument("Unknown solver '" + std::string(solver_name) + "'\n" +
-                                    "  Available solvers: 'pantr'");
+                                    "  Available solvers: 'pantr', 'strucpanoc', 'panoc'");
 } catch (std::exception &e) {
     std::cerr << "Error: " << typeid(e).name() << ":\n  " << e.what() << std::endl;
     return -1;

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <ostream>
@@ -102,6 +103,47 @@ struct PANOCExtraParams {
     double linesearch_tolerance_factor  = 10 * kEps;
     bool update_direction_in_candidate                    = false;
     bool recompute_last_prox_step_after_stepsize_change   = false;
+};
+/// alpaqa::PANOCParams as one struct (what make_inner_solver<PANOCSolver<...>> fills,
+/// mpc-driver.cpp:49-54); split() / join() map it onto the shared and the extra part.
+struct PANOCParams {
+    LipschitzEstimateParams Lipschitz;
+    int32_t max_iter = 100;
+    double max_time  = 300;
+    double min_linesearch_coefficient   = 1.0 / 256;
+    bool force_linesearch               = false;
+    double linesearch_strictness_factor = 0.95;
+    double L_min = 1e-5, L_max = 1e20;
+    PANOCStopCrit stop_crit = PANOCStopCrit::ApproxKKT;
+    int32_t max_no_progress = 10;
+    int32_t print_interval = 0, print_precision = 6;
+    double quadratic_upperbound_tolerance_factor = 10 * kEps;
+    double linesearch_tolerance_factor           = 10 * kEps;
+    bool update_direction_in_candidate                  = false;
+    bool recompute_last_prox_step_after_stepsize_change = false;
+
+    void split(PANTRParams &c, PANOCExtraParams &e) const {
+        c.Lipschitz = Lipschitz; c.max_iter = max_iter; c.max_time = max_time; c.L_min = L_min; c.L_max = L_max;
+        c.stop_crit = stop_crit; c.max_no_progress = max_no_progress; c.print_interval = print_interval;
+        c.print_precision = print_precision;
+        c.quadratic_upperbound_tolerance_factor = quadratic_upperbound_tolerance_factor;
+        e.min_linesearch_coefficient = min_linesearch_coefficient; e.force_linesearch = force_linesearch;
+        e.linesearch_strictness_factor = linesearch_strictness_factor;
+        e.linesearch_tolerance_factor = linesearch_tolerance_factor;
+        e.update_direction_in_candidate = update_direction_in_candidate;
+        e.recompute_last_prox_step_after_stepsize_change = recompute_last_prox_step_after_stepsize_change;
+    }
+    void join(const PANTRParams &c, const PANOCExtraParams &e) {
+        Lipschitz = c.Lipschitz; max_iter = c.max_iter; max_time = c.max_time; L_min = c.L_min; L_max = c.L_max;
+        stop_crit = c.stop_crit; max_no_progress = c.max_no_progress; print_interval = c.print_interval;
+        print_precision = c.print_precision;
+        quadratic_upperbound_tolerance_factor = c.quadratic_upperbound_tolerance_factor;
+        min_linesearch_coefficient = e.min_linesearch_coefficient; force_linesearch = e.force_linesearch;
+        linesearch_strictness_factor = e.linesearch_strictness_factor;
+        linesearch_tolerance_factor = e.linesearch_tolerance_factor;
+        update_direction_in_candidate = e.update_direction_in_candidate;
+        recompute_last_prox_step_after_stepsize_change = e.recompute_last_prox_step_after_stepsize_change;
+    }
 };
 /// alpaqa::LBFGSParams ("accel.*" with method=panoc, strucpanoc; dodo.py:35,38 set memory=50)
 struct LBFGSParams {
@@ -411,6 +453,48 @@ inline bool get_option(const SolverOptions &o, std::string_view key, double &out
     case FieldType::StopCrit: out = static_cast<int>(*static_cast<PANOCStopCrit *>(ref.ptr)); break;
     }
     return true;
+}
+
+/// Every option in the canonical spelling set_option() accepts (one entry per field).
+inline constexpr const char *kOptionKeys[] = {
+    "solver.Lipschitz.L_0", "solver.Lipschitz.epsilon", "solver.Lipschitz.delta", "solver.Lipschitz.Lgamma_factor",
+    "solver.max_iter", "solver.max_time", "solver.L_min", "solver.L_max", "solver.stop_crit",
+    "solver.max_no_progress", "solver.print_interval", "solver.print_precision",
+    "solver.quadratic_upperbound_tolerance_factor", "solver.TR_tolerance_factor",
+    "solver.ratio_threshold_acceptable", "solver.ratio_threshold_good", "solver.radius_factor_rejected",
+    "solver.radius_factor_acceptable", "solver.radius_factor_good", "solver.initial_radius", "solver.min_radius",
+    "solver.compute_ratio_using_new_stepsize", "solver.update_direction_on_prox_step",
+    "solver.recompute_last_prox_step_after_direction_reset", "solver.disable_acceleration",
+    "solver.ratio_approx_fbe_quadratic_model", "solver.min_linesearch_coefficient", "solver.force_linesearch",
+    "solver.linesearch_strictness_factor", "solver.linesearch_tolerance_factor",
+    "solver.update_direction_in_candidate", "solver.recompute_last_prox_step_after_stepsize_change",
+    "dir.hessian_vec_factor", "dir.finite_diff", "dir.finite_diff_stepsize", "dir.rescale_on_step_size_changes",
+    "dir.hessian_vec", "accel.tol_scale", "accel.tol_scale_root", "accel.tol_max", "accel.max_iter_factor",
+    "accel.memory", "accel.min_div_fac", "accel.min_abs_s", "accel.cbfgs.alpha", "accel.cbfgs.epsilon",
+    "accel.force_pos_def", "alm.tolerance", "alm.dual_tolerance", "alm.penalty_update_factor",
+    "alm.initial_penalty", "alm.initial_penalty_factor", "alm.initial_tolerance", "alm.tolerance_update_factor",
+    "alm.rel_penalty_increase_threshold", "alm.max_multiplier", "alm.max_penalty", "alm.min_penalty",
+    "alm.max_iter", "alm.max_time", "alm.print_interval", "alm.print_precision", "alm.single_penalty_factor",
+};
+
+/// "key=value" for one field, in the grammar set_option() parses back to the same value.
+inline std::string format_option(const SolverOptions &o, std::string_view key) {
+    FieldRef ref{};
+    bool known = false;
+    if (!find_field(const_cast<SolverOptions &>(o), key, ref, known))
+        return {};
+    std::string out = std::string(key) + "=";
+    char buf[64];
+    switch (ref.type) {
+    case FieldType::Double:
+    case FieldType::Duration:
+        std::snprintf(buf, sizeof buf, "%.17g", *static_cast<double *>(ref.ptr));
+        return out + buf;
+    case FieldType::Int: return out + std::to_string(*static_cast<int32_t *>(ref.ptr));
+    case FieldType::Bool: return out + (*static_cast<bool *>(ref.ptr) ? "true" : "false");
+    case FieldType::StopCrit: return out + enum_name(*static_cast<PANOCStopCrit *>(ref.ptr));
+    }
+    return {};
 }
 
 } // namespace pantr::host

@@ -1,13 +1,14 @@
 """The batches of BASELINE.json / SURVEY.md section 8(d), as host-side enumerators.
 
-  dodo_pantr_tasks      the PANTR rows of new-benchmarks-paper/dodo.py:69-111 (problem x
-                        {warm, cold} x horizon 10..60) with their option lists and output names
+  dodo_tasks            the rows of new-benchmarks-paper/dodo.py:69-111 for one solver (problem x
+                        {warm, cold} x horizon 10..60) with their option lists and output names;
+                        dodo_pantr_tasks: the PANTR rows
   config5_disturbances  the 1024 synthetic disturbances of config 5 (std::mt19937_64(12345) ->
                         uniform_real_distribution<double>(-1, 1), three draws per instance)
 """
 import numpy as np
 
-from . import DODO_HANGING_CHAIN_OPTS, DODO_PANTR_OPTS
+from . import DODO_HANGING_CHAIN_OPTS, DODO_OPTS
 
 NUM_SIM = 60          # dodo.py:10
 HORIZONS = tuple(range(10, 61, 10))  # dodo.py:5,9,71
@@ -18,25 +19,32 @@ def problem_name(problem, warm, solver, horizon, num_sim=NUM_SIM):
     return f"mpc-{problem}-{horizon},{num_sim}-{'warm' if warm else 'cold'}-{solver}"
 
 
-def dodo_pantr_tasks(problem="hanging_chain", horizons=HORIZONS, num_sim=NUM_SIM):
-    """PANTR tasks of mpc_benchmark(problem), dodo.py:69-111, in its enumeration order."""
+def dodo_tasks(problem="hanging_chain", method="pantr", horizons=HORIZONS, num_sim=NUM_SIM):
+    """Tasks of mpc_benchmark(problem) for one solver (pantr, panoc, strucpanoc), dodo.py:69-111,
+    in its enumeration order."""
     tasks = []
     for warm in (True, False):
         for horizon in horizons:
-            opts = list(DODO_PANTR_OPTS)
+            opts = list(DODO_OPTS[method][1:])                  # dodo.py:24-40 (method= goes first below)
             if problem == "hanging_chain":
                 opts += list(DODO_HANGING_CHAIN_OPTS)          # dodo.py:94-95
             else:
                 opts += ["num_dist=0", "solver.max_iter=250"]   # dodo.py:97-100
             if problem == "realistic_quadcopter":
-                opts += ["accel.tol_scale=1", "alm.initial_tolerance=1e-1"]  # dodo.py:101-105
-            name = problem_name(problem, warm, "pantr", horizon, num_sim)
+                if method == "pantr":
+                    opts += ["accel.tol_scale=1"]               # dodo.py:101-103
+                opts += ["alm.initial_tolerance=1e-1"]          # dodo.py:104-105
+            name = problem_name(problem, warm, method, horizon, num_sim)
             # run-single-mpc-exp.sh:19
-            argv = [problem, str(horizon), "ss2p", "method=pantr", f"num_sim={num_sim}",
+            argv = [problem, str(horizon), "ss2p", f"method={method}", f"num_sim={num_sim}",
                     f"results_name={name}", f"warm={'true' if warm else 'false'}"] + opts
-            tasks.append(dict(name=name, problem=problem, horizon=horizon, warm=warm,
+            tasks.append(dict(name=name, problem=problem, method=method, horizon=horizon, warm=warm,
                               num_sim=num_sim, argv=argv))
     return tasks
+
+
+def dodo_pantr_tasks(problem="hanging_chain", horizons=HORIZONS, num_sim=NUM_SIM):
+    return dodo_tasks(problem, "pantr", horizons, num_sim)
 
 
 class MT19937_64:

@@ -9,6 +9,7 @@
    checks that the batched solutions equal the closed-loop ones, and reports steps/s.
 
     python scripts/run_dodo_pantr.py --outdir output [--problem hanging_chain] [--num-sim 60]
+                                     [--method pantr|panoc|strucpanoc]   (the comparators: dodo.py:34-40)
 """
 import argparse
 import importlib.util
@@ -50,10 +51,11 @@ def main():
     ap.add_argument("--problem", default="hanging_chain")
     ap.add_argument("--num-sim", type=int, default=workloads.NUM_SIM)
     ap.add_argument("--horizons", type=int, nargs="*", default=list(workloads.HORIZONS))
+    ap.add_argument("--method", default="pantr", choices=sorted(pa.DODO_OPTS))
     args = ap.parse_args()
     os.makedirs(args.outdir, exist_ok=True)
-    tasks = workloads.dodo_pantr_tasks(args.problem, args.horizons, args.num_sim)
-    summary = {"tasks": [], "problem": args.problem}
+    tasks = workloads.dodo_tasks(args.problem, args.method, args.horizons, args.num_sim)
+    summary = {"tasks": [], "problem": args.problem, "method": args.method}
 
     # ---- 1. closed loops through the CLI, one process per task as doit runs them ----
     al = args.problem != "hanging_chain"  # general constraints: the CLI replays each task itself
@@ -85,10 +87,10 @@ def main():
     # ---- 2. the same steps as batches, one launch per horizon ----
     total_steps, total_kernel_s = 0, 0.0
     for N in args.horizons:
-        warm = load_results(args.outdir, workloads.problem_name(args.problem, True, "pantr", N, args.num_sim))
-        cold = load_results(args.outdir, workloads.problem_name(args.problem, False, "pantr", N, args.num_sim))
+        warm = load_results(args.outdir, workloads.problem_name(args.problem, True, args.method, N, args.num_sim))
+        cold = load_results(args.outdir, workloads.problem_name(args.problem, False, args.method, N, args.num_sim))
         ns = args.num_sim
-        batch = pa.PantrBatch(args.problem, N, 2 * ns, opts=pa.DODO_PANTR_OPTS)
+        batch = pa.PantrBatch(args.problem, N, 2 * ns, opts=pa.DODO_OPTS[args.method])
         sol_w, sol_c = warm["inputs"].T, cold["inputs"].T
         guess_w = np.vstack([first_guess(batch, 5, (-1.0, 1.0, 1.0))[None, :],
                              np.hstack([sol_w[:-1, batch.nu:], sol_w[:-1, -batch.nu:]])])

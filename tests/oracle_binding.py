@@ -230,6 +230,18 @@ def mpc(N, num_sim, warm, num_dist=5, u_dist=(-1.0, 1.0, 1.0), params=None):
     return states, inputs, guesses, [s.as_dict() for s in stats]
 
 
+def lbfgs_apply(S, Y, q, memory, mask=None):
+    """H q by the oracle's two-loop recursion over the pairs (S[i], Y[i]), oldest first."""
+    S, Y = np.ascontiguousarray(S, float), np.ascontiguousarray(Y, float)
+    out = np.array(q, dtype=float, copy=True)
+    f = lib().oracle_lbfgs_apply
+    f.argtypes = [C.c_int, C.c_int, C.c_int, _pd, _pd, _pd, C.c_void_p]
+    f.restype = C.c_int
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    ok = f(S.shape[1], memory, S.shape[0], S, Y, out, None if m is None else m.ctypes.data_as(C.c_void_p))
+    return bool(ok), out
+
+
 def steihaug_dense(H, g, radius, tol_scale=1.0, tol_scale_root=0.5, max_iter_factor=1.0):
     n = len(g)
     step = np.zeros(n)

@@ -12,6 +12,7 @@ import pytest
 
 import oracle_binding as ob
 import pantr_amd as pa
+from pantr_amd import workloads
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -49,6 +50,26 @@ def test_driver_closed_loop_matches_oracle(tmp_path, warm):
     assert res["problem"] == "hanging_chain" and res["nvar"] == 3 * N and res["ncon"] == 0
     assert res["horizon"] == N and res["formulation"] == "ss2p" and res["second_order"] is False
     assert res["solver"].startswith("ALMSolver<PANTRSolver<") and "method=pantr" in res["opts"]
+
+
+@pytest.mark.parametrize("method,solver", [("panoc", "ALMSolver<PANOCSolver<LBFGSDirection>>"),
+                                           ("strucpanoc", "ALMSolver<PANOCSolver<StructuredLBFGSDirection>>")])
+def test_driver_comparators_closed_loop_matches_oracle(tmp_path, method, solver):
+    """Row f4 through the CLI: method=panoc / strucpanoc with the options of dodo.py:34-40."""
+    N, num_sim = 10, 8
+    task = [t for t in workloads.dodo_tasks("hanging_chain", method, [N], num_sim) if t["warm"]][0]
+    r = subprocess.run([DRIVER] + task["argv"] + ["replay=true"], cwd=tmp_path, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stderr.count("Converged") == num_sim + 1 and "identical to the closed loop" in r.stdout
+    res = load_results(str(tmp_path), task["name"])
+    states, inputs, guesses, stats = ob.mpc(N, num_sim, True, params=ob.dodo_params(method))
+    assert np.array_equal(res["states"].T, states) and np.array_equal(res["inputs"].T, inputs)
+    ev = res["evaluations"]
+    assert ev["hess_ψ_prod"] == 0 and ev["ψ"] == sum(s["n_psi"] for s in stats)
+    assert ev["ψ_grad_ψ"] == sum(s["n_psi_grad_psi"] for s in stats)
+    assert ev["grad_L"] == sum(s["n_grad_L"] for s in stats)
+    assert res["solver"] == solver and f"method={method}" in res["opts"]
 
 
 def test_driver_errors(tmp_path):

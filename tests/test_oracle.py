@@ -351,3 +351,72 @@ def test_quadcopter_closed_loop():
     target = np.array([0.25, 0.25, 0.5])
     assert np.linalg.norm(st_w[-1, :3] - target) < np.linalg.norm(st_w[0, :3] - target)
     assert np.all(st_w[:, 0] ** 2 + st_w[:, 1] ** 2 >= 0.01 - 1e-6)   # stays outside the cylinder
+
+
+# ---- comparators: PANOC+ with L-BFGS / structured L-BFGS ----------
+def _dense_lbfgs(S, Y, q, gamma):
+    """H q with H from the BFGS recursion H+ = (I - rho s y')H(I - rho y s') + rho s s', H0 = gamma I."""
+    n = len(q)
+    H = gamma * np.eye(n)
+    for s_, y_ in zip(S, Y):
+        rho = 1.0 / (y_ @ s_)
+        V = np.eye(n) - rho * np.outer(y_, s_)
+        H = V.T @ H @ V + rho * np.outer(s_, s_)
+    return H @ q
+
+
+@pytest.mark.parametrize("memory,count", [(5, 3), (4, 9)])
+def test_lbfgs_two_loop_matches_dense_bfgs(rng, memory, count):
+    """The two-loop recursion (alpaqa::LBFGS::apply) against the dense recursion it abbreviates;
+    count > memory exercises the ring (only the newest `memory` pairs count)."""
+    n = 12
+    A = rng.standard_normal((n, n))
+    A = A @ A.T + n * np.eye(n)                       # SPD: y = A s has positive curvature
+    S = rng.standard_normal((count, n))
+    Y = S @ A
+    q = rng.standard_normal(n)
+    ok, Hq = ob.lbfgs_apply(S, Y, q, memory)
+    keep = slice(max(0, count - memory), count)
+    gamma = (Y[-1] @ S[-1]) / (Y[-1] @ Y[-1])         # step size from the newest pair
+    assert ok and np.allclose(Hq, _dense_lbfgs(S[keep], Y[keep], q, gamma), rtol=1e-10, atol=1e-12)
+    # on an index set J: the same recursion on the sub-vectors, nothing touched outside J
+    mask = np.arange(n) % 3 != 0
+    ok, HqJ = ob.lbfgs_apply(S, Y, q, memory, mask)
+    SJ, YJ = S[keep][:, mask], Y[keep][:, mask]
+    gammaJ = (YJ[-1] @ SJ[-1]) / (YJ[-1] @ YJ[-1])
+    assert ok and np.array_equal(HqJ[~mask], q[~mask])
+    assert np.allclose(HqJ[mask], _dense_lbfgs(SJ, YJ, q[mask], gammaJ), rtol=1e-10, atol=1e-12)
+    assert ob.lbfgs_apply(S[:0], Y[:0], q, memory)[0] is False  # no pairs: no direction
+
+
+@pytest.mark.parametrize("method", ["panoc", "strucpanoc"])
+def test_comparators_reach_the_pantr_optimum(method):
+    N = 20
+    x0 = disturbed_state()
+    u_ref, st_ref, _ = ob.solve(N, x0, np.zeros(NU * N), ob.dodo_params())
+    u, st, tr = ob.solve(N, x0, np.zeros(NU * N), ob.dodo_params(method), trace_cap=2000)
+    assert ob.STATUS[st["status"]] == "Converged" and st["eps"] <= 1e-8
+    assert abs(st["final_psi"] - st_ref["final_psi"]) <= 1e-10 * abs(st_ref["final_psi"])
+    assert np.abs(u - u_ref).max() <= 1e-6 and np.all(np.abs(u) <= 1.0)
+    assert st["n_hess_psi_prod"] == 0 and st["iterations"] > st_ref["iterations"]
+    assert st["tau_1_accepted"] + st["linesearch_failures"] <= st["count_tau"] <= st["iterations"]
+    # the line search makes the forward-backward envelope decrease monotonically (col 5 = fbe)
+    fbe = tr[:, 5]
+    assert np.all(np.diff(fbe) <= 1e-9 * (1 + np.abs(fbe[:-1])))
+    assert len(tr) == st["iterations"] + 1 and tr[-1, 0] == st["eps"]
+
+
+@pytest.mark.parametrize("method", ["panoc", "strucpanoc"])
+def test_comparators_alm_reaches_kkt_point(method):
+    problem, N = "quadcopter", 12
+    x0, u0 = ob.quad_initial_state(), ob.quad_initial_guess(N)
+    u, y, st = ob.quad_solve(problem, N, x0, u0, params=ob.quad_dodo_params(problem, method))
+    assert ob.STATUS[st["status"]] == "Converged" and st["eps"] <= 1e-8 and st["delta"] <= 1e-8
+    f, g = ob.quad_f_g(problem, N, x0, u)
+    lb = np.tile([-np.pi / 2, -np.pi / 2, np.cos(0.55), -np.inf], N + 1)
+    ub = np.tile([np.pi / 2, np.pi / 2, np.inf, 0.0], N + 1)
+    assert np.abs(g - np.clip(g, lb, ub)).max() <= 1e-7
+    u_ref, y_ref, st_ref = ob.quad_solve(problem, N, x0, u0)
+    f_ref, _ = ob.quad_f_g(problem, N, x0, u_ref)
+    assert abs(f - f_ref) <= 1e-6 * abs(f_ref)  # same local solution as PANTR
+
