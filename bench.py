@@ -164,7 +164,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B),
-                "kernel": "pantr_solve_kernel<ChainModel>", "kernel_ms": k_ms,
+                "kernel": "pantr_solve_kernel<ChainModel, 0>", "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": int(alg_bytes),
             },
         }

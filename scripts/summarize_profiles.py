@@ -21,7 +21,7 @@ os.makedirs(dst, exist_ok=True)
 KERNEL = "pantr_solve_kernel"
 
 summary = {"tag": tag, "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
-           "kernel": "pantr::pantr_solve_kernel<pantr::ChainModel>"}
+           "kernel": "pantr::pantr_solve_kernel<pantr::ChainModel, 0>"}
 stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 for r in csv.DictReader(open(stats)):
