@@ -184,10 +184,10 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
         return rc;
     const int method = static_cast<int>(b->opts.method);
     double *d_lbfgs  = nullptr;
-    if (method != 0) { // L-BFGS rings in HBM; rho and alpha in the ten spare LDS vector slots
+    if (method != 0) { // L-BFGS rings in HBM; rho and alpha in the nine spare LDS vector slots 10..18
         const size_t mem = b->opts.lbfgs.memory;
-        if (2 * mem > (size_t)10 * b->npad)
-            return fail(PANTR_ERR_OUT_OF_RANGE, "accel.memory too large for the LDS of this horizon (2 memory <= 10 n_pad)");
+        if (2 * mem > (size_t)9 * b->npad)
+            return fail(PANTR_ERR_OUT_OF_RANGE, "accel.memory too large for the LDS of this horizon (2 memory <= 9 n_pad)");
         const size_t need = (size_t)b->maxB * 2 * mem * b->npad;
         if (need > b->lbfgs_doubles) {
             if (b->d_lbfgs)

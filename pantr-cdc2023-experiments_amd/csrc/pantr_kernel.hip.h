@@ -61,8 +61,12 @@ struct DeviceStats {
 };
 
 constexpr int TRACE_COLS = 11;
-constexpr int NUM_VEC    = 21; ///< 20 working vectors + the in/out vector of the inner solver
-constexpr int S_XIO      = 20;
+constexpr int NUM_VEC    = 20; ///< working vectors of the inner solvers (slots S_* inside them)
+/// The in/out vector of an inner solve shares the slot of the direction's scratch vector (PANTR:
+/// the CG step; PANOC: unused): it is read before the first and written after the last use of
+/// that scratch.  20 slots x 192 doubles + the 10 KiB landing buffers = 40 KiB at N = 60: four
+/// hanging-chain instances per CU, one per SIMD.
+constexpr int S_XIO      = 19;
 
 struct SolveArgs {
     int32_t B, N, n, npad, nj;
