@@ -138,19 +138,64 @@ __device__ __forceinline__ double wave_shift4(double v) {
     return __hiloint2double(hi, lo);
 }
 
-/// 64-lane butterfly all-reduce: masks 32, 16, 8, 4, 2, 1; a + partner at every level, so
-/// all lanes finish with bit-identical sums.
+/// 64-lane xor-butterfly all-reduce, masks 32, 16, 8, 4, 2, 1 (a + partner at every level, so all
+/// lanes finish with bit-identical sums), without the LDS crossbar: v_permlane32_swap and
+/// v_permlane16_swap (gfx950) across rows, DPP moves inside a 16-lane row.  After a permlane swap
+/// of a value with itself the two results hold "own" and "partner" in one order or the other on
+/// every row, and own + partner is commutative.  ~190 cycles against 477 for six ds_bpermute
+/// levels (scripts/microbench/wave_sum_test.hip).  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ double dpp_partner(double v) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+/// {a, b} = {own, value of the lane 32 (SWAP32) or 16 lanes away} on every lane.
+template <bool SWAP32>
+__device__ __forceinline__ void row_partner(double v, double &a, double &b) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (SWAP32) {
+        auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        a = __hiloint2double(h[0], l[0]);
+        b = __hiloint2double(h[1], l[1]);
+    } else {
+        auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        a = __hiloint2double(h[0], l[0]);
+        b = __hiloint2double(h[1], l[1]);
+    }
+}
+/// Value of lane ^ 4: four lanes up for lanes with bit 2 clear, four lanes down for the others.
+__device__ __forceinline__ double xor4_partner(double v) {
+    double up = dpp_partner<0x104>(v), down = dpp_partner<0x114>(v); // row_shl:4, row_shr:4
+    return (threadIdx.x & 4) ? down : up;
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v = v + lane_read(v, (int)(threadIdx.x & 63) ^ m);
+#ifdef PANTR_TIMING_NO_SHUFFLE // timing-only build: results are wrong
+    return v * 64.0;
+#endif
+    double a, b;
+    row_partner<true>(v, a, b);
+    v = a + b;
+    row_partner<false>(v, a, b);
+    v = a + b;
+    v = v + dpp_partner<0x128>(v); // row_ror:8 = lane ^ 8
+    v = v + xor4_partner(v);
+    v = v + dpp_partner<0x4E>(v); // quad_perm [2,3,0,1]
+    v = v + dpp_partner<0xB1>(v); // quad_perm [1,0,3,2]
     return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v = fmax(v, lane_read(v, (int)(threadIdx.x & 63) ^ m));
-    return v;
+    double a, b;
+    row_partner<true>(v, a, b);
+    v = fmax(a, b);
+    row_partner<false>(v, a, b);
+    v = fmax(a, b);
+    v = fmax(v, dpp_partner<0x128>(v));
+    v = fmax(v, xor4_partner(v));
+    v = fmax(v, dpp_partner<0x4E>(v));
+    return fmax(v, dpp_partner<0xB1>(v));
 }
 
 /// Order this wavefront's LDS/global accesses: what any lane wrote before is visible to every
