@@ -305,19 +305,17 @@ struct WaveProblem {
         uint32_t mask = 0;
         int cnt       = 0;
         for (int j = 0; j < nj; ++j) {
-            int i = j * WAVE + L.l;
+            int i   = j * WAVE + L.l;
+            bool in = false;
             if (i < n) {
                 int c      = i % M::nu;
                 double xfw = x[i] - gamma * grad[i];
-                bool in    = M::u_lb(c) < xfw && xfw < M::u_ub(c);
-                mask |= (in ? 1u : 0u) << j;
-                cnt += in ? 1 : 0;
+                in = M::u_lb(c) < xfw && xfw < M::u_ub(c);
             }
+            mask |= (in ? 1u : 0u) << j;
+            cnt += __builtin_popcountll(__ballot(in ? 1 : 0)); // wave-uniform count, no reduction needed
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1)
-            cnt += __shfl_xor(cnt, m);
-        nJ = uniform(cnt);
+        nJ = cnt;
         return mask;
     }
 };
