@@ -14,6 +14,11 @@ provide the replay workload of BASELINE.json configs[1]:
       sol[300,180]   its solution, iters/cg/hv: its counters
   mpc_hanging_chain_N{10,20}_cold8.npz   small closed loops (cold) for CPU-side regression
   problem_functions_N7.npz               psi, grad psi, Hv at seeded points
+  solves_rows_f1_f4.npz                  rows f1/f4 of SURVEY.md section 8: one cold solve per
+      (problem, method) with the option sets of dodo.py:12-40,97-105 -- hanging_chain N=20 and
+      quadcopter / realistic_quadcopter N=12 x {pantr, panoc, strucpanoc}: initial state, solution,
+      multipliers and the solver's counters; plus psi, grad psi, yhat and Hv of the two quadcopter
+      models at a seeded point
 
 Usage: python tests/golden/make_golden.py
 """
@@ -66,7 +71,54 @@ def main():
         Hv.append(ob.hess_prod(N, x0, u[i], v[i]))
     np.savez_compressed(os.path.join(HERE, "problem_functions_N7.npz"), N=N, x0=x0, u=u, v=v,
                         psi=np.array(psi), grad=np.array(grad), Hv=np.array(Hv))
+    rows_f1_f4()
+
+
+ROWS = [(p, m) for p in ("hanging_chain", "quadcopter", "realistic_quadcopter")
+        for m in ("pantr", "panoc", "strucpanoc")]
+COUNTERS = ("status", "iterations", "outer_iterations", "n_psi", "n_psi_grad_psi", "n_grad_L",
+            "n_hess_psi_prod", "n_prox_grad_step", "lbfgs_rejected", "linesearch_backtracks")
+
+
+def solve_row(problem, method):
+    """One cold solve from the benchmark's initial state; returns x0, u, y, counters."""
+    if problem == "hanging_chain":
+        N = 20
+        x0 = ob.initial_state()
+        for _ in range(5):
+            x0 = ob.simulate(x0, (-1.0, 1.0, 1.0))
+        u, st, _ = ob.solve(N, x0, np.zeros(3 * N), ob.dodo_params(method))
+        y = np.zeros(0)
+    else:
+        N = 12
+        x0 = ob.quad_initial_state()
+        u, y, st = ob.quad_solve(problem, N, x0, ob.quad_initial_guess(N), params=ob.quad_dodo_params(problem, method))
+    return N, x0, u, y, np.array([st[k] for k in COUNTERS], np.int64), np.array([st["eps"], st["final_psi"]])
+
+
+def rows_f1_f4():
+    out = {}
+    for problem, method in ROWS:
+        N, x0, u, y, cnt, fl = solve_row(problem, method)
+        key = f"{problem}.{method}"
+        out.update({f"{key}.N": N, f"{key}.x0": x0, f"{key}.u": u, f"{key}.y": y, f"{key}.counters": cnt,
+                    f"{key}.eps_psi": fl})
+        print(f"{key}: N={N} status {cnt[0]} iterations {cnt[1]} outer {cnt[2]}")
+    rng = np.random.default_rng(11)
+    for problem in ("quadcopter", "realistic_quadcopter"):
+        N, n, m = 9, 36, 40
+        x0 = ob.quad_initial_state() + 0.05 * rng.standard_normal(9)
+        u = ob.quad_initial_guess(N) + 0.3 * rng.standard_normal(n)
+        y, Sig, v = rng.standard_normal(m), 10 ** rng.uniform(0, 3, m), rng.standard_normal(n)
+        psi, grad, yhat = ob.quad_psi_grad(problem, N, x0, y, Sig, u)
+        out.update({f"{problem}.fun.x0": x0, f"{problem}.fun.u": u, f"{problem}.fun.y": y, f"{problem}.fun.Sig": Sig,
+                    f"{problem}.fun.v": v, f"{problem}.fun.psi": psi, f"{problem}.fun.grad": grad,
+                    f"{problem}.fun.yhat": yhat, f"{problem}.fun.Hv": ob.quad_hess_prod(problem, N, x0, y, Sig, u, v)})
+    np.savez_compressed(os.path.join(HERE, "solves_rows_f1_f4.npz"), **out)
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rows":
+        rows_f1_f4()
+        sys.exit(0)
     main()

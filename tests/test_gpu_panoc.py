@@ -2,6 +2,8 @@
 with the structured L-BFGS direction (drivers/mpc-driver.cpp:371-384, dodo.py:34-40), the HIP path
 through the C ABI against the CPU oracle.  Same bar as test_gpu_parity.py: bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -112,3 +114,44 @@ def test_unsupported_comparator_options_fail_loudly():
         batch.close()
     with pytest.raises(pa.PantrError):
         pa.PantrBatch("hanging_chain", 5, 1, opts=("method=fbetrust",))
+
+
+# ---- the committed fixtures of rows f1/f4, without consulting the oracle -----------------------
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "solves_rows_f1_f4.npz")
+ROW_COUNTERS = ("status", "iterations", "outer_iterations", "n_psi", "n_psi_grad_psi", "n_grad_L",
+                "n_hess_psi_prod", "n_prox_grad_step", "lbfgs_rejected", "linesearch_backtracks")
+
+
+@pytest.mark.parametrize("problem", ["hanging_chain", "quadcopter", "realistic_quadcopter"])
+@pytest.mark.parametrize("method", ["pantr", "panoc", "strucpanoc"])
+def test_golden_rows_f1_f4_on_the_device(problem, method):
+    d = np.load(GOLDEN)
+    key = f"{problem}.{method}"
+    N, x0 = int(d[f"{key}.N"]), d[f"{key}.x0"][None, :]
+    if problem == "hanging_chain":
+        b = pa.PantrBatch(problem, N, 1, opts=pa.DODO_OPTS[method])
+        u, st = b.solve(x0, np.zeros((1, NU * N)))
+        y = np.zeros((1, 0))
+    else:
+        opts = list(pa.DODO_OPTS[method]) + ["solver.max_iter=250"]
+        if problem == "realistic_quadcopter":
+            opts += ["alm.initial_tolerance=1e-1"] + (["accel.tol_scale=1"] if method == "pantr" else [])
+        b = pa.PantrBatch(problem, N, 1, opts=opts)
+        u, y, st = b.solve_al(x0, b.initial_guess()[None, :])
+    b.close()
+    assert np.array_equal(u[0], d[f"{key}.u"]) and np.array_equal(y[0], d[f"{key}.y"])
+    assert [int(st[k][0]) for k in ROW_COUNTERS] == list(d[f"{key}.counters"])
+    assert st["eps"][0] == d[f"{key}.eps_psi"][0] and st["final_psi"][0] == d[f"{key}.eps_psi"][1]
+
+
+@pytest.mark.parametrize("problem", ["quadcopter", "realistic_quadcopter"])
+def test_golden_quadcopter_functions_on_the_device(problem):
+    d = np.load(GOLDEN)
+    g = lambda k: d[f"{problem}.fun.{k}"]  # noqa: E731
+    b = pa.PantrBatch(problem, 9, 1)
+    psi, grad, yhat = b.eval_psi_grad_psi_al(g("x0")[None], g("u")[None], g("y")[None], g("Sig")[None])
+    Hv = b.eval_hess_psi_prod_al(g("x0")[None], g("u")[None], g("y")[None], g("Sig")[None], g("v")[None])
+    b.close()
+    assert psi[0] == g("psi") and np.array_equal(grad[0], g("grad")) and np.array_equal(yhat[0], g("yhat"))
+    assert np.array_equal(Hv[0], g("Hv"))
+

@@ -420,3 +420,36 @@ def test_comparators_alm_reaches_kkt_point(method):
     f_ref, _ = ob.quad_f_g(problem, N, x0, u_ref)
     assert abs(f - f_ref) <= 1e-6 * abs(f_ref)  # same local solution as PANTR
 
+
+# ---- committed fixtures of the rows built around the path (f1, f4) --------
+ROWS_F = [(p, m) for p in ("hanging_chain", "quadcopter", "realistic_quadcopter")
+          for m in ("pantr", "panoc", "strucpanoc")]
+ROW_COUNTERS = ("status", "iterations", "outer_iterations", "n_psi", "n_psi_grad_psi", "n_grad_L",
+                "n_hess_psi_prod", "n_prox_grad_step", "lbfgs_rejected", "linesearch_backtracks")
+
+
+@pytest.mark.parametrize("problem,method", ROWS_F)
+def test_golden_rows_f1_f4(golden_dir, problem, method):
+    """The oracle reproduces tests/golden/solves_rows_f1_f4.npz (make_golden.py rows) bit for bit."""
+    d = np.load(os.path.join(golden_dir, "solves_rows_f1_f4.npz"))
+    key = f"{problem}.{method}"
+    N, x0 = int(d[f"{key}.N"]), d[f"{key}.x0"]
+    if problem == "hanging_chain":
+        u, st, _ = ob.solve(N, x0, np.zeros(NU * N), ob.dodo_params(method))
+        y = np.zeros(0)
+    else:
+        u, y, st = ob.quad_solve(problem, N, x0, ob.quad_initial_guess(N), params=ob.quad_dodo_params(problem, method))
+    assert np.array_equal(u, d[f"{key}.u"]) and np.array_equal(y, d[f"{key}.y"])
+    assert [st[k] for k in ROW_COUNTERS] == list(d[f"{key}.counters"])
+    assert st["eps"] == d[f"{key}.eps_psi"][0] and st["final_psi"] == d[f"{key}.eps_psi"][1]
+    assert st["status"] == 1 and st["eps"] <= 1e-8
+
+
+@pytest.mark.parametrize("problem", ["quadcopter", "realistic_quadcopter"])
+def test_golden_quadcopter_functions(golden_dir, problem):
+    d = np.load(os.path.join(golden_dir, "solves_rows_f1_f4.npz"))
+    g = lambda k: d[f"{problem}.fun.{k}"]  # noqa: E731
+    psi, grad, yhat = ob.quad_psi_grad(problem, 9, g("x0"), g("y"), g("Sig"), g("u"))
+    assert psi == g("psi") and np.array_equal(grad, g("grad")) and np.array_equal(yhat, g("yhat"))
+    assert np.array_equal(ob.quad_hess_prod(problem, 9, g("x0"), g("y"), g("Sig"), g("u"), g("v")), g("Hv"))
+
