@@ -66,9 +66,9 @@ TRACE_COLS = ("eps", "psi", "pnorm", "gamma", "radius", "rho", "q_model", "fbe",
 
 def build(force=False):
     """Compile the oracle with its own Makefile (building the checker is not using it)."""
-    if force or not os.path.exists(LIB_PATH):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "-B" if force else "-s"],
-                              stdout=subprocess.DEVNULL)
+    # always through make: a library older than its sources would silently test the wrong arithmetic
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"] + (["-B"] if force else []),
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return LIB_PATH
 
 
