@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent passes in flight per GPU, each on its own HIP stream and solver handle "
+                         "(default 1: one pass after the other, the configuration the roofline line describes)")
     args = ap.parse_args()
 
     import torch
@@ -108,32 +111,39 @@ def main():
     dev = torch.device("cuda", local_rank)
     x0 = torch.from_numpy(x0_h).to(dev)
     guess = torch.from_numpy(guess_h).to(dev)
-    u = torch.empty_like(guess)
-    stats_t = torch.zeros(B * pa.STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    S = max(1, args.streams)
+    us = [torch.empty_like(guess) for _ in range(S)]
+    stats_ts = [torch.zeros(B * pa.STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(S)]
+    batches = [pa.PantrBatch("hanging_chain", HORIZON, B, device=local_rank, opts=pa.DODO_PANTR_OPTS)
+               for _ in range(S)]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+    u, stats_t, batch = us[0], stats_ts[0], batches[0]
 
-    batch = pa.PantrBatch("hanging_chain", HORIZON, B, device=local_rank,
-                          opts=pa.DODO_PANTR_OPTS)
-    stream = torch.cuda.current_stream()
-
-    def one_pass():
-        u.copy_(guess)  # device-to-device reset of the in/out guesses
-        batch.solve_device(B, x0.data_ptr(), u.data_ptr(), stats_t.data_ptr(), stream.cuda_stream)  # m = 0: no y
+    def one_pass(i=0):
+        k = i % S
+        with torch.cuda.stream(streams[k]):
+            us[k].copy_(guess)  # device-to-device reset of the in/out guesses
+            batches[k].solve_device(B, x0.data_ptr(), us[k].data_ptr(), stats_ts[k].data_ptr(),
+                                    streams[k].cuda_stream)  # m = 0: no y
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_pass()
+    for i in range(max(args.warmup, S if S > 1 else 0)):
+        one_pass(i)
     barrier()
     kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_pass()
-        kernel_ms.append(batch.last_kernel_ms())  # HIP events on the launch stream
+    for i in range(args.steps):
+        one_pass(i)
+        if S == 1:
+            kernel_ms.append(batch.last_kernel_ms())  # HIP events on the launch stream (synchronises)
     barrier()
     elapsed = time.perf_counter() - t0
+    if S > 1:  # the last launch of every stream (durations overlap: they are latencies, not shares)
+        kernel_ms = [b.last_kernel_ms() for b in batches[:min(S, args.steps)]]
     elapsed = sharding.max_over_ranks(elapsed, dev)  # MAX over ranks (identity at N = 1)
 
     stats = np.frombuffer(stats_t.cpu().numpy().tobytes(), dtype=pa.STATS_DTYPE)
@@ -157,7 +167,7 @@ def main():
                 "workload": "hanging_chain horizon=60 replay batch: 300 MPC time steps of one closed "
                             "loop (num_sim=300 num_dist=5 u_dist=-1,1,1), each solved warm and cold = "
                             "600 PANTR solves per GPU per pass, tolerance 1e-8, dodo.py PANTR options",
-                "instances_per_gpu": B, "horizon": HORIZON, "n": n,
+                "instances_per_gpu": B, "horizon": HORIZON, "n": n, "streams": S,
                 "converged": converged, "max_abs_dev_from_recorded_warm_solutions": max_dev,
                 "vs_baseline_ref": "BASELINE.md 1.1: 4.21 steps/s (alpaqa PANTR cold+warm, unstated CPU, 1 thread)",
             },
@@ -173,7 +183,8 @@ def main():
             cores = min(16, len(os.sched_getaffinity(0)))
             line["cpu_baseline"] = cpu_baseline(x0_h, guess_h, cores)
         print(json.dumps(line), flush=True)
-    batch.close()
+    for b in batches:
+        b.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
