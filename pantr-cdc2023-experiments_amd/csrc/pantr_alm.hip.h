@@ -367,19 +367,19 @@ struct ScalarALProblem {
         wait_vmem(); // the products read the tape back through global loads
     }
 
-    /// The first CNT elements of this lane's row (lane & 15) of a tape block.  Only lanes 0..15
-    /// issue the loads (the other lanes own nothing and would fetch the same bytes again).
+    /// The first CNT elements of this lane's row (lane & 15) of a tape block.  Lanes 16..63 own
+    /// nothing and fetch the same bytes as lanes 0..15 (same cache lines; masking them off would
+    /// put a branch around every group of loads and split the stage bodies into separate
+    /// scheduling regions).
     template <int CNT>
     __device__ __forceinline__ void load_row(const double *block, double (&o)[CNT]) const {
         const double2 *p = reinterpret_cast<const double2 *>(block) + (lane & (ROW - 1));
-        if (lane < ROW) {
 #pragma unroll
-            for (int i = 0; i < (CNT + 1) / 2; ++i) {
-                double2 t = p[i * ROW];
-                o[2 * i]  = t.x;
-                if (2 * i + 1 < CNT)
-                    o[2 * i + 1] = t.y;
-            }
+        for (int i = 0; i < (CNT + 1) / 2; ++i) {
+            double2 t = p[i * ROW];
+            o[2 * i]  = t.x;
+            if (2 * i + 1 < CNT)
+                o[2 * i + 1] = t.y;
         }
     }
     /// Sum of products in four partial sums (term t goes to partial t mod 4, each an fma chain from
@@ -447,37 +447,66 @@ struct ScalarALProblem {
     }
     __device__ __forceinline__ void hess_prod(const double *, const double *v, double *Hv) const {
         wave_sync();
+        const int rem = N % DEPTH, Nfull = N - rem; // full groups run branch-free, the rest one by one
         // ---- forward: lane i < nx owns x_t[i] ----
         {
-            double xt = 0.0, A[DEPTH][nz];
+            double xt = 0.0;
+            auto stage = [&](int k, const double (&Arow)[nz]) {
+                if (lane < nx)
+                    Xt[k * nx + lane] = xt; // for the backward sweep
+                Dot4 acc;
+                add_bcast_all<0>(acc, Arow, xt);
+                add_all<nx, nu>(acc, Arow + nx, v + nu * k);
+                xt = acc.sum();
+            };
+            double A[DEPTH][nz];
 #pragma unroll
             for (int j = 0; j < DEPTH; ++j)
                 load_row(stage_block(j, 0), A[j]);
-            for (int k0 = 0; k0 < N; k0 += DEPTH) {
+            for (int k0 = 0; k0 < Nfull; k0 += DEPTH) {
 #pragma unroll
                 for (int j = 0; j < DEPTH; ++j) {
-                    const int k = k0 + j;
-                    if (k < N) {
-                        if (lane < nx)
-                            Xt[k * nx + lane] = xt; // for the backward sweep
-                        Dot4 acc;
-                        add_bcast_all<0>(acc, A[j], xt);
-                        add_all<nx, nu>(acc, A[j] + nx, v + nu * k);
-                        xt = acc.sum();
-                    }
-                    load_row(stage_block(k + DEPTH, 0), A[j]);
+                    stage(k0 + j, A[j]);
+                    load_row(stage_block(k0 + j + DEPTH, 0), A[j]);
                 }
+            }
+            for (int k = Nfull; k < N; ++k) {
+                double T[nz];
+                load_row(stage_block(k, 0), T);
+                stage(k, T);
             }
             if (lane < nx)
                 Xt[N * nx + lane] = xt;
+            wait_vmem(); // the clamped prefetches past the last stage
             wave_sync();
         }
         // ---- backward: lane l < nz owns component l of [lam_t ; Hv_k] ----
-        double lt, C[DEPTH][nz], Bc[DEPTH][nx];
+        // z = (x_t of the stage, v_k) does not depend on the previous stage: it is read from LDS one
+        // stage ahead into the other of two register sets
+        double lt;
+        auto load_z = [&](int k, double (&z)[nz]) {
+            k = k < 0 ? 0 : k;
 #pragma unroll
-        for (int j = 0; j < DEPTH; ++j) {
-            load_row(stage_block(N - 1 - j, 2), C[j]);
-            load_row(stage_block(N - 1 - j, 1), Bc[j]);
+            for (int d = 0; d < nx; ++d)
+                z[d] = Xt[k * nx + d];
+#pragma unroll
+            for (int c = 0; c < nu; ++c)
+                z[nx + c] = v[nu * k + c];
+        };
+        auto stage = [&](int k, const double (&Crow)[nz], const double (&Brow)[nx], const double (&z)[nz]) {
+            Dot4 acc;
+            add_all<0, nz>(acc, Crow, z);
+            add_bcast_all<nz>(acc, Brow, lt);
+            double w = acc.sum();
+            if (lane >= nx && lane < nz)
+                Hv[nu * k + (lane - nx)] = w;
+            lt = w;
+        };
+        double C[DEPTH][nz], Bc[DEPTH][nx];
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) { // the full groups start below the remainder stages
+            load_row(stage_block(Nfull - 1 - j, 2), C[j]);
+            load_row(stage_block(Nfull - 1 - j, 1), Bc[j]);
         }
         {
             double HN[nx];
@@ -486,22 +515,28 @@ struct ScalarALProblem {
             add_all<0, nx>(acc, HN, Xt + N * nx);
             lt = acc.sum();
         }
-        for (int k0 = N - 1; k0 >= 0; k0 -= DEPTH) {
+        for (int k = N - 1; k >= Nfull; --k) {
+            double TC[nz], TB[nx], z[nz];
+            load_row(stage_block(k, 2), TC);
+            load_row(stage_block(k, 1), TB);
+            load_z(k, z);
+            stage(k, TC, TB, z);
+        }
+        static_assert(DEPTH % 2 == 0, "the z register sets alternate inside a group");
+        double z0[nz], z1[nz];
+        load_z(Nfull - 1, z0);
+        for (int k0 = Nfull - 1; k0 >= 0; k0 -= DEPTH) {
 #pragma unroll
             for (int j = 0; j < DEPTH; ++j) {
-                const int k = k0 - j;
-                if (k >= 0) {
-                    Dot4 acc;
-                    add_all<0, nx>(acc, C[j], Xt + k * nx);
-                    add_all<nx, nu>(acc, C[j] + nx, v + nu * k);
-                    add_bcast_all<nz>(acc, Bc[j], lt);
-                    double w = acc.sum();
-                    if (lane >= nx && lane < nz)
-                        Hv[nu * k + (lane - nx)] = w;
-                    lt = w;
+                if (j % 2 == 0) {
+                    load_z(k0 - j - 1, z1);
+                    stage(k0 - j, C[j], Bc[j], z0);
+                } else {
+                    load_z(k0 - j - 1, z0);
+                    stage(k0 - j, C[j], Bc[j], z1);
                 }
-                load_row(stage_block(k - DEPTH, 2), C[j]);
-                load_row(stage_block(k - DEPTH, 1), Bc[j]);
+                load_row(stage_block(k0 - j - DEPTH, 2), C[j]);
+                load_row(stage_block(k0 - j - DEPTH, 1), Bc[j]);
             }
         }
         wait_vmem(); // the clamped prefetches past the first stage
