@@ -63,7 +63,7 @@ __device__ __forceinline__ void sincos_det(double x, double &s, double &c) {
     pc        = __builtin_fma(z, pc, -1.38888888888741095749e-03);
     pc        = __builtin_fma(z, pc, 4.16666666666666019037e-02);
     const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
-    const long long q = static_cast<long long>(kd) & 3;
+    const int q = static_cast<int>(kd) & 3; // |x| < 3e9 (64-bit conversions are emulated on the GPU)
     s = q == 0 ? sr : q == 1 ? cr : q == 2 ? -sr : -cr;
     c = q == 0 ? cr : q == 1 ? -sr : q == 2 ? -cr : sr;
 }
