@@ -9,13 +9,15 @@
 //   initial state ......... problems/problems/hanging_chain.cpp:121-124
 // The reference turns these into straight-line scalar C through CasADi.  Here lane 4p+c
 // (p = 0..9, c = 0..2; lanes 4p+3 and 40..63 idle) owns component c of chain point p: its
-// position and, for the nine free masses p < 9, its velocity.  A lone wavefront issues one fp64
-// instruction per ~8 cycles whatever its ILP, so the layout minimises instructions:
+// position and, for the nine free masses p < 9, its velocity.  A lone wavefront pays for every
+// instruction it issues (~5 cycles independent, 8-12 in a dependent fp64 chain, 60 for an LDS
+// crossbar round trip), so the layout minimises instructions:
 //   * one instruction handles a component of all ten points,
 //   * the three components of a point sit in one DPP quad: 3-term sums and broadcasts are
 //     quad_perm moves (VALU speed),
 //   * position and velocity of a point share a lane (no shuffle between them),
-//   * the only LDS-crossbar traffic is the neighbouring point (lane +-4), one ds_bpermute pair.
+//   * the neighbouring point (lane +-4) is four whole-wave DPP shifts by one lane away
+//     (no LDS-crossbar traffic).
 // Second-order information (Hessian-vector products): the gradient sweep at the current point
 // records, per RK4 substage and spring, the 3x3 matrices K = dF/dd and M = d(K lF)/dd; a product
 // is then two linear sweeps of a few FMAs per substage over that tape.

@@ -10,13 +10,14 @@
 //
 // Data placement (DESIGN.md "Layout"):
 //   LDS     : the 20 decision-space vectors of the solve (3 iterates x {x, xhat, grad, p}, q,
-//             Hv output, r_J, and the CG vectors z, r, d, Bd, step), n_pad doubles each
+//             Hv output, r_J, and the CG vectors z, r, d, Bd, step; the step slot doubles as the
+//             in/out vector of the solve), n_pad doubles each
 //   HBM/L2  : the state trajectory X[(N+1)][64] and its tangent Xt written by the forward
 //             sweeps and re-read (one stage ahead) by the reverse sweeps, one 512-byte row
 //             per stage per wavefront
 //   VGPR    : the stage state (one component per lane), adjoints, RK4 intermediates
 //   SGPR    : every scalar of the algorithm (psi, gamma, L, radius, rho, ...), made uniform
-//             with readfirstlane after each butterfly reduction
+//             with readfirstlane after each wavefront all-reduce
 #pragma once
 #include "wave_math.hip.h"
 #include <stdint.h>
