@@ -12,8 +12,8 @@
 // do not fit the LDS next to the iterates, so they live in an HBM ring per instance; lane l owns the
 // elements l, l+64, ... of every vector, in LDS and in HBM alike, so a pair is written and read back
 // by the same lanes (coalesced 512-byte rows, no cross-lane ordering needed).  rho and alpha are
-// small LDS arrays (in the vector slots PANOC leaves free) that every lane writes with the same
-// value.
+// small LDS arrays (in the vector slots PANOC leaves free), written by lane 0 and read by all (one
+// wavefront's LDS operations execute in order).
 #pragma once
 #include "pantr_kernel.hip.h"
 
@@ -42,7 +42,9 @@ struct LbfgsRing {
     __device__ __forceinline__ double *y(int i) const { return Y + (size_t)i * npad; }
 };
 
-/// One PANOC inner solve; same contract as pantr_inner().  lbfgs_ws: 2 * memory * npad doubles of
+/// One PANOC inner solve; same contract as pantr_inner().  (-DPANTR_PHASE_TIMING: final_gamma /
+/// final_psi / final_fbe / final_radius return the seconds spent in the L-BFGS application /
+/// psi_grad / psi(xhat) / the L-BFGS update.)  lbfgs_ws: 2 * memory * npad doubles of
 /// HBM for this instance.
 template <class PB, bool STRUCTURED>
 __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P, double tolerance,
@@ -101,12 +103,61 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
                 yrow[i] = positive ? bn[i] - b[i] : b[i] - bn[i];
             }
         }
-        lb.rho[lb.idx] = 1.0 / yTs;
+        if (lane == 0)
+            lb.rho[lb.idx] = 1.0 / yTs;
         lb.idx         = lb.succ(lb.idx);
         lb.full        = lb.full || lb.idx == 0;
         return true;
     };
-    // dot of an HBM row with an LDS vector, optionally restricted to the mask
+    // A pair's rows in registers (lane l holds elements l, l+64, ...): the two-loop recursion is a
+    // chain of 2 x count row operations, each a reduction that needs the previous one's result, so
+    // the rows of the next RING pairs are in flight from HBM while the current pair is reduced (RING
+    // register sets, loops unrolled by RING so that no set is copied; an exposed fetch costs ~1 us,
+    // the arithmetic of a pair ~0.3 us).
+    constexpr int NJR  = 4; // register rows cover n <= 256; longer vectors take the row-by-row path
+    constexpr int RING = 4;
+    struct PairRegs {
+        double s[NJR], y[NJR];
+    };
+    auto fetch = [&](int i, PairRegs &r) {
+        const double *srow = lb.s(i), *yrow = lb.y(i);
+#pragma unroll
+        for (int j = 0; j < NJR; ++j) {
+            int e = j * WAVE + lane;
+            if (j < nj && e < n) {
+                r.s[j] = srow[e];
+                r.y[j] = yrow[e];
+            }
+        }
+    };
+    // sum over the mask of a[j] * b[j] (b: registers or an LDS vector)
+    auto dot_rr = [&](const double (&a)[NJR], const double (&b)[NJR], uint32_t mask) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NJR; ++j)
+            if (j < nj && j * WAVE + lane < n)
+                acc = acc + a[j] * ((mask >> j) & 1u ? b[j] : 0.0);
+        return uniform(wave_sum(acc));
+    };
+    auto dot_rv = [&](const double (&a)[NJR], const double *v, uint32_t mask) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NJR; ++j) {
+            int e = j * WAVE + lane;
+            if (j < nj && e < n)
+                acc = acc + a[j] * ((mask >> j) & 1u ? v[e] : 0.0);
+        }
+        return uniform(wave_sum(acc));
+    };
+    auto axmy_r = [&](double c, const double (&a)[NJR], double *v, uint32_t mask) { // v <- v - c a on the mask
+#pragma unroll
+        for (int j = 0; j < NJR; ++j) {
+            int e = j * WAVE + lane;
+            if (j < nj && e < n && ((mask >> j) & 1u))
+                v[e] = v[e] - c * a[j];
+        }
+    };
+    // the same three operations on rows left in HBM (n > 512)
     auto dot_row = [&](const double *row, const double *v, uint32_t mask) {
         double acc = 0.0;
         for (int j = 0; j < nj; ++j) {
@@ -116,7 +167,6 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
         }
         return uniform(wave_sum(acc));
     };
-    // v <- v - c row on the mask
     auto axmy_row = [&](double c, const double *row, double *v, uint32_t mask) {
         for (int j = 0; j < nj; ++j) {
             int i = j * WAVE + lane;
@@ -138,37 +188,91 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
         if (cnt == 0)
             return false;
         double gamma = -1.0;
-        if (!masked) {
-            int newest = lb.pred(lb.idx);
-            gamma      = 1.0 / (lb.rho[newest] * dot_row(lb.y(newest), lb.y(newest), mask));
-        }
-        for (int c = 0; c < cnt; ++c) {
-            int i = lb.from_newest(c);
-            if (masked) {
-                lb.rho[i] = 1.0 / dot_row(lb.s(i), lb.y(i), mask);
-                if (!(lb.rho[i] > 0))
-                    continue;
+        if (nj > NJR) { // row-by-row from HBM
+            if (!masked) {
+                int newest = lb.pred(lb.idx);
+                gamma      = 1.0 / (lb.rho[newest] * dot_row(lb.y(newest), lb.y(newest), mask));
             }
-            double a    = lb.rho[i] * dot_row(lb.s(i), v, mask);
-            lb.alpha[i] = a;
-            axmy_row(a, lb.y(i), v, mask);
-            if (masked && gamma < 0)
-                gamma = 1.0 / (lb.rho[i] * dot_row(lb.y(i), lb.y(i), mask));
+            for (int c = 0; c < cnt; ++c) {
+                int i = lb.from_newest(c);
+                if (masked) {
+                    lb.rho[i] = 1.0 / dot_row(lb.s(i), lb.y(i), mask);
+                    if (!(lb.rho[i] > 0))
+                        continue;
+                }
+                double a    = lb.rho[i] * dot_row(lb.s(i), v, mask);
+                if (lane == 0)
+                    lb.alpha[i] = a;
+                axmy_row(a, lb.y(i), v, mask);
+                if (masked && gamma < 0)
+                    gamma = 1.0 / (lb.rho[i] * dot_row(lb.y(i), lb.y(i), mask));
+            }
+            if (masked && gamma < 0) // no pair with positive curvature on J
+                return false;
+            scale(gamma, v, mask);
+            for (int c = 0; c < cnt; ++c) {
+                int i = lb.from_oldest(c);
+                if (masked && !(lb.rho[i] > 0))
+                    continue;
+                double beta = lb.rho[i] * dot_row(lb.y(i), v, mask);
+                axmy_row(beta - lb.alpha[i], lb.s(i), v, mask);
+            }
+            return true;
         }
+        PairRegs R[RING];
+        // op(c, rows of the c-th pair in the order idx(c)) for c = 0..cnt-1
+        auto sweep = [&](auto &&idx, auto &&op) {
+#pragma unroll
+            for (int j = 0; j < RING; ++j)
+                if (j < cnt)
+                    fetch(idx(j), R[j]);
+            for (int c0 = 0; c0 < cnt; c0 += RING) {
+#pragma unroll
+                for (int j = 0; j < RING; ++j) {
+                    const int c = c0 + j;
+                    if (c < cnt) {
+                        op(c, R[j]);
+                        if (c + RING < cnt)
+                            fetch(idx(c + RING), R[j]);
+                    }
+                }
+            }
+        };
+        // ---- newest to oldest ----
+        sweep([&](int c) { return lb.from_newest(c); },
+              [&](int c, const PairRegs &r) {
+                  int i = lb.from_newest(c);
+                  if (!masked && c == 0)
+                      gamma = 1.0 / (lb.rho[i] * dot_rr(r.y, r.y, mask));
+                  if (masked) {
+                      double rho_i = 1.0 / dot_rr(r.s, r.y, mask);
+                      if (lane == 0)
+                          lb.rho[i] = rho_i;
+                      if (!(rho_i > 0))
+                          return;
+                  }
+                  double a    = lb.rho[i] * dot_rv(r.s, v, mask);
+                  if (lane == 0) // one writer: a 64-lane write to one LDS address serialises
+                      if (lane == 0)
+                    lb.alpha[i] = a;
+                  axmy_r(a, r.y, v, mask);
+                  if (masked && gamma < 0)
+                      gamma = 1.0 / (lb.rho[i] * dot_rr(r.y, r.y, mask));
+              });
         if (masked && gamma < 0) // no pair with positive curvature on J
             return false;
         scale(gamma, v, mask);
-        for (int c = 0; c < cnt; ++c) {
-            int i = lb.from_oldest(c);
-            if (masked && !(lb.rho[i] > 0))
-                continue;
-            double beta = lb.rho[i] * dot_row(lb.y(i), v, mask);
-            axmy_row(beta - lb.alpha[i], lb.s(i), v, mask);
-        }
+        // ---- oldest to newest ----
+        sweep([&](int c) { return lb.from_oldest(c); },
+              [&](int c, const PairRegs &r) {
+                  int i = lb.from_oldest(c);
+                  if (masked && !(lb.rho[i] > 0))
+                      return;
+                  double beta = lb.rho[i] * dot_rv(r.y, v, mask);
+                  axmy_r(beta - lb.alpha[i], r.s, v, mask);
+              });
         return true;
     };
-    // rows are read with the generic dot above: HBM rows are dense, so y'y of a row is dot_row(y, y)
-    // with the row passed as both operands (the second one is only masked, never re-read from LDS)
 
     auto qub_violated = [&](const IterateRef &i) {
         double margin = (1.0 + fabs(i.psi_x)) * P.quadratic_upperbound_tolerance_factor;
@@ -269,14 +373,14 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
                     if (i < n)
                         q[i] = (mask >> j) & 1u ? -G_(curr)[i] : P_(curr)[i];
                 }
-                ok = nJ > 0 && lbfgs_apply(q, nJ == n ? ~0u : mask, nJ != n);
+                PANTR_PHASE(final_gamma, ok = nJ > 0 && lbfgs_apply(q, nJ == n ? ~0u : mask, nJ != n));
             } else {
                 for (int j = 0; j < nj; ++j) {
                     int i = j * WAVE + lane;
                     if (i < n)
                         q[i] = P_(curr)[i];
                 }
-                ok = lbfgs_apply(q, ~0u, false);
+                PANTR_PHASE(final_gamma, ok = lbfgs_apply(q, ~0u, false));
             }
             bool finite = true;
             for (int j = 0; j < nj; ++j) {
@@ -310,7 +414,7 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
                                                  : (xi + (1.0 - tau) * P_(curr)[i]) + tau * q[i];
                     }
                 }
-                next.psi_x = pb.eval_psi_grad(X_(next), G_(next));
+                PANTR_PHASE(final_psi, next.psi_x = pb.eval_psi_grad(X_(next), G_(next)));
                 if (tau != 0)
                     ++st.n_psi_grad_psi;
                 else
@@ -327,7 +431,7 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
             }
             pb.prox_grad_step(next.gamma, X_(next), G_(next), XH_(next), P_(next), next.pTp, next.gradTp);
             ++st.n_prox_grad_step;
-            next.psi_xh = pb.eval_psi_xhat(XH_(next), next.yh);
+            PANTR_PHASE(final_fbe, next.psi_xh = pb.eval_psi_xhat(XH_(next), next.yh));
             ++st.n_psi;
             if (next.L < P.L_max && qub_violated(next)) {
                 next.gamma = next.gamma / 2.0;
@@ -368,11 +472,11 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
         }
         bool accepted;
         if (STRUCTURED) {
-            accepted = lbfgs_update(X_(curr), X_(next), G_(curr), G_(next), true, true);
+            PANTR_PHASE(final_radius, accepted = lbfgs_update(X_(curr), X_(next), G_(curr), G_(next), true, true));
         } else {
             if (curr.gamma != next.gamma)
                 lb.reset();
-            accepted = lbfgs_update(X_(curr), X_(next), P_(curr), P_(next), false, false);
+            PANTR_PHASE(final_radius, accepted = lbfgs_update(X_(curr), X_(next), P_(curr), P_(next), false, false));
         }
         st.lbfgs_rejected += accepted ? 0 : 1;
         swap_iter(curr, next);

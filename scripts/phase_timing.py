@@ -23,7 +23,30 @@ def report(name, st):
     print(f"   {'everything else':18s} {100*rest/el:5.1f} %   {rest/max(it,1)*1e6:8.1f} us per iteration")
 
 
+def report_panoc(name, st):
+    st = st.ravel()
+    el, it = st["elapsed_s"].sum(), st["iterations"].sum()
+    print(f"{name}: {len(st)} solves, mean {el/len(st)*1e3:.2f} ms, {it/len(st):.1f} iterations")
+    rest = el
+    for label, field, cnt in (("L-BFGS apply", "final_gamma", "iterations"), ("psi_grad", "final_psi", "n_psi_grad_psi"),
+                              ("psi(xhat)", "final_fbe", "n_psi"), ("L-BFGS update", "final_radius", "iterations")):
+        t, c = st[field].sum(), st[cnt].sum()
+        rest -= t
+        print(f"   {label:18s} {100*t/el:5.1f} %   {t/max(c,1)*1e6:8.1f} us per call")
+    print(f"   {'everything else':18s} {100*rest/el:5.1f} %   {rest/max(it,1)*1e6:8.1f} us per iteration")
+
+
 which = sys.argv[1:] or ["hanging_chain", "quadcopter", "realistic_quadcopter"]
+if "panoc" in which or "strucpanoc" in which:
+    d = np.load(os.path.join(ROOT, "tests/golden/mpc_hanging_chain_N60_warm300.npz"))
+    x0 = np.vstack([d["x0"][:60], d["x0"][:60]]); u0 = np.vstack([d["guess"][:60], np.zeros_like(d["guess"][:60])])
+    for m in [w for w in which if w in ("panoc", "strucpanoc")]:
+        b = pa.PantrBatch("hanging_chain", 60, len(x0), opts=pa.DODO_OPTS[m])
+        report_panoc(f"hanging_chain N=60 {m} (60 warm + 60 cold)", b.solve(x0, u0)[1])
+        b.close()
+    which = [w for w in which if w not in ("panoc", "strucpanoc")]
+    if not which:
+        sys.exit(0)
 if "hanging_chain" in which:
     d = np.load(os.path.join(ROOT, "tests/golden/mpc_hanging_chain_N60_warm300.npz"))
     x0 = np.vstack([d["x0"], d["x0"]]); u0 = np.vstack([d["guess"], np.zeros_like(d["guess"])])
