@@ -50,11 +50,11 @@ struct ScalarALProblem {
     double *lds; ///< n-vectors: NUM_VEC slots of npad doubles
     int N, n, npad, nj, m, mpad, mj;
     double x0[nx];
-    double *mv;  ///< m-vectors: y, Sigma, e1, e2, yh0, yh1, yh2, yh_t (tangent of yhat), mpad doubles each
+    double *mv;  ///< m-vectors: y, Sigma, e1, e2, yh0, yh1, yh2, y/Sigma, mpad doubles each
     double *X;   ///< LDS: primal trajectory (N+1) x nx
     double *Xt;  ///< LDS: tangent trajectory (N+1) x nx
     double *tape; ///< HBM: this instance's second-order tape (see workspace_doubles)
-    enum { MV_Y = 0, MV_SIG = 1, MV_E1 = 2, MV_E2 = 3, MV_YH = 4, MV_COUNT = 7 };
+    enum { MV_Y = 0, MV_SIG = 1, MV_E1 = 2, MV_E2 = 3, MV_YH = 4, MV_YS = 7, MV_COUNT = 8 };
 
     // Second-order tape, per stage three blocks of 16 rows x 16 doubles: JT row i = (dx+_i/dz_d)_d,
     // JC row d = (dx+_i/dz_d)_i, HC row l = column l of H_k.  After the N stages one block with the
@@ -205,26 +205,28 @@ struct ScalarALProblem {
     template <class T>
     __device__ __forceinline__ T forward(const double *u, const double *v, double *yh) const {
         wave_sync();
-        const double *y = mvec(MV_Y), *Sig = mvec(MV_SIG);
-        T s[nx], xn[nx], c[nc], uk[nu];
+        const double *yS = mvec(MV_YS), *Sig = mvec(MV_SIG);
+        T s[nx], xn[nx], c[nc], uk[nu], yhv[nc];
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             s[l] = T{} + x0[l];
         T accf = T{}, accal = T{};
         for (int k = 0; k <= N; ++k) {
-            store_x(k, s);
             const auto t1 = M::trig_uniform(s);
             M::constr(t1, s, c);
 #pragma unroll
             for (int i = 0; i < nc; ++i) {
                 int j  = nc * k + i;
-                T zeta = c[i] + (y[j] / Sig[j]);
+                T zeta = c[i] + yS[j]; // y / Sigma: set_al()
                 T zhat = tmax(tmin(zeta, M::d_ub(i)), M::d_lb(i));
                 T d    = zeta - zhat;
-                T yhv  = Sig[j] * d;
-                store_yh(yh, j, yhv);
-                accal = accal + (yhv * d);
+                yhv[i] = Sig[j] * d;
+                accal  = accal + (yhv[i] * d);
             }
+            store_x(k, s); // one lane-0 block per stage: state row and multiplier estimates
+#pragma unroll
+            for (int i = 0; i < nc; ++i)
+                store_yh(yh, nc * k + i, yhv[i]);
             if (k == N)
                 break;
             load_u(u, v, k, uk);
@@ -284,13 +286,13 @@ struct ScalarALProblem {
     /// yhat_k(x_k) on dual numbers (the value part repeats forward()'s arithmetic).
     __device__ __forceinline__ void stage_multipliers(const typename M::template Trig<dual> &t1,
                                                       const dual (&s)[nx], int k, dual (&yk)[nc]) const {
-        const double *y = mvec(MV_Y), *Sig = mvec(MV_SIG);
+        const double *yS = mvec(MV_YS), *Sig = mvec(MV_SIG);
         dual c[nc];
         M::constr(t1, s, c);
 #pragma unroll
         for (int i = 0; i < nc; ++i) {
             int j     = nc * k + i;
-            dual zeta = c[i] + (y[j] / Sig[j]);
+            dual zeta = c[i] + yS[j];
             dual zhat = tmax(tmin(zeta, M::d_ub(i)), M::d_lb(i));
             dual d    = zeta - zhat;
             yk[i]     = Sig[j] * d;
@@ -542,6 +544,15 @@ struct ScalarALProblem {
         wait_vmem(); // the clamped prefetches past the first stage
         wave_sync();
     }
+    /// y / Sigma for the sweeps; call whenever y or Sigma changed (they are fixed during an inner solve).
+    __device__ __forceinline__ void set_al() const {
+        wave_sync();
+        const double *y = mvec(MV_Y), *Sig = mvec(MV_SIG);
+        double *yS = mvec(MV_YS);
+        for (int j = lane; j < m; j += WAVE)
+            yS[j] = y[j] / Sig[j];
+        wave_sync();
+    }
     /// err_z = Sigma^{-1} (yhat - y) into e2, then y <- yhat.
     __device__ __forceinline__ void update_multipliers(int yh_slot) const {
         wave_sync();
@@ -685,7 +696,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
             double yub = M::d_ub(ci) == __builtin_huge_val() ? 0.0 : A.max_multiplier;
             y[j]       = fmin(fmax(y[j], ylb), yub);
         }
-        wave_sync();
+        pb.set_al();
         r = inner_solve<METHOD>(
             pb, P, eps, A.max_time_s, t_start, x_io, st,
             trace && i == 0 ? a.trace + (size_t)inst * a.trace_cap * TRACE_COLS : nullptr, a.trace_cap,
@@ -811,7 +822,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
         pb.mvec(PB::MV_Y)[j]   = a.y[(size_t)inst * a.m + j];
         pb.mvec(PB::MV_SIG)[j] = a.Sig[(size_t)inst * a.m + j];
     }
-    wave_sync();
+    pb.set_al();
     double psi = 0.0;
     if (a.mode == ALM_EVAL_PSI_GRAD) {
         psi = pb.eval_psi_xhat(u, 0);
