@@ -74,7 +74,7 @@ struct Dual {
 };
 inline Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.t + b.t}; }
 inline Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.t - b.t}; }
-inline Dual operator*(Dual a, Dual b) { return {a.v * b.v, (a.v * b.t) + (a.t * b.v)}; }
+inline Dual operator*(Dual a, Dual b) { return {a.v * b.v, std::fma(a.t, b.v, a.v * b.t)}; }
 inline Dual operator*(double c, Dual a) { return {c * a.v, c * a.t}; }
 inline Dual operator+(Dual a, double c) { return {a.v + c, a.t}; }
 inline Dual operator-(Dual a, double c) { return {a.v - c, a.t}; }

@@ -53,6 +53,9 @@ inline void sincos_t(Dual x, Dual &s, Dual &c) {
     c = {cv, -(sv * x.t)};
 }
 inline Dual operator-(Dual a) { return {-a.v, -a.t}; }
+/// c k + s in one rounding (the Runge-Kutta combinations of the scalar models)
+inline double madd(double c, double k, double s) { return std::fma(c, k, s); }
+inline Dual madd(double c, Dual k, Dual s) { return {std::fma(c, k.v, s.v), std::fma(c, k.t, s.t)}; }
 /// clamp pieces with the tangent of the selected branch
 inline double tmin(double a, double b) { return a < b ? a : b; }
 inline double tmax(double a, double b) { return a > b ? a : b; }
@@ -65,7 +68,7 @@ inline Dual tmax(Dual a, double b) { return a.v > b ? a : Dual{b, 0.0}; }
 template <bool REALISTIC>
 struct QuadcopterT {
     static constexpr int nx = 9, nu = 4, nc = 4;
-    static constexpr double Ts = 0.1, g_grav = 9.81, c6 = Ts / 6;
+    static constexpr double Ts = 0.1, hTs = 0.5 * Ts, g_grav = 9.81, c6 = Ts / 6;
     static constexpr double r2 = 0.1 * 0.1; ///< collision cylinder radius squared (quadcopter.py:70)
     static constexpr double pf[3] = {0.25, 0.25, 0.5}; // quadcopter.py:90
     static const char *name() { return REALISTIC ? "realistic_quadcopter" : "quadcopter"; }
@@ -287,29 +290,29 @@ struct SingleShootingAL {
         T k1[nx], k2[nx], k3[nx], k4[nx], w[nx];
         Model::fc(s, u, k1);
         for (int l = 0; l < nx; ++l)
-            w[l] = s[l] + 0.5 * (Model::Ts * k1[l]);
+            w[l] = madd(Model::hTs, k1[l], s[l]);
         Model::fc(w, u, k2);
         for (int l = 0; l < nx; ++l)
-            w[l] = s[l] + 0.5 * (Model::Ts * k2[l]);
+            w[l] = madd(Model::hTs, k2[l], s[l]);
         Model::fc(w, u, k3);
         for (int l = 0; l < nx; ++l)
-            w[l] = s[l] + Model::Ts * k3[l];
+            w[l] = madd(Model::Ts, k3[l], s[l]);
         Model::fc(w, u, k4);
         for (int l = 0; l < nx; ++l)
-            xn[l] = s[l] + Model::c6 * (((k1[l] + 2.0 * k2[l]) + 2.0 * k3[l]) + k4[l]);
+            xn[l] = madd(Model::c6, madd(2.0, k3[l], madd(2.0, k2[l], k1[l])) + k4[l], s[l]);
     }
     template <class T>
     static void rk4_adj(const T *s, const T *u, const T *mu, T *sbar, T *ubar) {
         T k[nx], w2[nx], w3[nx], w4[nx];
         Model::fc(s, u, k);
         for (int l = 0; l < nx; ++l)
-            w2[l] = s[l] + 0.5 * (Model::Ts * k[l]);
+            w2[l] = madd(Model::hTs, k[l], s[l]);
         Model::fc(w2, u, k);
         for (int l = 0; l < nx; ++l)
-            w3[l] = s[l] + 0.5 * (Model::Ts * k[l]);
+            w3[l] = madd(Model::hTs, k[l], s[l]);
         Model::fc(w3, u, k);
         for (int l = 0; l < nx; ++l)
-            w4[l] = s[l] + Model::Ts * k[l];
+            w4[l] = madd(Model::Ts, k[l], s[l]);
         T kb1[nx], kb2[nx], kb3[nx], kb4[nx], a[nx], ua[nu];
         for (int l = 0; l < nx; ++l) {
             T sg   = Model::c6 * mu[l];
@@ -322,21 +325,21 @@ struct SingleShootingAL {
         Model::fc_adj(w4, u, kb4, a, ubar);
         for (int l = 0; l < nx; ++l) {
             sbar[l] = sbar[l] + a[l];
-            kb3[l]  = kb3[l] + Model::Ts * a[l];
+            kb3[l]  = madd(Model::Ts, a[l], kb3[l]);
         }
         Model::fc_adj(w3, u, kb3, a, ua);
         for (int c = 0; c < nu; ++c)
             ubar[c] = ubar[c] + ua[c];
         for (int l = 0; l < nx; ++l) {
             sbar[l] = sbar[l] + a[l];
-            kb2[l]  = kb2[l] + 0.5 * (Model::Ts * a[l]);
+            kb2[l]  = madd(Model::hTs, a[l], kb2[l]);
         }
         Model::fc_adj(w2, u, kb2, a, ua);
         for (int c = 0; c < nu; ++c)
             ubar[c] = ubar[c] + ua[c];
         for (int l = 0; l < nx; ++l) {
             sbar[l] = sbar[l] + a[l];
-            kb1[l]  = kb1[l] + 0.5 * (Model::Ts * a[l]);
+            kb1[l]  = madd(Model::hTs, a[l], kb1[l]);
         }
         Model::fc_adj(s, u, kb1, a, ua);
         for (int c = 0; c < nu; ++c)

@@ -106,19 +106,19 @@ struct ScalarALProblem {
         M::fc(t1, s, u, k1);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
-            w[l] = s[l] + 0.5 * (M::Ts * k1[l]);
+            w[l] = madd(M::hTs, k1[l], s[l]);
         M::fc(M::template trig_of<UNIFORM>(w), w, u, k2);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
-            w[l] = s[l] + 0.5 * (M::Ts * k2[l]);
+            w[l] = madd(M::hTs, k2[l], s[l]);
         M::fc(M::template trig_of<UNIFORM>(w), w, u, k3);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
-            w[l] = s[l] + M::Ts * k3[l];
+            w[l] = madd(M::Ts, k3[l], s[l]);
         M::fc(M::template trig_of<UNIFORM>(w), w, u, k4);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
-            xn[l] = s[l] + M::c6 * (((k1[l] + 2.0 * k2[l]) + 2.0 * k3[l]) + k4[l]);
+            xn[l] = madd(M::c6, madd(2.0, k3[l], madd(2.0, k2[l], k1[l])) + k4[l], s[l]);
     }
     /// Adjoint of one RK4 step (wave-uniform values).  The Trig of each substage state is evaluated
     /// once and serves the recomputed forward pass and the adjoint.  WITH_XN: also returns the
@@ -131,7 +131,7 @@ struct ScalarALProblem {
         M::fc(t1, s, u, k);
 #pragma unroll
         for (int l = 0; l < nx; ++l) {
-            w2[l] = s[l] + 0.5 * (M::Ts * k[l]);
+            w2[l] = madd(M::hTs, k[l], s[l]);
             if (WITH_XN)
                 ksum[l] = k[l];
         }
@@ -139,24 +139,24 @@ struct ScalarALProblem {
         M::fc(t2, w2, u, k);
 #pragma unroll
         for (int l = 0; l < nx; ++l) {
-            w3[l] = s[l] + 0.5 * (M::Ts * k[l]);
+            w3[l] = madd(M::hTs, k[l], s[l]);
             if (WITH_XN)
-                ksum[l] = ksum[l] + 2.0 * k[l];
+                ksum[l] = madd(2.0, k[l], ksum[l]);
         }
         const auto t3 = M::trig_uniform(w3);
         M::fc(t3, w3, u, k);
 #pragma unroll
         for (int l = 0; l < nx; ++l) {
-            w4[l] = s[l] + M::Ts * k[l];
+            w4[l] = madd(M::Ts, k[l], s[l]);
             if (WITH_XN)
-                ksum[l] = ksum[l] + 2.0 * k[l];
+                ksum[l] = madd(2.0, k[l], ksum[l]);
         }
         const auto t4 = M::trig_uniform(w4);
         if (WITH_XN) {
             M::fc(t4, w4, u, k);
 #pragma unroll
             for (int l = 0; l < nx; ++l)
-                xn[l] = s[l] + M::c6 * (ksum[l] + k[l]);
+                xn[l] = madd(M::c6, ksum[l] + k[l], s[l]);
         }
         T kb1[nx], kb2[nx], kb3[nx], kb4[nx], a[nx], ua[nu];
 #pragma unroll
@@ -172,7 +172,7 @@ struct ScalarALProblem {
 #pragma unroll
         for (int l = 0; l < nx; ++l) {
             sbar[l] = sbar[l] + a[l];
-            kb3[l]  = kb3[l] + M::Ts * a[l];
+            kb3[l]  = madd(M::Ts, a[l], kb3[l]);
         }
         M::fc_adj(t3, u, kb3, a, ua);
 #pragma unroll
@@ -181,7 +181,7 @@ struct ScalarALProblem {
 #pragma unroll
         for (int l = 0; l < nx; ++l) {
             sbar[l] = sbar[l] + a[l];
-            kb2[l]  = kb2[l] + 0.5 * (M::Ts * a[l]);
+            kb2[l]  = madd(M::hTs, a[l], kb2[l]);
         }
         M::fc_adj(t2, u, kb2, a, ua);
 #pragma unroll
@@ -190,7 +190,7 @@ struct ScalarALProblem {
 #pragma unroll
         for (int l = 0; l < nx; ++l) {
             sbar[l] = sbar[l] + a[l];
-            kb1[l]  = kb1[l] + 0.5 * (M::Ts * a[l]);
+            kb1[l]  = madd(M::hTs, a[l], kb1[l]);
         }
         M::fc_adj(t1, u, kb1, a, ua);
 #pragma unroll

@@ -19,7 +19,7 @@ namespace pantr {
 template <bool REALISTIC>
 struct QuadModelT {
     static constexpr int nx = 9, nu = 4, nc = 4;
-    static constexpr double Ts = 0.1, g_grav = 9.81, c6 = Ts / 6;
+    static constexpr double Ts = 0.1, hTs = 0.5 * Ts, g_grav = 9.81, c6 = Ts / 6;
     static constexpr double r2 = 0.1 * 0.1; ///< collision cylinder radius squared (quadcopter.py:70)
     __host__ __device__ static constexpr double pf(int i) { return i == 2 ? 0.5 : 0.25; } // quadcopter.py:90
     __host__ __device__ static const char *name() { return REALISTIC ? "realistic_quadcopter" : "quadcopter"; }

@@ -18,7 +18,7 @@ struct dual {
 __device__ __forceinline__ dual operator+(dual a, dual b) { return {a.v + b.v, a.t + b.t}; }
 __device__ __forceinline__ dual operator-(dual a, dual b) { return {a.v - b.v, a.t - b.t}; }
 __device__ __forceinline__ dual operator*(dual a, dual b) {
-    return {a.v * b.v, (a.v * b.t) + (a.t * b.v)};
+    return {a.v * b.v, __builtin_fma(a.t, b.v, a.v * b.t)};
 }
 __device__ __forceinline__ dual operator*(double c, dual a) { return {c * a.v, c * a.t}; }
 __device__ __forceinline__ dual operator+(dual a, double c) { return {a.v + c, a.t}; }
@@ -37,6 +37,11 @@ __device__ __forceinline__ dual operator/(dual a, dual b) {
     return {q, (a.t - q * b.t) / b.v};
 }
 __device__ __forceinline__ dual operator-(dual a) { return {-a.v, -a.t}; }
+/// c k + s in one rounding (the Runge-Kutta combinations of the scalar models)
+__device__ __forceinline__ double madd(double c, double k, double s) { return __builtin_fma(c, k, s); }
+__device__ __forceinline__ dual madd(double c, dual k, dual s) {
+    return {__builtin_fma(c, k.v, s.v), __builtin_fma(c, k.t, s.t)};
+}
 /// clamp pieces with the tangent of the selected branch
 __device__ __forceinline__ double tmin(double a, double b) { return a < b ? a : b; }
 __device__ __forceinline__ double tmax(double a, double b) { return a > b ? a : b; }
