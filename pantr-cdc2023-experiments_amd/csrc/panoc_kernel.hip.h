@@ -119,45 +119,45 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
     struct PairRegs {
         double s[NJR], y[NJR];
     };
+    // element j of this lane: index (clamped into the vector so that loads need no lane mask) and
+    // whether it exists; selects instead of lane-masked branches keep a row operation one basic block
+    int eidx[NJR];
+    bool valid[NJR];
+#pragma unroll
+    for (int j = 0; j < NJR; ++j) {
+        int e    = j * WAVE + lane;
+        valid[j] = j < nj && e < n;
+        eidx[j]  = e < n ? e : n - 1;
+    }
     auto fetch = [&](int i, PairRegs &r) {
         const double *srow = lb.s(i), *yrow = lb.y(i);
 #pragma unroll
-        for (int j = 0; j < NJR; ++j) {
-            int e = j * WAVE + lane;
-            if (j < nj && e < n) {
-                r.s[j] = srow[e];
-                r.y[j] = yrow[e];
+        for (int j = 0; j < NJR; ++j)
+            if (j < nj) { // wave-uniform
+                r.s[j] = srow[eidx[j]];
+                r.y[j] = yrow[eidx[j]];
             }
-        }
     };
-    // sum over the mask of a[j] * b[j] (b: registers or an LDS vector)
+    // sum over the mask of a[j] * b[j]
     auto dot_rr = [&](const double (&a)[NJR], const double (&b)[NJR], uint32_t mask) {
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < NJR; ++j)
-            if (j < nj && j * WAVE + lane < n)
-                acc = acc + a[j] * ((mask >> j) & 1u ? b[j] : 0.0);
+            if (j < nj) {
+                double t = acc + a[j] * ((mask >> j) & 1u ? b[j] : 0.0);
+                acc      = valid[j] ? t : acc;
+            }
         return uniform(wave_sum(acc));
     };
-    auto dot_rv = [&](const double (&a)[NJR], const double *v, uint32_t mask) {
-        double acc = 0.0;
+    auto axmy_r = [&](double c, const double (&a)[NJR], double (&v)[NJR], uint32_t mask) { // v <- v - c a on the mask
 #pragma unroll
-        for (int j = 0; j < NJR; ++j) {
-            int e = j * WAVE + lane;
-            if (j < nj && e < n)
-                acc = acc + a[j] * ((mask >> j) & 1u ? v[e] : 0.0);
-        }
-        return uniform(wave_sum(acc));
+        for (int j = 0; j < NJR; ++j)
+            if (j < nj) {
+                double t = v[j] - c * a[j];
+                v[j]     = valid[j] && ((mask >> j) & 1u) ? t : v[j];
+            }
     };
-    auto axmy_r = [&](double c, const double (&a)[NJR], double *v, uint32_t mask) { // v <- v - c a on the mask
-#pragma unroll
-        for (int j = 0; j < NJR; ++j) {
-            int e = j * WAVE + lane;
-            if (j < nj && e < n && ((mask >> j) & 1u))
-                v[e] = v[e] - c * a[j];
-        }
-    };
-    // the same three operations on rows left in HBM (n > 512)
+    // the same operations on rows left in HBM and the vector left in LDS (n > 256)
     auto dot_row = [&](const double *row, const double *v, uint32_t mask) {
         double acc = 0.0;
         for (int j = 0; j < nj; ++j) {
@@ -220,6 +220,10 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
             return true;
         }
         PairRegs R[RING];
+        double qr[NJR]; // the vector being transformed stays in registers for the whole recursion
+#pragma unroll
+        for (int j = 0; j < NJR; ++j)
+            qr[j] = j < nj ? v[eidx[j]] : 0.0;
         // op(c, rows of the c-th pair in the order idx(c)) for c = 0..cnt-1
         auto sweep = [&](auto &&idx, auto &&op) {
 #pragma unroll
@@ -244,33 +248,45 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
                   int i = lb.from_newest(c);
                   if (!masked && c == 0)
                       gamma = 1.0 / (lb.rho[i] * dot_rr(r.y, r.y, mask));
+                  double rho_i;
                   if (masked) {
-                      double rho_i = 1.0 / dot_rr(r.s, r.y, mask);
+                      rho_i = 1.0 / dot_rr(r.s, r.y, mask);
                       if (lane == 0)
                           lb.rho[i] = rho_i;
                       if (!(rho_i > 0))
                           return;
+                  } else {
+                      rho_i = lb.rho[i];
                   }
-                  double a    = lb.rho[i] * dot_rv(r.s, v, mask);
+                  double a = rho_i * dot_rr(r.s, qr, mask);
                   if (lane == 0) // one writer: a 64-lane write to one LDS address serialises
-                      if (lane == 0)
-                    lb.alpha[i] = a;
-                  axmy_r(a, r.y, v, mask);
+                      lb.alpha[i] = a;
+                  axmy_r(a, r.y, qr, mask);
                   if (masked && gamma < 0)
-                      gamma = 1.0 / (lb.rho[i] * dot_rr(r.y, r.y, mask));
+                      gamma = 1.0 / (rho_i * dot_rr(r.y, r.y, mask));
               });
         if (masked && gamma < 0) // no pair with positive curvature on J
             return false;
-        scale(gamma, v, mask);
+#pragma unroll
+        for (int j = 0; j < NJR; ++j)
+            if (j < nj) {
+                double t = gamma * qr[j];
+                qr[j]    = valid[j] && ((mask >> j) & 1u) ? t : qr[j];
+            }
         // ---- oldest to newest ----
         sweep([&](int c) { return lb.from_oldest(c); },
               [&](int c, const PairRegs &r) {
                   int i = lb.from_oldest(c);
-                  if (masked && !(lb.rho[i] > 0))
+                  double rho_i = lb.rho[i];
+                  if (masked && !(rho_i > 0))
                       return;
-                  double beta = lb.rho[i] * dot_rv(r.y, v, mask);
-                  axmy_r(beta - lb.alpha[i], r.s, v, mask);
+                  double beta = rho_i * dot_rr(r.y, qr, mask);
+                  axmy_r(beta - lb.alpha[i], r.s, qr, mask);
               });
+#pragma unroll
+        for (int j = 0; j < NJR; ++j)
+            if (valid[j])
+                v[j * WAVE + lane] = qr[j];
         return true;
     };
 
