@@ -98,6 +98,10 @@ struct WaveProblem {
     double4 *tape;  ///< global: recorded second-order rows, M::TAPE_D4_PER_STAGE per stage
     double4 *st;    ///< global: tangent spring vectors of the current Hv, M::ST_D4_PER_STAGE per stage
     char *tbuf0, *tbuf1; ///< LDS: two stage-sized landing buffers (distinct objects) for the LDS-DMA
+    /// The first stage's K rows of the current tape are already in flight to (or in) tbuf0: every
+    /// product leaves them there for the next one, so only the first product after a recording
+    /// waits for them.
+    mutable bool primed = false;
 
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
 
@@ -118,7 +122,10 @@ struct WaveProblem {
     // ---- the interface pantr_inner() drives (m = 0: no multipliers) ----------------------------
     __device__ __forceinline__ double eval_psi_grad(const double *u, double *grad) const { return psi_grad<false>(u, grad); }
     __device__ __forceinline__ double eval_psi_xhat(const double *u, int) const { return psi_forward<true>(u); }
-    __device__ __forceinline__ void eval_grad_xhat(const double *u, double *grad, int) const { grad_reverse<true>(u, grad); }
+    __device__ __forceinline__ void eval_grad_xhat(const double *u, double *grad, int) const {
+        grad_reverse<true>(u, grad);
+        primed = false; // new tape
+    }
     __device__ __forceinline__ void hess_prod(const double *, const double *v, double *Hv) const { hess_prod_tape(v, Hv); }
     __device__ __forceinline__ void update_multipliers(int) const {}
 
@@ -189,7 +196,8 @@ struct WaveProblem {
             M::xt_store(L, Xt + (size_t)k * M::XT_DOUBLES, s_t);
             s_t = M::rk4_tan(L, cur, s_t, uc_t, st + (size_t)k * M::ST_D4_PER_STAGE);
         };
-        M::prefetch_fwd(L, tape, tbuf0);
+        if (!primed)
+            M::prefetch_fwd(L, tape, tbuf0);
         for (int k = 0; k < N; k += 2) {
             stage_fwd(k, tbuf0, tbuf1);
             if (k + 1 < N)
@@ -229,6 +237,8 @@ struct WaveProblem {
             stage_rev(k - 1, tbuf0, tbuf1);
         }
         wave_sync();
+        M::prefetch_fwd(L, tape, tbuf0); // for the next product (the CG algebra runs meanwhile)
+        primed = true;
     }
 
     // ---- vector helpers over the LDS vectors: lane l owns i = l, l+64, ... ------------------
@@ -774,6 +784,7 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
         pb, P, P.tolerance, P.max_time_s, t_start, x_io, st,
         trace ? a.trace + (size_t)inst * a.trace_cap * TRACE_COLS : nullptr, a.trace_cap,
         a.lbfgs ? a.lbfgs + (size_t)inst * 2 * P.lbfgs_memory * a.npad : nullptr);
+    wait_vmem(); // the tape rows the last product left in flight for a successor
     for (int j = 0; j < nj; ++j) { // solution (or the untouched guess when nothing was overwritten)
         int i = j * WAVE + lane;
         if (i < n)
@@ -847,6 +858,7 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
             pb.hess_prod_tape(v, o);
         s1 = (double)(clock64() - c0);      // shader cycles
         s2 = (double)(wall_clock64() - w0); // 100 MHz ticks
+        wait_vmem();                        // the rows left in flight for a successor
     } else {
         pb.prox_grad_step(a.gamma, u, v, o, o2, s0, s1);
         s2 = pb.proj_grad_unit_norm(u, v);

@@ -5,6 +5,8 @@ specification), which is stricter than the 1e-10 relative tolerance t
 north star states; RTOL below is that stated tolerance and is what the asserts enforce
 where a comparison is not required to be exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -177,3 +179,23 @@ def test_config4_horizon_sweep(rng):
             batch.close()
             st_o, in_o, _, _ = ob.mpc(N, num_sim, warm)
             assert np.array_equal(states[:, 0], st_o) and np.array_equal(inputs[:, 0], in_o)
+
+
+def test_bench_workload_matches_oracle_at_full_occupancy():
+    """The 600-instance replay batch bench.py times (BASELINE.json configs[1], warm + cold), solved
+    in one launch with every SIMD of the chip busy: each instance equals the oracle's solve, and a
+    second launch reproduces the first (no dependence on scheduling)."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_hanging_chain_N60_warm300.npz"))
+    x0 = np.vstack([d["x0"], d["x0"]])
+    u0 = np.vstack([d["guess"], np.zeros_like(d["guess"])])
+    batch = pa.PantrBatch("hanging_chain", 60, len(x0), opts=pa.DODO_PANTR_OPTS)
+    u, st = batch.solve(x0, u0)
+    u2, st2 = batch.solve(x0, u0)
+    batch.close()
+    assert np.array_equal(u, u2) and np.array_equal(st["n_hess_psi_prod"], st2["n_hess_psi_prod"])
+    assert np.array_equal(u[:300], d["sol"])  # the recorded closed loop (committed fixture)
+    u_o, st_o = ob.solve_batch(60, x0, u0, ob.dodo_params(), nthreads=min(16, os.cpu_count() or 1))
+    assert np.array_equal(u, u_o)
+    for key in ("iterations", "n_hess_psi_prod", "cg_iterations", "status"):
+        assert np.array_equal(st[key], np.array([s[key] for s in st_o])), key
+
