@@ -121,7 +121,8 @@ struct ScalarALProblem {
             xn[l] = madd(M::c6, madd(2.0, k3[l], madd(2.0, k2[l], k1[l])) + k4[l], s[l]);
     }
     /// Adjoint of one RK4 step (wave-uniform values).  The Trig of each substage state is evaluated
-    /// once and serves the recomputed forward pass and the adjoint.  WITH_XN: also returns the
+    /// once and serves the recomputed forward pass and the adjoint (kept in its compact form in
+    /// between: with dual numbers the full form of three substages would hold 72 VGPRs).  WITH_XN: also returns the
     /// step itself (x_next), whose tangent parts are a column of the stage Jacobian.
     template <bool WITH_XN, class T>
     __device__ __forceinline__ void rk4_adj(const typename M::template Trig<T> &t1, const T (&s)[nx],
@@ -135,25 +136,25 @@ struct ScalarALProblem {
             if (WITH_XN)
                 ksum[l] = k[l];
         }
-        const auto t2 = M::trig_uniform(w2);
-        M::fc(t2, w2, u, k);
+        const auto c2 = M::trig_seed(w2);
+        M::fc(M::expand(c2), w2, u, k);
 #pragma unroll
         for (int l = 0; l < nx; ++l) {
             w3[l] = madd(M::hTs, k[l], s[l]);
             if (WITH_XN)
                 ksum[l] = madd(2.0, k[l], ksum[l]);
         }
-        const auto t3 = M::trig_uniform(w3);
-        M::fc(t3, w3, u, k);
+        const auto c3 = M::trig_seed(w3);
+        M::fc(M::expand(c3), w3, u, k);
 #pragma unroll
         for (int l = 0; l < nx; ++l) {
             w4[l] = madd(M::Ts, k[l], s[l]);
             if (WITH_XN)
                 ksum[l] = madd(2.0, k[l], ksum[l]);
         }
-        const auto t4 = M::trig_uniform(w4);
+        const auto c4 = M::trig_seed(w4);
         if (WITH_XN) {
-            M::fc(t4, w4, u, k);
+            M::fc(M::expand(c4), w4, u, k);
 #pragma unroll
             for (int l = 0; l < nx; ++l)
                 xn[l] = madd(M::c6, ksum[l] + k[l], s[l]);
@@ -168,13 +169,13 @@ struct ScalarALProblem {
             kb4[l]  = sg;
             sbar[l] = mu[l];
         }
-        M::fc_adj(t4, u, kb4, a, ubar);
+        M::fc_adj(M::expand(c4), u, kb4, a, ubar);
 #pragma unroll
         for (int l = 0; l < nx; ++l) {
             sbar[l] = sbar[l] + a[l];
             kb3[l]  = madd(M::Ts, a[l], kb3[l]);
         }
-        M::fc_adj(t3, u, kb3, a, ua);
+        M::fc_adj(M::expand(c3), u, kb3, a, ua);
 #pragma unroll
         for (int c = 0; c < nu; ++c)
             ubar[c] = ubar[c] + ua[c];
@@ -183,7 +184,7 @@ struct ScalarALProblem {
             sbar[l] = sbar[l] + a[l];
             kb2[l]  = madd(M::hTs, a[l], kb2[l]);
         }
-        M::fc_adj(t2, u, kb2, a, ua);
+        M::fc_adj(M::expand(c2), u, kb2, a, ua);
 #pragma unroll
         for (int c = 0; c < nu; ++c)
             ubar[c] = ubar[c] + ua[c];

@@ -71,6 +71,26 @@ struct QuadModelT {
         return {{v.s0, v.c0 * s[6].t}, {v.c0, -(v.s0 * s[6].t)}, {v.s1, v.c1 * s[7].t},
                 {v.c1, -(v.s1 * s[7].t)}, {v.s2, v.c2 * s[8].t}, {v.c2, -(v.s2 * s[8].t)}};
     }
+    /// Compact form of a Trig that is kept alive across the substages of a Runge-Kutta adjoint: the
+    /// wave-uniform values (scalar registers) and, for dual numbers, the three angle tangents; the
+    /// six tangent parts are rebuilt by expand() where the Trig is used (same products, same bits).
+    struct TrigSeedD {
+        Trig<double> v;
+    };
+    struct TrigSeedT {
+        Trig<double> v;
+        double a0, a1, a2;
+    };
+    __device__ static __forceinline__ TrigSeedD trig_seed(const double *s) { return {trig_uniform(s)}; }
+    __device__ static __forceinline__ TrigSeedT trig_seed(const dual *s) {
+        return {trig_uniform(s[6].v, s[7].v, s[8].v), s[6].t, s[7].t, s[8].t};
+    }
+    __device__ static __forceinline__ Trig<double> expand(const TrigSeedD &c) { return c.v; }
+    __device__ static __forceinline__ Trig<dual> expand(const TrigSeedT &c) {
+        const Trig<double> &v = c.v;
+        return {{v.s0, v.c0 * c.a0}, {v.c0, -(v.s0 * c.a0)}, {v.s1, v.c1 * c.a1},
+                {v.c1, -(v.s1 * c.a1)}, {v.s2, v.c2 * c.a2}, {v.c2, -(v.s2 * c.a2)}};
+    }
     template <bool UNIFORM, class T>
     __device__ static __forceinline__ Trig<T> trig_of(const T *s) {
         if constexpr (UNIFORM)
