@@ -100,11 +100,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the PANTR solver has no CPU path")
+    # Rehearsal aid for the multi-rank path on a box with fewer GPUs than ranks (several ranks share
+    # a device, rendezvous over gloo): PANTR_BENCH_REHEARSAL=1.  Never set by the driver.
+    rehearsal = os.environ.get("PANTR_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")  # RCCL; used for barriers + one MAX reduction only
+        # RCCL ("nccl"); used for barriers + one MAX reduction only
+        dist.init_process_group(backend="gloo" if rehearsal else "nccl")
 
     x0_h, guess_h, sol_warm = load_workload()
     B, n = guess_h.shape
@@ -144,7 +150,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if S > 1:  # the last launch of every stream (durations overlap: they are latencies, not shares)
         kernel_ms = [b.last_kernel_ms() for b in batches[:min(S, args.steps)]]
-    elapsed = sharding.max_over_ranks(elapsed, dev)  # MAX over ranks (identity at N = 1)
+    elapsed = sharding.max_over_ranks(elapsed, None if rehearsal else dev)  # MAX over ranks (identity at N = 1)
 
     stats = np.frombuffer(stats_t.cpu().numpy().tobytes(), dtype=pa.STATS_DTYPE)
     converged = int(np.sum(stats["status"] == 1))
