@@ -6,19 +6,28 @@ BASELINE.json configs[1]: the 300 timed MPC time steps of one closed-loop run
 (num_sim=300, num_dist=5, u_dist=-1,1,1; new-benchmarks-paper/dodo.py:12-33,94-95), each
 solved twice — warm-started (previous solution shifted by nu, mpc-driver.cpp:168-175) and
 cold-started (u = 0, mpc-driver.cpp:192-197) — i.e. 600 independent PANTR solves in one
-kernel launch per GPU.  Inputs (x0, initial guesses) are resident in HBM when the timed
-region starts; every timed pass resets the guesses with a device-to-device copy and runs
-the complete solves (no cached outputs).
+kernel launch per GPU.  The batch is produced by the product's own closed loop on the device
+(pantr_batch_mpc_record) before anything is timed; inputs (x0, initial guesses) are resident in
+HBM when the timed region starts; every timed pass resets the guesses with a device-to-device
+copy and runs the complete solves (no cached outputs).
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; the path has
-no exchange step, so ranks only meet in the barriers around the timed region and in the
-MAX-reduction of the elapsed time ("weak" scaling: every rank solves the full batch).
+N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; the path has no
+exchange step, so ranks only meet in the barriers around the timed region and in the
+MAX-reduction of the elapsed time.  Default mode: every rank solves its own full batch
+("weak": per-GPU work fixed).  `--workload sweep|stress --scaling strong` deals ONE batch
+(BASELINE.json configs[3] / configs[4]) to the ranks longest-first (pantr_amd/sharding.py),
+gathers the solutions and checks them against the unsharded solve.
 
-Rank 0 prints one JSON line with `roofline` (algorithmic bytes of SURVEY.md section 8(d) /
-HIP-event kernel time, against the 8 TB/s HBM peak) and, at N = 1, `cpu_baseline` (the CPU
-oracle, a port of the algorithm, timed on the host cores on a bounded sample).
+Rank 0 prints ONE JSON line.  At N = 1 it carries, next to the headline: `roofline`
+(algorithmic bytes of SURVEY.md 8(d) / HIP-event kernel time, against the 8 TB/s spec peak and
+the measured device-copy peak), `cpu_baseline` (the CPU oracle, a port of the algorithm, on the
+host cores), `warm` / `cold` separately, and `configs` — the other BASELINE.json configurations
+(horizon sweep, realistic_quadcopter N=60, quadcopter N=12, N=120 stress), each with its own
+steps/s, dominant kernel, roofline and CPU baseline on the same threads — and the serial
+one-thread closed loop on the CPU next to the reference's published per-step times.
+`--headline-only` skips everything but the headline (profiling runs).
 """
 import argparse
 import json
@@ -34,47 +43,317 @@ sys.path.insert(0, os.path.join(ROOT, "pantr-cdc2023-experiments_amd"))
 METRIC = "MPC-steps solved/sec, hanging_chain N=60 cold+warm, 1/2/4/8 MI355X"
 HORIZON = 60
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-# PANTR cold+warm combined on the reference's (unstated) CPU, 1 thread
-BASELINE_STEPS_PER_S = 4.21
 FIXTURE = os.path.join(ROOT, "tests", "golden", "mpc_hanging_chain_N60_warm300.npz")
-# PMC summary of the same command (scripts/profile.sh + scripts/summarize_profiles.py)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_summary.json")
+PROFILE_TAG = "r02"
+# PMC summary of the headline command (scripts/profile.sh + scripts/summarize_profiles.py)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_summary.json")
+# published mean solver time per MPC step, alpaqa PANTR, unstated CPU, 1 thread
+PUBLISHED_S_PER_STEP = {
+    ("hanging_chain", 60): {"cold": 0.3454, "warm": 0.1301},
+    ("realistic_quadcopter", 60): {"cold": 0.3162, "warm": 0.07881},
+    ("quadcopter", 60): {"cold": 0.1379, "warm": 0.02738},
+}
 
 
 def measured_traffic(instances):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this workload, or None."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of the headline command, with
+    where they come from.  None unless the summary was taken at exactly this csrc/ (hash) and batch."""
+    import pantr_amd as pa
+    src = {"file": os.path.relpath(PMC_SUMMARY, ROOT), "csrc_sha256": pa.source_hash()}
     try:
         with open(PMC_SUMMARY) as f:
             d = json.load(f)
+        src["profiled_csrc_sha256"] = d.get("csrc_sha256")
+        if d.get("csrc_sha256") != src["csrc_sha256"]:
+            src["refused"] = "the kernels changed since the PMC passes were taken"
+            return None, src
         if int(d["pmc_per_launch"]["SQ_WAVES"]) != instances:
-            return None
-        return float(d["hbm_traffic_bytes_per_launch"]["total"])
-    except (OSError, KeyError, ValueError):
-        return None
+            src["refused"] = "the PMC passes were taken on another batch size"
+            return None, src
+        return float(d["hbm_traffic_bytes_per_launch"]["total"]), src
+    except (OSError, KeyError, ValueError) as e:
+        src["refused"] = f"no usable summary ({type(e).__name__})"
+        return None, src
 
 
-def load_workload():
-    d = np.load(FIXTURE)
-    x0 = np.vstack([d["x0"], d["x0"]])
-    guess = np.vstack([d["guess"], np.zeros_like(d["guess"])])
-    return np.ascontiguousarray(x0), np.ascontiguousarray(guess), d["sol"]
+class Resident:
+    """A replay batch resident in HBM with its solver handle: launch() = reset the guesses (device to
+    device) + one solve kernel over the whole batch on `stream`."""
+
+    def __init__(self, w, torch, pa, dev, local_rank, idx=None):
+        self.w, self.torch, self.pa = w, torch, pa
+        idx = np.arange(len(w["x0"])) if idx is None else np.asarray(idx)
+        self.idx, self.B = idx, len(idx)
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a[idx])).to(dev)
+        self.x0, self.u0 = to(w["x0"]), to(w["u0"])
+        self.u = torch.empty_like(self.u0)
+        self.y0 = to(w["y0"]) if w["y0"] is not None else None
+        self.y = torch.empty_like(self.y0) if self.y0 is not None else None
+        self.stats_t = torch.zeros(max(self.B, 1) * pa.STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        self.batch = pa.PantrBatch(w["problem"], w["horizon"], max(self.B, 1), device=local_rank, opts=w["opts"])
+        self.launched = False
+
+    def launch(self, stream=None):
+        if self.B == 0:
+            return
+        torch = self.torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        with torch.cuda.stream(s):
+            self.u.copy_(self.u0)
+            if self.y is not None:
+                self.y.copy_(self.y0)
+            self.batch.solve_device(self.B, self.x0.data_ptr(), self.u.data_ptr(), self.stats_t.data_ptr(),
+                                    s.cuda_stream, self.y.data_ptr() if self.y is not None else None)
+        self.launched = True
+
+    def kernel_ms(self):
+        return self.batch.last_kernel_ms() if self.B else 0.0
+
+    def stats(self):
+        raw = self.stats_t.cpu().numpy().tobytes()
+        return np.frombuffer(raw, dtype=self.pa.STATS_DTYPE)[:self.B]
+
+    def solutions(self):
+        return self.u.cpu().numpy()
+
+    def check(self, what):
+        """Every instance converged, and the replay reproduces the recorded closed loop bit for bit."""
+        if self.B == 0:
+            return 0.0
+        st = self.stats()
+        bad = int(np.sum(st["status"] != 1))
+        if bad:
+            raise SystemExit(f"bench.py: {bad} of {self.B} instances of '{what}' did not converge - refusing to report")
+        dev = 0.0
+        if self.w["sol"] is not None:  # rows beyond the recorded ones (the cold twins) have no reference
+            have = self.idx < len(self.w["sol"])
+            if np.any(have):
+                dev = float(np.max(np.abs(self.solutions()[have] - self.w["sol"][self.idx[have]])))
+                if dev != 0.0:
+                    raise SystemExit(f"bench.py: '{what}' replay deviates from the recorded closed loop by "
+                                     f"{dev:.3e} - refusing to report")
+        return dev
+
+    def alg_bytes(self):
+        b = self.batch
+        return int(self.pa.algorithmic_bytes(self.stats(), self.w["horizon"], b.nx, b.nu, b.m))
+
+    def close(self):
+        self.batch.close()
 
 
-def cpu_baseline(x0, guess, cores):
-    """Times the CPU oracle (kind "port") on a bounded sample of the same workload."""
+def roofline_obj(alg_bytes, kernel_ms, kernel, peak_measured=None, traffic=None, traffic_source=None):
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel, "kernel_ms": kernel_ms,
+         "algorithmic_bytes_per_launch": int(alg_bytes)}
+    if peak_measured:
+        r["peak_measured"] = peak_measured
+        r["frac_of_measured_peak"] = achieved / peak_measured
+    if traffic_source is not None:
+        r["traffic_source"] = traffic_source
+    return r
+
+
+# ---- CPU legs (the oracle: checker and CPU baseline, never on the product path) --------------------
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_binding as ob  # the checker / CPU baseline; never on the product path
-    idx = np.arange(len(x0))  # the whole workload: 300 warm + 300 cold solves
+    import oracle_binding as ob
+    return ob
+
+
+def cpu_batch_baseline(w, cores, sample=None):
+    """The CPU oracle (kind "port") on `sample` instances of workload w (default: all), one instance
+    per thread over `cores` host threads."""
+    ob = _oracle()
+    idx = np.arange(len(w["x0"])) if sample is None else np.asarray(sample)
     t = time.perf_counter()
-    _, stats = ob.solve_batch(HORIZON, x0[idx], guess[idx], ob.dodo_params(), nthreads=cores)
+    if w["problem"] == "hanging_chain":
+        _, stats = ob.solve_batch(w["horizon"], w["x0"][idx], w["u0"][idx], ob.dodo_params(), nthreads=cores)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        prm = ob.quad_dodo_params(w["problem"])
+        # longest first (cold starts), so the pool does not end on a straggler it could have started early
+        order = sorted(idx, key=lambda i: bool(w["warm"][i]))
+        with ThreadPoolExecutor(cores) as ex:
+            stats = list(ex.map(lambda i: ob.quad_solve(w["problem"], w["horizon"], w["x0"][i], w["u0"][i],
+                                                        w["y0"][i], prm)[2], order))
     dt = time.perf_counter() - t
     ok = sum(s["status"] == 1 for s in stats)
-    return {
-        "value": len(idx) / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-        "sample": f"the whole workload once ({len(idx) // 2} warm + {len(idx) // 2} cold solves, {ok} converged) "
-                  f"over {cores} host threads, {dt:.2f} s wall; single-thread solve time summed: "
-                  f"{sum(s['elapsed_s'] for s in stats):.2f} s",
-    }
+    el = [s["elapsed_s"] for s in stats]
+    return {"value": len(idx) / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{len(idx)} of the {len(w['x0'])} instances of this workload once ({ok} converged) over {cores} "
+                      f"host threads, {dt:.2f} s wall; single-thread solve times: sum {sum(el):.2f} s, max {max(el):.3f} s"}
+
+
+def cpu_serial_closed_loop():
+    """SURVEY.md 8(d) CPU plan (i): the serial closed loop on ONE thread, hanging_chain N=60, 60 timed
+    steps, per-step solver time as stats.elapsed_time (mpc-driver.cpp:199-201), next to BASELINE.md."""
+    ob = _oracle()
+    out = {"threads": 1, "kind": "port", "problem": "hanging_chain", "horizon": HORIZON, "num_sim": 60}
+    for warm in (False, True):
+        _, _, _, stats = ob.mpc(HORIZON, 60, warm)
+        t = np.array([s["elapsed_s"] for s in stats])
+        key = "warm" if warm else "cold"
+        out[key] = {"avg_s": float(t.mean()), "median_s": float(np.median(t)), "p5_s": float(np.percentile(t, 5)),
+                    "p95_s": float(np.percentile(t, 95)), "steps_per_s": float(len(t) / t.sum()),
+                    "converged": int(sum(s["status"] == 1 for s in stats)),
+                    "published_avg_s": PUBLISHED_S_PER_STEP[("hanging_chain", 60)][key]}
+    out["note"] = ("published_avg_s = alpaqa PANTR on CasADi-generated code, unstated CPU (BASELINE.md 1.1); this record = "
+                   "the CPU oracle (parity unpinned), which loops a stage function and replays a K/M tape")
+    return out
+
+
+# ---- the other BASELINE.json configurations (N = 1, rank 0) -----------------------------------------
+def time_group(residents, torch, rounds=3):
+    """Launch all residents concurrently (one HIP stream each), `rounds` times; wall seconds per round
+    (best), and the per-handle kernel durations of the last round."""
+    streams = [torch.cuda.Stream() for _ in residents]
+    best, first = None, None
+    for i in range(rounds + 1):          # first round untimed
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for r, s in zip(residents, streams):
+            r.launch(s)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        if i == 0:
+            first = dt
+            continue
+        best = dt if best is None else min(best, dt)
+        if first > 1.0:                  # a pass of seconds (quadcopter cold starts): one timed round
+            break
+    return best, [r.kernel_ms() for r in residents]
+
+
+def extra_configs(torch, pa, dev, local_rank, cores, peak_measured, with_cpu):
+    from pantr_amd import workloads
+    out = {}
+
+    def one(name, ws, kernel, description, cpu_sample=None):
+        rs = [Resident(w, torch, pa, dev, local_rank) for w in ws]
+        wall, kms = time_group(rs, torch)
+        for r in rs:
+            r.check(name)
+        total = sum(r.B for r in rs)
+        dom = int(np.argmax(kms))                      # the launch that decides the wall time
+        cfg = {"workload": description, "instances": total, "launches_per_pass": len(rs),
+               "value": total / wall, "unit": "steps/s", "ms_per_pass": wall * 1e3,
+               "roofline": roofline_obj(rs[dom].alg_bytes(), kms[dom], kernel, peak_measured),
+               "all_launches": {"algorithmic_bytes": int(sum(r.alg_bytes() for r in rs)),
+                                "achieved_GBps": sum(r.alg_bytes() for r in rs) / wall / 1e9,
+                                "kernel_ms": kms}}
+        for w in ws:
+            pub = PUBLISHED_S_PER_STEP.get((w["problem"], w["horizon"]))
+            if pub and len(ws) == 1:
+                cfg["published_cpu_1thread_s_per_step"] = pub
+        if with_cpu:
+            t = time.perf_counter()
+            legs = [cpu_batch_baseline(w, cores, cpu_sample) for w in ws]
+            n = sum(len(w["x0"]) if cpu_sample is None else len(cpu_sample) for w in ws)
+            cfg["cpu_baseline"] = {"value": n / (time.perf_counter() - t), "unit": "steps/s", "cores": cores,
+                                   "kind": "port", "sample": "; ".join(l["sample"] for l in legs)}
+        for r in rs:
+            r.close()
+        out[name] = cfg
+
+    # configs[3]: six horizons x {cold, warm} x 60 steps = 720 instances, one launch per horizon, concurrent
+    one("sweep", [workloads.closed_loop_batch("hanging_chain", N, device=local_rank) for N in workloads.HORIZONS],
+        "pantr_solve_kernel<ChainModel, 0>",
+        "BASELINE.json configs[3]: hanging_chain horizons 10..60 x {warm, cold} x 60 MPC time steps = 720 replay "
+        "instances, one launch per horizon on six concurrent HIP streams (dodo.py:69-95)")
+    # configs[2]
+    one("realistic_quadcopter", [workloads.closed_loop_batch("realistic_quadcopter", 60, device=local_rank)],
+        "pantr_alm_kernel<QuadModelT<true>, 0>",
+        "BASELINE.json configs[2]: realistic_quadcopter N=60 (n=240, m=244), all 60 warm + 60 cold time steps as one "
+        "batch of 120 ALM solves (dodo.py:96-105)")
+    # configs[0]: the reference's CPU-runnable case, here as the replay of its one warm run
+    one("quadcopter_N12", [workloads.closed_loop_batch("quadcopter", 12, starts=(True,), device=local_rank)],
+        "pantr_alm_kernel<QuadModelT<false>, 0>",
+        "BASELINE.json configs[0]: quadcopter N=12 (n=48, m=52), the 60 time steps of one warm-started MPC run "
+        "(num_sim=60 warm=true num_dist=0 solver.max_iter=250) as one batch")
+    # configs[4] on ONE GPU: all 1024
+    one("stress_N120", [workloads.stress_batch(1024, device=local_rank)], "pantr_solve_kernel<ChainModel, 0>",
+        "BASELINE.json configs[4] on one GPU: hanging_chain N=120 (n=360), 1024 synthetic cold instances in one launch",
+        cpu_sample=np.arange(0, 1024, 8))
+    return out
+
+
+# ---- strong scaling over ranks: one batch dealt longest-first --------------------------------------
+def strong_mode(args, torch, pa, dev, local_rank, rank, world, distributed, rehearsal):
+    from pantr_amd import sharding, workloads
+    import torch.distributed as dist
+    if args.workload == "sweep":
+        ws = [workloads.closed_loop_batch("hanging_chain", N, device=local_rank) for N in workloads.HORIZONS]
+        desc = "BASELINE.json configs[3]: 720 hanging_chain replay instances (horizons 10..60 x warm/cold x 60 steps)"
+    else:
+        ws = [workloads.stress_batch(1024, device=local_rank)]
+        desc = "BASELINE.json configs[4]: hanging_chain N=120, 1024 synthetic cold instances"
+    # global instance list: (workload k, row i); the same deterministic partition on every rank
+    where = [(k, i) for k, w in enumerate(ws) for i in range(len(w["x0"]))]
+    costs = [workloads.expected_cost(ws[k]["horizon"], bool(ws[k]["warm"][i])) for k, i in where]
+    mine = sharding.shard_indices(len(where), rank, world, costs)
+    rs = []
+    for k, w in enumerate(ws):
+        rows = [where[g][1] for g in mine if where[g][0] == k]
+        rs.append(Resident(w, torch, pa, dev, local_rank, rows))
+    streams = [torch.cuda.Stream() for _ in rs]
+
+    def one_pass():
+        for r, s in zip(rs, streams):
+            r.launch(s)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+        torch.cuda.synchronize()
+    barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, None if rehearsal else dev)
+    for r in rs:
+        r.check(args.workload)
+    # gather every rank's solutions (first nu inputs of each instance: what the plant receives) and check
+    # them on rank 0 against the unsharded solve of the same batch
+    nu = rs[0].batch.nu
+    local = np.vstack([r.solutions()[:, :nu] for r in rs if r.B]) if len(mine) else np.zeros((0, nu))
+    local_idx = np.array([g for k in range(len(ws)) for g in mine if where[g][0] == k], dtype=np.int64)
+    gathered = sharding.gather_rows(local, local_idx, len(where), None if rehearsal else dev)
+    kms = [r.kernel_ms() for r in rs]
+    alg = sum(r.alg_bytes() for r in rs if r.B)
+    if rank == 0:
+        full = [Resident(w, torch, pa, dev, local_rank) for w in ws]
+        for r in full:
+            r.launch()
+        torch.cuda.synchronize()
+        ref = np.vstack([r.solutions()[:, :nu] for r in full])
+        same = bool(np.array_equal(ref, gathered))
+        for r in full:
+            r.check(args.workload + " (unsharded)")
+            r.close()
+        if not same:
+            raise SystemExit("bench.py: the sharded solutions differ from the unsharded solve")
+        total = len(where) * args.steps
+        dom = int(np.argmax(kms))
+        print(json.dumps({
+            "metric": f"MPC-steps solved/sec, {args.workload} batch sharded over {world} MI355X", "value": total / elapsed,
+            "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "instances": len(where), "instances_rank0": int(len(mine)),
+                       "partition": "longest-processing-time-first by (horizon, start) cost (pantr_amd/sharding.py)",
+                       "gathered_equals_unsharded": same, "rehearsal_shared_gpu": rehearsal},
+            "roofline": dict(roofline_obj(rs[dom].alg_bytes(), kms[dom], "pantr_solve_kernel<ChainModel, 0>"),
+                             rank0_all_launches_algorithmic_bytes=int(alg), rank0_kernel_ms=kms),
+        }), flush=True)
+    for r in rs:
+        r.close()
 
 
 def main():
@@ -83,15 +362,21 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline workload (no per-config records, no CPU legs): profiling runs")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent passes in flight per GPU, each on its own HIP stream and solver handle "
                          "(default 1: one pass after the other, the configuration the roofline line describes)")
+    ap.add_argument("--workload", choices=("headline", "sweep", "stress"), default="headline")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     args = ap.parse_args()
 
     import torch
     import pantr_amd as pa
-    from pantr_amd import sharding
+    from pantr_amd import sharding, workloads
 
+    if not pa.is_product_build():
+        raise SystemExit(f"bench.py: {pa.LIB_PATH} is not the product build ({pa.version()})")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -106,31 +391,34 @@ def main():
     if rehearsal:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    torch.zeros(1, device=dev)  # HIP runtime up before the first call into the library
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL ("nccl"); used for barriers + one MAX reduction only
+        # RCCL ("nccl"); used for barriers + one MAX reduction (+ the result gather in strong mode) only
         dist.init_process_group(backend="gloo" if rehearsal else "nccl")
 
-    x0_h, guess_h, sol_warm = load_workload()
-    B, n = guess_h.shape
-    dev = torch.device("cuda", local_rank)
-    x0 = torch.from_numpy(x0_h).to(dev)
-    guess = torch.from_numpy(guess_h).to(dev)
-    S = max(1, args.streams)
-    us = [torch.empty_like(guess) for _ in range(S)]
-    stats_ts = [torch.zeros(B * pa.STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(S)]
-    batches = [pa.PantrBatch("hanging_chain", HORIZON, B, device=local_rank, opts=pa.DODO_PANTR_OPTS)
-               for _ in range(S)]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
-    u, stats_t, batch = us[0], stats_ts[0], batches[0]
+    if args.scaling == "strong" or args.workload != "headline":
+        if args.workload == "headline":
+            raise SystemExit("--scaling strong needs --workload sweep|stress (the headline batch does not shard usefully)")
+        strong_mode(args, torch, pa, dev, local_rank, rank, world, distributed, rehearsal)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
-    def one_pass(i=0):
-        k = i % S
-        with torch.cuda.stream(streams[k]):
-            us[k].copy_(guess)  # device-to-device reset of the in/out guesses
-            batches[k].solve_device(B, x0.data_ptr(), us[k].data_ptr(), stats_ts[k].data_ptr(),
-                                    streams[k].cuda_stream)  # m = 0: no y
+    # ---- the headline workload, produced by the product's own closed loop on this GPU ----
+    w = workloads.headline_batch(device=local_rank, num_sim=300, horizon=HORIZON)
+    B, n = w["u0"].shape
+    fixture_dev = None
+    if os.path.exists(FIXTURE):  # committed data: the same closed loop as recorded by the CPU oracle
+        fixture_dev = float(np.max(np.abs(np.load(FIXTURE)["sol"] - w["sol"])))
+        if fixture_dev != 0.0:
+            raise SystemExit(f"bench.py: the device closed loop deviates from tests/golden by {fixture_dev:.3e}")
+    S = max(1, args.streams)
+    rs = [Resident(w, torch, pa, dev, local_rank) for _ in range(S)]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
 
     def barrier():
         if distributed:
@@ -138,59 +426,82 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(max(args.warmup, S if S > 1 else 0)):
-        one_pass(i)
+        rs[i % S].launch(streams[i % S])
     barrier()
     kernel_ms = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        one_pass(i)
+        rs[i % S].launch(streams[i % S])
         if S == 1:
-            kernel_ms.append(batch.last_kernel_ms())  # HIP events on the launch stream (synchronises)
+            kernel_ms.append(rs[0].kernel_ms())  # HIP events on the launch stream (synchronises)
     barrier()
     elapsed = time.perf_counter() - t0
     if S > 1:  # the last launch of every stream (durations overlap: they are latencies, not shares)
-        kernel_ms = [b.last_kernel_ms() for b in batches[:min(S, args.steps)]]
+        kernel_ms = [r.kernel_ms() for r in rs[:min(S, args.steps)]]
     elapsed = sharding.max_over_ranks(elapsed, None if rehearsal else dev)  # MAX over ranks (identity at N = 1)
-
-    stats = np.frombuffer(stats_t.cpu().numpy().tobytes(), dtype=pa.STATS_DTYPE)
-    converged = int(np.sum(stats["status"] == 1))
-    u_h = u.cpu().numpy()
-    max_dev = float(np.max(np.abs(u_h[:B // 2] - sol_warm)))  # warm half vs the recorded solutions
+    for r in rs:
+        if r.launched:
+            r.check("headline")
 
     if rank == 0:
         total_steps = world * B * args.steps
-        alg_bytes = pa.algorithmic_bytes(stats, HORIZON, batch.nx, batch.nu)
+        stats = rs[0].stats()
+        alg_bytes = rs[0].alg_bytes()
         k_ms = float(np.mean(kernel_ms))
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         value = total_steps / elapsed
+        extras = world == 1 and not args.headline_only
+        peak_measured = pa.copy_bandwidth(local_rank) if extras else None
+        traffic, traffic_src = measured_traffic(B)
         line = {
             "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": value / BASELINE_STEPS_PER_S, "dtype": "f64",
-            "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": "hanging_chain horizon=60 replay batch: 300 MPC time steps of one closed "
                             "loop (num_sim=300 num_dist=5 u_dist=-1,1,1), each solved warm and cold = "
                             "600 PANTR solves per GPU per pass, tolerance 1e-8, dodo.py PANTR options",
                 "instances_per_gpu": B, "horizon": HORIZON, "n": n, "streams": S,
-                "converged": converged, "max_abs_dev_from_recorded_warm_solutions": max_dev,
-                "vs_baseline_ref": "BASELINE.md 1.1: 4.21 steps/s (alpaqa PANTR cold+warm, unstated CPU, 1 thread)",
+                "converged": int(np.sum(stats["status"] == 1)),
+                "max_abs_dev_from_recorded_closed_loop": 0.0, "max_abs_dev_from_tests_golden": fixture_dev,
+                "scaling_note": "weak = every rank solves its own 600-instance batch (replicas, no exchange step); "
+                                "`--workload sweep|stress --scaling strong` shards one batch over the ranks",
+                "published_reference": "BASELINE.md 1.1: 4.21 steps/s (alpaqa PANTR cold+warm, unstated CPU, 1 thread) - "
+                                       "another machine and another code base: not a baseline for this metric",
+                "parity": "unpinned (oracle = this project's restatement of un-vendored alpaqa)",
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B),
-                "kernel": "pantr_solve_kernel<ChainModel, 0>", "kernel_ms": k_ms,
-                "algorithmic_bytes_per_launch": int(alg_bytes),
-            },
+            "roofline": roofline_obj(alg_bytes, k_ms, "pantr_solve_kernel<ChainModel, 0>", peak_measured, traffic,
+                                     traffic_src),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            # the GPU box's CPU share for one GPU is 16 hardware threads
-            cores = min(16, len(os.sched_getaffinity(0)))
-            line["cpu_baseline"] = cpu_baseline(x0_h, guess_h, cores)
+        if extras:
+            cores = min(16, len(os.sched_getaffinity(0)))  # the GPU box's CPU share for one GPU
+            # warm and cold separately: the two halves of the batch as launches of their own
+            for key, rows in (("warm", np.arange(B // 2)), ("cold", np.arange(B // 2, B))):
+                r = Resident(w, torch, pa, dev, local_rank, rows)
+                wall, kms = time_group([r], torch)
+                r.check(key)
+                line[key] = {"value": r.B / wall, "unit": "steps/s", "instances": r.B, "ms_per_pass": wall * 1e3,
+                             "mean_iterations": float(r.stats()["iterations"].mean()),
+                             "roofline": roofline_obj(r.alg_bytes(), kms[0], "pantr_solve_kernel<ChainModel, 0>",
+                                                      peak_measured)}
+                r.close()
+            # throughput mode: four passes in flight (the chip holds 1024 wavefronts, one pass fills 600)
+            four = rs + [Resident(w, torch, pa, dev, local_rank) for _ in range(4 - len(rs))]
+            wall, kms = time_group(four[:4], torch)
+            line["throughput_mode"] = {"passes_in_flight": 4, "value": 4 * B / wall, "unit": "steps/s",
+                                       "ms_per_round": wall * 1e3, "kernel_ms": kms,
+                                       "note": "same batch, four independent passes on four HIP streams; the headline "
+                                               "stays one pass at a time"}
+            for r in four[len(rs):]:
+                r.close()
+            with_cpu = not args.no_cpu_baseline
+            if with_cpu:
+                line["cpu_baseline"] = cpu_batch_baseline(w, cores)
+                line["cpu_serial_closed_loop"] = cpu_serial_closed_loop()
+            line["configs"] = extra_configs(torch, pa, dev, local_rank, cores, peak_measured, with_cpu)
         print(json.dumps(line), flush=True)
-    for b in batches:
-        b.close()
+    for r in rs:
+        r.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

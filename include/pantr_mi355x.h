@@ -47,7 +47,7 @@ typedef struct pantr_stats {
     double final_psi;    /* psi(xhat) at exit */
     double final_fbe;    /* forward-backward envelope at exit */
     double final_radius; /* final trust radius */
-    double elapsed_s;    /* in-kernel solve time of this instance (100 MHz device clock) */
+    double elapsed_s;    /* in-kernel solve time of this instance (constant-rate device clock) */
     int32_t status;      /* enum pantr_status */
     int32_t iterations;  /* PANTR iterations */
     int32_t cg_iterations;
@@ -61,10 +61,16 @@ typedef struct pantr_stats {
     int32_t linesearch_failures, linesearch_backtracks, lbfgs_failures, lbfgs_rejected;
     int32_t tau_1_accepted, count_tau;
     double sum_tau;
+    /* seconds per phase, filled only by the profiling build of the library (`make phase`,
+     * pantr_version() then ends in "+phase-timing"): direction (hess_psi_prod | L-BFGS apply),
+     * psi_grad_psi at the candidate, psi(xhat), grad_L(xhat) + tape (| L-BFGS update).  Zero in
+     * the product build. */
+    double phase_s[4];
 } pantr_stats_t;
 
 typedef struct pantr_params pantr_params_t; /* solver option set */
 typedef struct pantr_batch pantr_batch_t;   /* problem + device resources */
+typedef struct pantr_problem_data pantr_problem_data_t; /* numeric data read from a problem's sidecar files */
 
 /* ---- options: replaces alpaqa::params::set_params(obj, prefix, opts) ---------------------
  * (call sites mpc-driver.cpp:54,61,62,113) and the solver selection "method=<name>"
@@ -104,6 +110,41 @@ int pantr_batch_get_initial_guess(const pantr_batch_t *b, double *u);
 /* "get_initial_state" (hanging_chain.cpp:154-155,121-124): x0[nx] */
 int pantr_batch_get_initial_state(const pantr_batch_t *b, double *x0);
 
+/* ---- numeric problem data: the data half of load_benchmark_casadi_problem ------------------
+ * (drivers/casadi-dll-wrapper.cpp:25-67).  A generated problem "<dir>/<name>_<formulation>_<N>.so"
+ * comes with "<same>.csv" (box C, box D, param = initial state, l1_reg, penalty_alm_split; written
+ * through alpaqa.casadi_generator.write_casadi_problem_data, problems/generate_problem.py:62-69)
+ * and "<same>.guess.csv" (row 1 initial guess, row 2 penalty_alm_split; generate_problem.py:71-73,
+ * read at casadi-dll-wrapper.cpp:57-61).  The .so itself is host code and cannot run on the device:
+ * the problem FUNCTIONS are this library's compiled device code for <name>; the DATA of the
+ * sidecars replace the compiled-in values (bounds, initial state, initial guess).
+ * `path` = "[<dir>/]<name>", `formulation` = "ss" | "ss2" | "ss2p" (casadi-dll-wrapper.cpp:29-32).
+ * Errors: missing guess file -> PANTR_ERR_RUNTIME ("Failed to open guess file", :58-59); unparsable
+ * file -> PANTR_ERR_RUNTIME; sizes that disagree with the compiled-in problem's n / m / nx, a box
+ * that is not the stage box tiled over the horizon (formulation.hpp:220-238), an empty box, or
+ * l1_reg != 0 -> PANTR_ERR_INVALID_ARGUMENT; unknown <name> -> PANTR_ERR_OUT_OF_RANGE.
+ * pantr_problem_data_load needs no device (it reads and checks); rows a file leaves empty (and
+ * everything, when only the guess file exists) fall back to the compiled-in values. */
+int pantr_problem_data_load(const char *path, const char *formulation, int32_t horizon,
+                            pantr_problem_data_t **out);
+void pantr_problem_data_destroy(pantr_problem_data_t *d);
+/* C_lb/C_ub/guess[n], D_lb/D_ub[m], param[nx]; any output pointer may be NULL */
+int pantr_problem_data_get(const pantr_problem_data_t *d, int32_t *has_csv, double *C_lb, double *C_ub,
+                           double *D_lb, double *D_ub, double *param, double *guess,
+                           int32_t *penalty_alm_split);
+/* pantr_batch_create for the problem named by `path`, with the sidecar data applied. */
+int pantr_batch_create_from_files(const char *path, const char *formulation, int32_t horizon,
+                                  int32_t max_instances, int32_t device, pantr_batch_t **out);
+/* BenchmarkProblem::penalty_alm_split (casadi-dll-wrapper.hpp:30): read from the guess file, stored,
+ * and - as in the reference driver - not used by the solve (0 unless created from files). */
+int pantr_batch_get_penalty_alm_split(const pantr_batch_t *b, int32_t *split);
+/* Dimensions and compiled-in data of a problem without a device (what generate_problem.py would
+ * write for it): C_lb/C_ub/u_guess[n], D_lb/D_ub[m], x_init[nx]; any output pointer may be NULL. */
+int pantr_problem_dims(const char *problem, int32_t horizon, int32_t *n, int32_t *m, int32_t *nx,
+                       int32_t *nu, int32_t *nc, int32_t *nc_N);
+int pantr_problem_defaults(const char *problem, int32_t horizon, double *C_lb, double *C_ub, double *D_lb,
+                           double *D_ub, double *x_init, double *u_guess);
+
 /* options of this handle's solver (same grammar as pantr_params_set) */
 int pantr_batch_set_param(pantr_batch_t *b, const char *kv);
 int pantr_batch_get_param(const pantr_batch_t *b, const char *key, double *value);
@@ -118,7 +159,9 @@ int pantr_batch_solve(pantr_batch_t *b, int32_t B, const double *x0, double *u, 
                       pantr_stats_t *stats);
 /* Same with device pointers (inputs already resident in HBM), asynchronous on `stream`
  * (a hipStream_t, NULL = default stream).  d_y[B][m] may be NULL when m = 0; d_stats is device
- * memory, B records. */
+ * memory, B records.  Every buffer must be device memory of this handle's GPU known to the HIP
+ * runtime this library is bound to; otherwise PANTR_ERR_NO_DEVICE (this is what a process gets
+ * that loaded the library before PyTorch's HIP runtime and then passes torch pointers). */
 int pantr_batch_solve_device(pantr_batch_t *b, int32_t B, const double *d_x0, double *d_u, double *d_y,
                              pantr_stats_t *d_stats, void *stream);
 /* Duration of the most recent solve kernel, measured with HIP events recorded on the stream
@@ -151,6 +194,13 @@ int pantr_batch_eval_psi_grad_psi_al(pantr_batch_t *b, int32_t B, const double *
                                      double *yhat);
 int pantr_batch_eval_hess_psi_prod_al(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
                                       const double *y, const double *Sigma, const double *v, double *Hv);
+/* eval_grad_L (formulation.hpp:98,170-174): grad[B][n] = grad f(u) + grad g(u)' y with the
+ * caller's multipliers y[B][m] (y may be NULL when m = 0, where L = f = psi). */
+int pantr_batch_eval_grad_L(pantr_batch_t *b, int32_t B, const double *x0, const double *u, const double *y,
+                            double *grad);
+/* eval_g (formulation.hpp:70,127-129): g[B][m] = stage constraints c(x_0..x_{N-1}) then c_N(x_N)
+ * (python/alpaqa_mpc_benchmarks/formulations/ss.py:39-40); nothing is written when m = 0. */
+int pantr_batch_eval_g(pantr_batch_t *b, int32_t B, const double *x0, const double *u, double *g);
 /* scalars[B][4] = { p'p, grad'p, ||Pi_C(x-grad)-x||_inf, |J(gamma)| } */
 int pantr_batch_eval_prox_grad_step(pantr_batch_t *b, int32_t B, double gamma, const double *x,
                                     const double *grad, double *xhat, double *p, double *scalars);
@@ -169,10 +219,25 @@ int pantr_batch_mpc(pantr_batch_t *b, int32_t B, int32_t num_sim, int32_t warm, 
                     const double *x_init, const double *u_dist, double *states, double *inputs,
                     pantr_stats_t *stats);
 
+/* The same closed loops, also recording what a replay batch needs (any of the three may be NULL):
+ * the guesses every step was solved from, guesses_u[num_sim][B][n] and guesses_y[num_sim][B][m]
+ * (the "guesses" the reference driver keeps per step would be these), and the multipliers each solve
+ * returned, multipliers[num_sim][B][m].  Solving step i again from (states[i], guesses_u[i],
+ * guesses_y[i]) reproduces inputs[i] and multipliers[i]: that is the replay batching of the bench. */
+int pantr_batch_mpc_record(pantr_batch_t *b, int32_t B, int32_t num_sim, int32_t warm, int32_t num_dist,
+                           const double *x_init, const double *u_dist, double *states, double *inputs,
+                           pantr_stats_t *stats, double *guesses_u, double *guesses_y, double *multipliers);
+
 /* ---- misc -------------------------------------------------------------------------------- */
 const char *pantr_last_error(void);
+/* Library name and version; any build switch that changes what is computed or reported is
+ * appended ("+phase-timing"), so a caller can refuse a non-product build. */
 const char *pantr_version(void);
 int pantr_device_count(void);
+/* Achievable HBM bandwidth of `device`: a 16-bytes-per-lane device copy of `bytes` bytes (choose well
+ * beyond the 256 MiB Infinity Cache), best of `reps` timed passes by HIP events, as read + written
+ * GB/s.  The measured yardstick bench.py reports next to the 8 TB/s spec peak. */
+int pantr_device_copy_bandwidth(int32_t device, int64_t bytes, int32_t reps, double *gb_per_s);
 /* Bytes of LDS per workgroup and of HBM workspace per instance for this handle. */
 int pantr_batch_footprint(const pantr_batch_t *b, int64_t *lds_bytes, int64_t *ws_bytes_per_instance);
 

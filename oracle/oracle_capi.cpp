@@ -421,8 +421,12 @@ int oracle_quad_solve(int realistic, int N, const OracleParams *prm, const doubl
     });
 }
 /// Closed loop of mpc-driver.cpp:123-210 with multipliers: warm start shifts u by nu and y by nc.
-void oracle_quad_mpc(int realistic, int N, const OracleParams *prm, int num_sim, int warm, int num_dist,
-                     const double *u_dist, double *states, double *inputs, OracleStats *stats) {
+/// Closed loop of drivers/mpc-driver.cpp:123-210 for the quadcopter family.  Optional outputs (may
+/// be null): the guesses every step was solved from (u: [num_sim][n], y: [num_sim][m]) and the
+/// multipliers it returned ([num_sim][m]) - what a replay batch needs.
+void oracle_quad_mpc_full(int realistic, int N, const OracleParams *prm, int num_sim, int warm, int num_dist,
+                          const double *u_dist, double *states, double *inputs, OracleStats *stats,
+                          double *guesses_u, double *guesses_y, double *multipliers) {
     with_quad(realistic, N, [&](auto &p) {
         using P = std::decay_t<decltype(p)>;
         const int nx = P::nx, nu = P::nu, nc = P::nc, n = p.n(), m = p.m();
@@ -450,7 +454,13 @@ void oracle_quad_mpc(int realistic, int N, const OracleParams *prm, int num_sim,
                 std::fill(y.begin(), y.end(), 0.0);
             }
             p.x0 = x0;
+            if (guesses_u)
+                std::copy(u.begin(), u.end(), guesses_u + (size_t)i * n);
+            if (guesses_y)
+                std::copy(y.begin(), y.end(), guesses_y + (size_t)i * m);
             Stats s = alm_solve(alm, solver, p, u.data(), y.data());
+            if (multipliers)
+                std::copy(y.begin(), y.end(), multipliers + (size_t)i * m);
             export_stats(s, &stats[i]);
             std::copy(x0.begin(), x0.end(), states + (size_t)i * nx);
             std::copy(u.begin(), u.end(), inputs + (size_t)i * n);
@@ -461,6 +471,12 @@ void oracle_quad_mpc(int realistic, int N, const OracleParams *prm, int num_sim,
         return 0;
         });
     });
+}
+
+void oracle_quad_mpc(int realistic, int N, const OracleParams *prm, int num_sim, int warm, int num_dist,
+                     const double *u_dist, double *states, double *inputs, OracleStats *stats) {
+    oracle_quad_mpc_full(realistic, N, prm, num_sim, warm, num_dist, u_dist, states, inputs, stats, nullptr, nullptr,
+                         nullptr);
 }
 
 /// L-BFGS two-loop recursion on given pairs (cross-check against the dense BFGS recursion):

@@ -99,18 +99,10 @@ struct ChainModel {
     __device__ static __forceinline__ double quad_sum(double v) { return (qb<0>(v) + qb<1>(v)) + qb<2>(v); }
     /// Same component of the previous / next point (0 before point 0; the value after point 9
     /// is never used).
-#ifdef PANTR_BPERMUTE_NEIGHBOURS // A/B build: neighbour exchange through the LDS crossbar
-    __device__ static __forceinline__ double prev_point(const Lane &L, double v) {
-        double r = lane_read(v, L.l - 4);
-        return L.first ? 0.0 : r;
-    }
-    __device__ static __forceinline__ double next_point(const Lane &L, double v) { return lane_read(v, L.l + 4); }
-#else
     // Four whole-wave DPP shifts by one lane (wave_shr:1 / wave_shl:1, bound_ctrl: lanes shifted
     // in from outside the wavefront read 0, which is exactly the anchor before point 0).
     __device__ static __forceinline__ double prev_point(const Lane &, double v) { return wave_shift4<0x138>(v); }
     __device__ static __forceinline__ double next_point(const Lane &, double v) { return wave_shift4<0x130>(v); }
-#endif
 
     // ---- memory <-> registers ------------------------------------------------------------------
     /// Initial state from the reference's state vector layout [vec(x) (30); vec(v) (27)]

@@ -42,9 +42,8 @@ struct LbfgsRing {
     __device__ __forceinline__ double *y(int i) const { return Y + (size_t)i * npad; }
 };
 
-/// One PANOC inner solve; same contract as pantr_inner().  (-DPANTR_PHASE_TIMING: final_gamma /
-/// final_psi / final_fbe / final_radius return the seconds spent in the L-BFGS application /
-/// psi_grad / psi(xhat) / the L-BFGS update.)  lbfgs_ws: 2 * memory * npad doubles of
+/// One PANOC inner solve; same contract as pantr_inner().  (-DPANTR_PHASE_TIMING: stats.phase_s[] receives
+/// the seconds spent in the L-BFGS application / psi_grad / psi(xhat) / the L-BFGS update.)  lbfgs_ws: 2 * memory * npad doubles of
 /// HBM for this instance.
 template <class PB, bool STRUCTURED>
 __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P, double tolerance,
@@ -365,7 +364,7 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
             o[0] = eps_k; o[1] = curr.psi_x; o[2] = __builtin_sqrt(curr.pTp); o[3] = curr.gamma;
             o[4] = tau; o[5] = curr.fbe(); o[6] = lb.idx + (lb.full ? lb.memory : 0);
         }
-        double elapsed   = (double)(wall_clock64() - t_start) * 1e-8;
+        double elapsed   = (double)(wall_clock64() - t_start) * P.tick_s;
         bool converged   = eps_k <= tolerance;
         bool out_of_time = elapsed > deadline_s;
         bool out_of_iter = k == P.max_iter;
@@ -389,14 +388,14 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
                     if (i < n)
                         q[i] = (mask >> j) & 1u ? -G_(curr)[i] : P_(curr)[i];
                 }
-                PANTR_PHASE(final_gamma, ok = nJ > 0 && lbfgs_apply(q, nJ == n ? ~0u : mask, nJ != n));
+                PANTR_PHASE(PH_DIRECTION, ok = nJ > 0 && lbfgs_apply(q, nJ == n ? ~0u : mask, nJ != n));
             } else {
                 for (int j = 0; j < nj; ++j) {
                     int i = j * WAVE + lane;
                     if (i < n)
                         q[i] = P_(curr)[i];
                 }
-                PANTR_PHASE(final_gamma, ok = lbfgs_apply(q, ~0u, false));
+                PANTR_PHASE(PH_DIRECTION, ok = lbfgs_apply(q, ~0u, false));
             }
             bool finite = true;
             for (int j = 0; j < nj; ++j) {
@@ -430,7 +429,7 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
                                                  : (xi + (1.0 - tau) * P_(curr)[i]) + tau * q[i];
                     }
                 }
-                PANTR_PHASE(final_psi, next.psi_x = pb.eval_psi_grad(X_(next), G_(next)));
+                PANTR_PHASE(PH_PSI_GRAD, next.psi_x = pb.eval_psi_grad(X_(next), G_(next)));
                 if (tau != 0)
                     ++st.n_psi_grad_psi;
                 else
@@ -447,7 +446,7 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
             }
             pb.prox_grad_step(next.gamma, X_(next), G_(next), XH_(next), P_(next), next.pTp, next.gradTp);
             ++st.n_prox_grad_step;
-            PANTR_PHASE(final_fbe, next.psi_xh = pb.eval_psi_xhat(XH_(next), next.yh));
+            PANTR_PHASE(PH_PSI_XHAT, next.psi_xh = pb.eval_psi_xhat(XH_(next), next.yh));
             ++st.n_psi;
             if (next.L < P.L_max && qub_violated(next)) {
                 next.gamma = next.gamma / 2.0;
@@ -488,11 +487,11 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
         }
         bool accepted;
         if (STRUCTURED) {
-            PANTR_PHASE(final_radius, accepted = lbfgs_update(X_(curr), X_(next), G_(curr), G_(next), true, true));
+            PANTR_PHASE(PH_GRAD_XHAT, accepted = lbfgs_update(X_(curr), X_(next), G_(curr), G_(next), true, true));
         } else {
             if (curr.gamma != next.gamma)
                 lb.reset();
-            PANTR_PHASE(final_radius, accepted = lbfgs_update(X_(curr), X_(next), P_(curr), P_(next), false, false));
+            PANTR_PHASE(PH_GRAD_XHAT, accepted = lbfgs_update(X_(curr), X_(next), P_(curr), P_(next), false, false));
         }
         st.lbfgs_rejected += accepted ? 0 : 1;
         swap_iter(curr, next);

@@ -47,6 +47,7 @@ template <class M>
 struct ScalarALProblem {
     static constexpr int nx = M::nx, nu = M::nu, nc = M::nc;
     int lane;
+    const BoxData *box; ///< bounds of u (box C) and of the constraints (box D), kernel argument
     double *lds; ///< n-vectors: NUM_VEC slots of npad doubles
     int N, n, npad, nj, m, mpad, mj;
     double x0[nx];
@@ -219,7 +220,7 @@ struct ScalarALProblem {
             for (int i = 0; i < nc; ++i) {
                 int j  = nc * k + i;
                 T zeta = c[i] + yS[j]; // y / Sigma: set_al()
-                T zhat = tmax(tmin(zeta, M::d_ub(i)), M::d_lb(i));
+                T zhat = tmax(tmin(zeta, box->d_ub[i]), box->d_lb[i]);
                 T d    = zeta - zhat;
                 yhv[i] = Sig[j] * d;
                 accal  = accal + (yhv[i] * d);
@@ -294,7 +295,7 @@ struct ScalarALProblem {
         for (int i = 0; i < nc; ++i) {
             int j     = nc * k + i;
             dual zeta = c[i] + yS[j];
-            dual zhat = tmax(tmin(zeta, M::d_ub(i)), M::d_lb(i));
+            dual zhat = tmax(tmin(zeta, box->d_ub[i]), box->d_lb[i]);
             dual d    = zeta - zhat;
             yk[i]     = Sig[j] * d;
         }
@@ -405,10 +406,6 @@ struct ScalarALProblem {
         /// two wait states after a VALU write; inline asm is outside the compiler's hazard pass).
         template <int T, int SRC, bool FIRST = false>
         __device__ __forceinline__ void add_bcast(double coef, double own) {
-#ifdef PANTR_NO_DPP_FMAC // A/B build: the same sum with v_readlane broadcasts
-            part<T>() = __builtin_fma(read_lane<SRC>(own), coef, part<T>());
-            return;
-#endif
             if (FIRST)
                 asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
                              : "+v"(part<T>())
@@ -603,7 +600,7 @@ struct ScalarALProblem {
                 int c     = i % nu;
                 double xi = x[i], gi = grad[i];
                 double t  = (-gamma) * gi;
-                double pi = fmin(fmax(t, M::u_lb(c) - xi), M::u_ub(c) - xi);
+                double pi = fmin(fmax(t, box_pick(box->u_lb, c) - xi), box_pick(box->u_ub, c) - xi);
                 p[i]      = pi;
                 xh[i]     = xi + pi;
                 a1        = a1 + pi * pi;
@@ -621,7 +618,7 @@ struct ScalarALProblem {
                 int c     = i % nu;
                 double xi = x[i];
                 double t  = (-1.0) * grad[i];
-                double pi = fmin(fmax(t, M::u_lb(c) - xi), M::u_ub(c) - xi);
+                double pi = fmin(fmax(t, box_pick(box->u_lb, c) - xi), box_pick(box->u_ub, c) - xi);
                 r         = fmax(r, fabs(pi));
             }
         }
@@ -637,7 +634,7 @@ struct ScalarALProblem {
             if (i < n) {
                 int c      = i % nu;
                 double xfw = x[i] - gamma * grad[i];
-                in = M::u_lb(c) < xfw && xfw < M::u_ub(c);
+                in = box_pick(box->u_lb, c) < xfw && xfw < box_pick(box->u_ub, c);
             }
             mask |= (in ? 1u : 0u) << j;
             cnt += __builtin_popcountll(__ballot(in ? 1 : 0)); // wave-uniform count, no reduction needed
@@ -660,7 +657,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
     const AlmKernelParams &A = a.alm;
     using PB = ScalarALProblem<M>;
     PB pb;
-    pb.lane = lane; pb.lds = lds; pb.N = a.N; pb.n = a.n; pb.npad = a.npad; pb.nj = a.nj;
+    pb.lane = lane; pb.box = &a.prm.box; pb.lds = lds; pb.N = a.N; pb.n = a.n; pb.npad = a.npad; pb.nj = a.nj;
     pb.m = a.m; pb.mpad = a.mpad; pb.mj = a.mj;
     pb.mv = lds + (size_t)NUM_VEC * a.npad;
     pb.X  = pb.mv + (size_t)PB::MV_COUNT * a.mpad;
@@ -693,13 +690,16 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
         // eval_proj_multipliers(y, M): no lower bound -> y <= 0 is impossible ... (y >= 0 side only), etc.
         for (int j = lane; j < m; j += WAVE) {
             int ci     = j % M::nc;
-            double ylb = M::d_lb(ci) == -__builtin_huge_val() ? 0.0 : -A.max_multiplier;
-            double yub = M::d_ub(ci) == __builtin_huge_val() ? 0.0 : A.max_multiplier;
+            double ylb = box_pick(P.box.d_lb, ci) == -__builtin_huge_val() ? 0.0 : -A.max_multiplier;
+            double yub = box_pick(P.box.d_ub, ci) == __builtin_huge_val() ? 0.0 : A.max_multiplier;
             y[j]       = fmin(fmax(y[j], ylb), yub);
         }
         pb.set_al();
+        // every inner solve has solver.max_time of its own, capped by what is left of alm.max_time
+        const long long t_inner = wall_clock64();
+        const double remaining  = A.max_time_s - (double)(t_inner - t_start) * P.tick_s;
         r = inner_solve<METHOD>(
-            pb, P, eps, A.max_time_s, t_start, x_io, st,
+            pb, P, eps, fmin(P.solver_max_time_s, remaining), t_inner, x_io, st,
             trace && i == 0 ? a.trace + (size_t)inst * a.trace_cap * TRACE_COLS : nullptr, a.trace_cap,
             a.lbfgs ? a.lbfgs + (size_t)inst * 2 * P.lbfgs_memory * a.npad : nullptr);
         total_inner += r.iterations;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
         for (int j = lane; j < m; j += WAVE)
             mx = fmax(mx, fabs(e2[j]));
         norm_e2 = uniform(wave_max(mx));
-        double elapsed     = (double)(wall_clock64() - t_start) * 1e-8;
+        double elapsed     = (double)(wall_clock64() - t_start) * P.tick_s;
         bool alm_converged = r.eps <= A.tolerance && inner_converged && norm_e2 <= A.dual_tolerance;
         bool out_of_time = elapsed > A.max_time_s, out_of_iter = i + 1 == A.max_iter;
         outer = i + 1;
@@ -755,13 +755,11 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
         st.status       = status == Busy ? (int)MaxIter : status;
         st.iterations   = total_inner;
         st.eps          = r.eps;
-#ifndef PANTR_PHASE_TIMING
         st.final_gamma  = r.gamma;
         st.final_psi    = r.psi;
         st.final_fbe    = r.fbe;
         st.final_radius = r.radius;
-#endif
-        st.elapsed_s    = (double)(wall_clock64() - t_start) * 1e-8;
+        st.elapsed_s    = (double)(wall_clock64() - t_start) * P.tick_s;
         st.outer_iterations           = outer;
         st.inner_convergence_failures = failures;
         st.delta                      = norm_e2;
@@ -777,7 +775,7 @@ namespace pantr {
 // ---------------------------------------------------------------------------------------
 // Stand-alone problem-function kernels for the scalar AL problems (row-level parity tests)
 // ---------------------------------------------------------------------------------------
-enum AlmEvalMode : int32_t { ALM_EVAL_PSI_GRAD = 0, ALM_EVAL_HESS_PROD = 1 };
+enum AlmEvalMode : int32_t { ALM_EVAL_PSI_GRAD = 0, ALM_EVAL_HESS_PROD = 1, ALM_EVAL_GRAD_L = 2 };
 
 struct AlmEvalArgs {
     int32_t B, N, n, npad, nj, m, mpad, mj, mode, reps; ///< reps: development aid (timing), normally 1
@@ -790,6 +788,7 @@ struct AlmEvalArgs {
     double *out_v;     ///< [B][n] grad | Hv
     double *out_m;     ///< [B][m] yhat
     double *ws;        ///< [B][ScalarALProblem::workspace_doubles(N)]
+    BoxData box;
 };
 
 template <class M>
@@ -800,7 +799,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
         return;
     using PB = ScalarALProblem<M>;
     PB pb;
-    pb.lane = lane; pb.lds = lds; pb.N = a.N; pb.n = a.n; pb.npad = a.npad; pb.nj = a.nj;
+    pb.lane = lane; pb.box = &a.box; pb.lds = lds; pb.N = a.N; pb.n = a.n; pb.npad = a.npad; pb.nj = a.nj;
     pb.m = a.m; pb.mpad = a.mpad; pb.mj = a.mj;
     pb.mv = lds + (size_t)NUM_VEC * a.npad;
     pb.X  = pb.mv + (size_t)PB::MV_COUNT * a.mpad;
@@ -830,6 +829,14 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
         pb.eval_grad_xhat(u, o, 0);
         for (int j = lane; j < a.m; j += WAVE)
             a.out_m[(size_t)inst * a.m + j] = pb.mvec(PB::MV_YH)[j];
+    } else if (a.mode == ALM_EVAL_GRAD_L) {
+        // grad_x L(x, y) = grad f + grad g' y (formulation.hpp:98,170-174): the trajectory at u, then
+        // the adjoint sweep with the caller's y as the multipliers (Sigma plays no role)
+        pb.eval_psi_xhat(u, 0);
+        pb.template reverse<double>(u, nullptr, pb.mvec(PB::MV_Y), [&](int i, double g) {
+            if (lane == 0)
+                o[i] = g;
+        });
     } else {
         pb.eval_psi_xhat(u, 0);
         pb.eval_grad_xhat(u, pb.vec(3), 0); // records the tape at u

@@ -3,6 +3,7 @@
 // compute entry point needs a HIP device and fails with PANTR_ERR_NO_DEVICE without one.
 #include "../../include/pantr_mi355x.h"
 #include "../host/params.hpp"
+#include "../host/problem_data.hpp"
 #include "chain_model.hip.h"
 #include "pantr_kernel.hip.h"
 #include "pantr_alm.hip.h"
@@ -13,7 +14,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,7 +28,6 @@ static_assert(sizeof(pantr_stats_t) == sizeof(DeviceStats), "stats layout mismat
 namespace {
 
 thread_local std::string g_last_error;
-int g_eval_reps = 1; ///< development aid: repeat count of the timed op in pantr_eval_kernel
 
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
@@ -69,13 +71,86 @@ struct pantr_batch {
     int32_t trace_instances = 0, trace_cap = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
+    // numeric problem data: the compiled-in model's, or what create_from_files read from the sidecars
+    BoxData box{};
+    std::vector<double> x_init, u_guess;
+    int32_t penalty_alm_split = 0;
+    double tick_s = 1e-8;  ///< seconds per wall_clock64() tick of this device
+    int32_t eval_reps = 1; ///< development aid: repeat count of the timed op in the eval kernels
 };
 
 namespace {
 
+/// Problem name -> id ("dl:" prefixes dropped, casadi-dll-wrapper.cpp:74-76).
+int parse_problem(const char *problem, ProblemId &id, std::string &name) {
+    name = problem;
+    while (name.rfind("dl:", 0) == 0)
+        name = name.substr(3);
+    if (name == "hanging_chain")
+        id = ProblemId::HangingChain;
+    else if (name == "quadcopter")
+        id = ProblemId::Quadcopter;
+    else if (name == "realistic_quadcopter")
+        id = ProblemId::RealisticQuadcopter;
+    else
+        return fail(PANTR_ERR_OUT_OF_RANGE, "unknown problem '" + name +
+                                                "' (available: hanging_chain, quadcopter, realistic_quadcopter)");
+    return PANTR_OK;
+}
+
+/// Shape and compiled-in numeric data of a problem (host only).
+host::ModelShape model_shape(ProblemId id, int32_t N) {
+    host::ModelShape s{};
+    if (id == ProblemId::HangingChain) {
+        s.nx = ChainModel::nx; s.nu = ChainModel::nu; s.nc = 0; s.nc_N = 0;
+    } else {
+        s.nx = QuadModelT<false>::nx; s.nu = QuadModelT<false>::nu;
+        s.nc = s.nc_N = QuadModelT<false>::nc;
+    }
+    s.n = s.nu * N;
+    s.m = s.nc * N + s.nc_N; // ss.py:39-40
+    return s;
+}
+void model_defaults(ProblemId id, const host::ModelShape &s, BoxData &box, std::vector<double> &x_init,
+                    std::vector<double> &u_guess) {
+    const bool al = id != ProblemId::HangingChain;
+    for (int c = 0; c < 4; ++c) {
+        box.u_lb[c] = c < s.nu ? (al ? QuadModelT<false>::u_lb(c) : ChainModel::u_lb(c)) : 0.0;
+        box.u_ub[c] = c < s.nu ? (al ? QuadModelT<false>::u_ub(c) : ChainModel::u_ub(c)) : 0.0;
+        box.d_lb[c] = c < s.nc ? QuadModelT<false>::d_lb(c) : 0.0;
+        box.d_ub[c] = c < s.nc ? QuadModelT<false>::d_ub(c) : 0.0;
+    }
+    x_init.assign(s.nx, 0.0);
+    if (al)
+        QuadModelT<false>::initial_state(x_init.data()); // quadcopter.py:80-88
+    else
+        for (int l = 0; l < s.nx; ++l)
+            x_init[l] = ChainModel::initial_state(l); // hanging_chain.cpp:121-124
+    u_guess.assign(s.n, 0.0); // hanging_chain.cpp:135 / quadcopter.py:111
+    for (int i = 0; i < s.n; ++i)
+        u_guess[i] = al ? QuadModelT<false>::initial_guess(i % s.nu) : 0.0;
+}
+
 template <class T>
 int dev_alloc(T *&p, size_t count) {
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+    return PANTR_OK;
+}
+
+/// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a handle: keep a
+/// running maximum per kernel and never lower it (a later, smaller handle must not shrink the limit
+/// of a live, larger one).
+int raise_dynamic_lds(const void *kernel, size_t bytes) {
+    static std::mutex mtx;
+    static std::map<std::pair<int, const void *>, size_t> current;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mtx);
+    size_t &cur = current[{dev, kernel}];
+    if (bytes <= cur)
+        return PANTR_OK;
+    HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    cur = bytes;
     return PANTR_OK;
 }
 
@@ -114,8 +189,10 @@ int check_supported(const SolverOptions &o) {
     return PANTR_OK;
 }
 
-KernelParams to_kernel_params(const SolverOptions &o, int m) {
+KernelParams to_kernel_params(const SolverOptions &o, double tick_s, const BoxData &box) {
     KernelParams k{};
+    k.tick_s = tick_s;
+    k.solver_max_time_s = o.solver.max_time;
     const auto &s = o.solver;
     k.L_0 = s.Lipschitz.L_0; k.lip_eps = s.Lipschitz.epsilon; k.lip_delta = s.Lipschitz.delta;
     k.Lgamma_factor = s.Lipschitz.Lgamma_factor;
@@ -143,7 +220,7 @@ KernelParams to_kernel_params(const SolverOptions &o, int m) {
     k.force_linesearch = o.panoc.force_linesearch ? 1 : 0;
     k.lbfgs_min_div_fac = o.lbfgs.min_div_fac; k.lbfgs_min_abs_s = o.lbfgs.min_abs_s;
     k.lbfgs_memory = o.lbfgs.memory; k.lbfgs_force_pos_def = o.lbfgs.force_pos_def ? 1 : 0;
-    (void)m;
+    k.box = box;
     return k;
 }
 
@@ -210,7 +287,7 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
         a.x0 = d_x0; a.u = d_u; a.y = d_y; a.ws = b->d_ws; a.lbfgs = d_lbfgs; a.stats = d_stats;
         a.trace = b->trace_instances > 0 ? b->d_trace : nullptr;
         a.order = b->have_order ? b->d_order : nullptr;
-        a.prm   = to_kernel_params(b->opts, b->m);
+        a.prm   = to_kernel_params(b->opts, b->tick_s, b->box);
         a.alm   = to_alm_params(b->opts);
         HIP_TRY(hipEventRecord(b->ev_start, stream));
         with_quad_model(b, [&](auto model) {
@@ -234,7 +311,7 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
     a.x0 = d_x0; a.u = d_u; a.ws = b->d_ws; a.lbfgs = d_lbfgs; a.stats = d_stats;
     a.trace = b->trace_instances > 0 ? b->d_trace : nullptr;
     a.order = b->have_order ? b->d_order : nullptr;
-    a.prm   = to_kernel_params(b->opts, b->m);
+    a.prm   = to_kernel_params(b->opts, b->tick_s, b->box);
     HIP_TRY(hipEventRecord(b->ev_start, stream));
     if (method == 0)
         hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
@@ -274,9 +351,10 @@ int run_eval(pantr_batch *b, int32_t B, int mode, double gamma, const double *x0
         HIP_TRY(hipMemcpy(b->d_v, v, nb, hipMemcpyHostToDevice));
     EvalArgs a{};
     a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj; a.mode = mode;
-    a.reps = g_eval_reps;
+    a.reps = b->eval_reps;
     a.x0 = b->d_x0; a.u = b->d_u; a.v = v ? b->d_v : nullptr;
     a.out_s = b->d_s; a.out_v = b->d_o1; a.out_v2 = b->d_o2; a.ws = b->d_ws; a.gamma = gamma;
+    a.box = b->box;
     hipLaunchKernelGGL(pantr_eval_kernel<ChainModel>, dim3(B), dim3(WAVE), 4 * b->npad * sizeof(double), 0, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
@@ -296,12 +374,66 @@ int run_eval(pantr_batch *b, int32_t B, int mode, double gamma, const double *x0
 extern "C" {
 
 const char *pantr_last_error(void) { return g_last_error.c_str(); }
-const char *pantr_version(void) { return "pantr-mi355x 0.1 (gfx950)"; }
+const char *pantr_version(void) {
+    // any build switch that changes what the library computes or reports is named here
+#ifdef PANTR_PHASE_TIMING
+    return "pantr-mi355x 0.2 (gfx950) +phase-timing";
+#else
+    return "pantr-mi355x 0.2 (gfx950)";
+#endif
+}
 int pantr_device_count(void) {
     int c = 0;
     if (hipGetDeviceCount(&c) != hipSuccess)
         return 0;
     return c;
+}
+
+// ---- achievable HBM bandwidth (the yardstick next to the 8 TB/s spec peak) --------
+namespace {
+/// 16 bytes per lane per access, grid-stride: dst[i] = src[i].
+__global__ __launch_bounds__(256) void copy16_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst,
+                                                     size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        dst[i] = src[i];
+}
+} // namespace
+
+int pantr_device_copy_bandwidth(int32_t device, int64_t bytes, int32_t reps, double *gb_per_s) {
+    if (!gb_per_s || bytes < (1 << 20) || reps < 1)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "need an output pointer, bytes >= 1 MiB and reps >= 1");
+    HIP_TRY(hipSetDevice(device));
+    const size_t count = (size_t)bytes / sizeof(double2);
+    double2 *src = nullptr, *dst = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&] {
+        if (src) (void)hipFree(src);
+        if (dst) (void)hipFree(dst);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&src), count * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dst), count * sizeof(double2));
+    if (e == hipSuccess) e = hipMemset(src, 1, count * sizeof(double2));
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float best_ms = 0;
+    for (int r = 0; e == hipSuccess && r < reps + 1; ++r) { // first pass untimed (page faults, clocks)
+        (void)hipEventRecord(e0, nullptr);
+        hipLaunchKernelGGL(copy16_kernel, dim3(256 * 16), dim3(256), 0, nullptr, src, dst, count);
+        (void)hipEventRecord(e1, nullptr);
+        e = hipEventSynchronize(e1);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0 && (best_ms == 0 || ms < best_ms))
+            best_ms = ms;
+    }
+    cleanup();
+    if (e != hipSuccess)
+        return fail(PANTR_ERR_NO_DEVICE, std::string("copy bandwidth measurement: ") + hipGetErrorString(e));
+    *gb_per_s = 2.0 * (double)(count * sizeof(double2)) / (best_ms * 1e-3) / 1e9; // read + write
+    return PANTR_OK;
 }
 
 // ---- options ---------------------------------------------------------------------------
@@ -330,19 +462,10 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
                        pantr_batch_t **out) {
     if (!problem || !out)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
-    std::string name = problem;
-    while (name.rfind("dl:", 0) == 0) // casadi-dll-wrapper.cpp:74-76
-        name = name.substr(3);
+    std::string name;
     ProblemId id;
-    if (name == "hanging_chain")
-        id = ProblemId::HangingChain;
-    else if (name == "quadcopter")
-        id = ProblemId::Quadcopter;
-    else if (name == "realistic_quadcopter")
-        id = ProblemId::RealisticQuadcopter;
-    else
-        return fail(PANTR_ERR_OUT_OF_RANGE, "unknown problem '" + name +
-                                                "' (available: hanging_chain, quadcopter, realistic_quadcopter)");
+    if (int rc = parse_problem(problem, id, name))
+        return rc;
     if (horizon < 1)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "horizon must be >= 1");
     if (max_instances < 1)
@@ -354,16 +477,19 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
         return fail(PANTR_ERR_OUT_OF_RANGE, "device ordinal out of range");
     HIP_TRY(hipSetDevice(device));
 
-    auto b = std::make_unique<pantr_batch>();
-    b->problem = id; b->name = name; b->device = device; b->N = horizon;
-    if (id == ProblemId::HangingChain) {
-        b->nx = ChainModel::nx; b->nu = ChainModel::nu; b->nc = 0; b->nc_N = 0;
-    } else {
-        b->nx = QuadModelT<false>::nx; b->nu = QuadModelT<false>::nu;
-        b->nc = b->nc_N = QuadModelT<false>::nc;
+    // one cleanup path: every early return below frees what was allocated so far
+    std::unique_ptr<pantr_batch, void (*)(pantr_batch_t *)> b(new pantr_batch, pantr_batch_destroy);
+    {
+        int khz = 0; // wall_clock64() rate
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0)
+            b->tick_s = 1.0 / (1e3 * (double)khz);
     }
-    b->n = b->nu * b->N;
-    b->m = b->nc * b->N + b->nc_N; // ss.py:39-40
+    b->problem = id; b->name = name; b->device = device; b->N = horizon;
+    {
+        const host::ModelShape sh = model_shape(id, horizon);
+        b->nx = sh.nx; b->nu = sh.nu; b->nc = sh.nc; b->nc_N = sh.nc_N; b->n = sh.n; b->m = sh.m;
+        model_defaults(id, sh, b->box, b->x_init, b->u_guess);
+    }
     b->nj   = (b->n + WAVE - 1) / WAVE;
     b->npad = b->nj * WAVE;
     b->mj   = (b->m + WAVE - 1) / WAVE;
@@ -389,17 +515,19 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
                               (const void *)&pantr_alm_kernel<QuadModelT<false>, 2>,
                               (const void *)&pantr_alm_kernel<QuadModelT<true>, 0>,
                               (const void *)&pantr_alm_kernel<QuadModelT<true>, 1>,
-                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 2>})
-            HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_alm_eval_kernel<QuadModelT<false>>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pantr_alm_eval_kernel<QuadModelT<true>>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 2>,
+                              (const void *)&pantr_alm_eval_kernel<QuadModelT<false>>,
+                              (const void *)&pantr_alm_eval_kernel<QuadModelT<true>>})
+            if (int rc = raise_dynamic_lds(k, b->lds_bytes))
+                return rc;
     } else {
         for (const void *k : {(const void *)&pantr_solve_kernel<ChainModel, 0>,
                               (const void *)&pantr_solve_kernel<ChainModel, 1>,
                               (const void *)&pantr_solve_kernel<ChainModel, 2>})
-            HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+            if (int rc = raise_dynamic_lds(k, b->lds_bytes))
+                return rc;
+        if (int rc = raise_dynamic_lds((const void *)&pantr_eval_kernel<ChainModel>, 4 * (size_t)b->npad * sizeof(double)))
+            return rc;
     }
     const size_t B  = b->maxB;
     const size_t nv = std::max(b->n, b->nx); // the vector buffers also carry nx-sized rows
@@ -410,16 +538,9 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
         (rc = dev_alloc(b->d_o2, B * nv)) || (rc = dev_alloc(b->d_s, B * 4)) ||
         (rc = dev_alloc(b->d_ws, std::max<size_t>(B * b->ws_per_instance, 1))) || (rc = dev_alloc(b->d_stats, B)) ||
         (rc = dev_alloc(b->d_order, B)) || (rc = dev_alloc(b->d_y, B * mv)) || (rc = dev_alloc(b->d_sig, B * mv)) ||
-        (rc = dev_alloc(b->d_om, B * mv)) || (rc = dev_alloc(b->d_uinit, nv))) {
-        pantr_batch_destroy(b.release());
+        (rc = dev_alloc(b->d_om, B * mv)) || (rc = dev_alloc(b->d_uinit, nv)))
         return rc;
-    }
-    {
-        std::vector<double> ui(b->n);
-        for (int i = 0; i < b->n; ++i)
-            ui[i] = b->al() ? QuadModelT<false>::initial_guess(i % b->nu) : 0.0;
-        HIP_TRY(hipMemcpy(b->d_uinit, ui.data(), ui.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
+    HIP_TRY(hipMemcpy(b->d_uinit, b->u_guess.data(), (size_t)b->n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(b->d_ws, 0, std::max<size_t>(B * b->ws_per_instance, 1) * sizeof(double)));
     HIP_TRY(hipEventCreate(&b->ev_start));
     HIP_TRY(hipEventCreate(&b->ev_stop));
@@ -461,8 +582,8 @@ int pantr_batch_get_box_C(const pantr_batch_t *b, double *lb, double *ub) {
     if (!b || !lb || !ub)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
     for (int i = 0; i < b->n; ++i) { // formulation.hpp:220-227: U tiled N times
-        lb[i] = b->al() ? QuadModelT<false>::u_lb(i % b->nu) : ChainModel::u_lb(i % b->nu);
-        ub[i] = b->al() ? QuadModelT<false>::u_ub(i % b->nu) : ChainModel::u_ub(i % b->nu);
+        lb[i] = b->box.u_lb[i % b->nu];
+        ub[i] = b->box.u_ub[i % b->nu];
     }
     return PANTR_OK;
 }
@@ -471,8 +592,8 @@ int pantr_batch_get_box_D(const pantr_batch_t *b, double *lb, double *ub) {
     if (!b || (b->m > 0 && (!lb || !ub)))
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
     for (int j = 0; j < b->m; ++j) { // formulation.hpp:229-238: D tiled N times, then D_N
-        lb[j] = QuadModelT<false>::d_lb(j % b->nc);
-        ub[j] = QuadModelT<false>::d_ub(j % b->nc);
+        lb[j] = b->box.d_lb[j % b->nc];
+        ub[j] = b->box.d_ub[j % b->nc];
     }
     return PANTR_OK;
 }
@@ -480,20 +601,159 @@ int pantr_batch_get_box_D(const pantr_batch_t *b, double *lb, double *ub) {
 int pantr_batch_get_initial_guess(const pantr_batch_t *b, double *u) {
     if (!b || !u)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
-    for (int i = 0; i < b->n; ++i) // hanging_chain.cpp:135 / quadcopter.py:111
-        u[i] = b->al() ? QuadModelT<false>::initial_guess(i % b->nu) : 0.0;
+    std::copy(b->u_guess.begin(), b->u_guess.end(), u);
     return PANTR_OK;
 }
 
 int pantr_batch_get_initial_state(const pantr_batch_t *b, double *x0) {
     if (!b || !x0)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
-    if (b->al()) {
-        QuadModelT<false>::initial_state(x0); // quadcopter.py:80-88
-        return PANTR_OK;
+    std::copy(b->x_init.begin(), b->x_init.end(), x0);
+    return PANTR_OK;
+}
+
+int pantr_batch_get_penalty_alm_split(const pantr_batch_t *b, int32_t *split) {
+    if (!b || !split)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    *split = b->penalty_alm_split;
+    return PANTR_OK;
+}
+
+// ---- compiled-in problem data and the sidecar files (host only: no device needed) ----------------
+int pantr_problem_dims(const char *problem, int32_t horizon, int32_t *n, int32_t *m, int32_t *nx, int32_t *nu,
+                       int32_t *nc, int32_t *nc_N) {
+    if (!problem)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    std::string name;
+    ProblemId id;
+    if (int rc = parse_problem(problem, id, name))
+        return rc;
+    if (horizon < 1)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "horizon must be >= 1");
+    const host::ModelShape s = model_shape(id, horizon);
+    if (n) *n = s.n;
+    if (m) *m = s.m;
+    if (nx) *nx = s.nx;
+    if (nu) *nu = s.nu;
+    if (nc) *nc = s.nc;
+    if (nc_N) *nc_N = s.nc_N;
+    return PANTR_OK;
+}
+
+int pantr_problem_defaults(const char *problem, int32_t horizon, double *C_lb, double *C_ub, double *D_lb,
+                           double *D_ub, double *x_init, double *u_guess) {
+    if (!problem)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    std::string name;
+    ProblemId id;
+    if (int rc = parse_problem(problem, id, name))
+        return rc;
+    if (horizon < 1)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "horizon must be >= 1");
+    const host::ModelShape s = model_shape(id, horizon);
+    BoxData box{};
+    std::vector<double> xi, ug;
+    model_defaults(id, s, box, xi, ug);
+    for (int i = 0; i < s.n; ++i) {
+        if (C_lb) C_lb[i] = box.u_lb[i % s.nu];
+        if (C_ub) C_ub[i] = box.u_ub[i % s.nu];
     }
-    for (int l = 0; l < b->nx; ++l)
-        x0[l] = ChainModel::initial_state(l);
+    for (int j = 0; j < s.m; ++j) {
+        if (D_lb) D_lb[j] = box.d_lb[j % s.nc];
+        if (D_ub) D_ub[j] = box.d_ub[j % s.nc];
+    }
+    if (x_init) std::copy(xi.begin(), xi.end(), x_init);
+    if (u_guess) std::copy(ug.begin(), ug.end(), u_guess);
+    return PANTR_OK;
+}
+
+struct pantr_problem_data {
+    host::ProblemData d;
+    host::ModelShape shape{};
+    ProblemId id = ProblemId::HangingChain;
+};
+
+int pantr_problem_data_load(const char *path, const char *formulation, int32_t horizon,
+                            pantr_problem_data_t **out) {
+    if (!path || !formulation || !out)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    const std::string form = formulation;
+    if (form != "ss" && form != "ss2" && form != "ss2p") // casadi-dll-wrapper.cpp:29-32
+        return fail(PANTR_ERR_INVALID_ARGUMENT,
+                    "formulation '" + form + "' is not available (single shooting only: ss, ss2, ss2p)");
+    if (horizon < 1)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "horizon must be >= 1");
+    auto pd = std::make_unique<pantr_problem_data>();
+    std::string err;
+    switch (host::load_problem_data(path, form, horizon, pd->d, err)) {
+    case host::LoadStatus::Ok: break;
+    default: return fail(PANTR_ERR_RUNTIME, err); // std::runtime_error in the reference (:58-59)
+    }
+    std::string name;
+    if (int rc = parse_problem(pd->d.name.c_str(), pd->id, name))
+        return rc;
+    pd->shape = model_shape(pd->id, horizon);
+    if (!host::check_problem_data(pd->d, pd->shape, err))
+        return fail(PANTR_ERR_INVALID_ARGUMENT, err); // std::logic_error-like: wrong dimensions
+    *out = pd.release();
+    return PANTR_OK;
+}
+
+void pantr_problem_data_destroy(pantr_problem_data_t *d) { delete d; }
+
+int pantr_problem_data_get(const pantr_problem_data_t *pd, int32_t *has_csv, double *C_lb, double *C_ub,
+                           double *D_lb, double *D_ub, double *param, double *guess, int32_t *penalty_alm_split) {
+    if (!pd)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    // rows the files do not give fall back to the compiled-in model's values
+    BoxData box{};
+    std::vector<double> xi, ug;
+    model_defaults(pd->id, pd->shape, box, xi, ug);
+    const auto &d = pd->d;
+    const auto &s = pd->shape;
+    if (has_csv) *has_csv = d.have_csv ? 1 : 0;
+    for (int i = 0; i < s.n; ++i) {
+        if (C_lb) C_lb[i] = d.C_lb.empty() ? box.u_lb[i % s.nu] : d.C_lb[i];
+        if (C_ub) C_ub[i] = d.C_ub.empty() ? box.u_ub[i % s.nu] : d.C_ub[i];
+        if (guess) guess[i] = d.guess[i];
+    }
+    for (int j = 0; j < s.m; ++j) {
+        if (D_lb) D_lb[j] = d.D_lb.empty() ? box.d_lb[j % s.nc] : d.D_lb[j];
+        if (D_ub) D_ub[j] = d.D_ub.empty() ? box.d_ub[j % s.nc] : d.D_ub[j];
+    }
+    for (int l = 0; l < s.nx; ++l)
+        if (param) param[l] = d.param.empty() ? xi[l] : d.param[l];
+    if (penalty_alm_split) *penalty_alm_split = d.penalty_alm_split;
+    return PANTR_OK;
+}
+
+int pantr_batch_create_from_files(const char *path, const char *formulation, int32_t horizon,
+                                  int32_t max_instances, int32_t device, pantr_batch_t **out) {
+    if (!out)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    pantr_problem_data_t *raw = nullptr;
+    if (int rc = pantr_problem_data_load(path, formulation, horizon, &raw))
+        return rc;
+    std::unique_ptr<pantr_problem_data> pd(raw);
+    pantr_batch_t *h = nullptr;
+    if (int rc = pantr_batch_create(pd->d.name.c_str(), horizon, max_instances, device, &h))
+        return rc;
+    std::unique_ptr<pantr_batch, void (*)(pantr_batch_t *)> b(h, pantr_batch_destroy);
+    const auto &d = pd->d;
+    for (int c = 0; c < b->nu && !d.C_lb.empty(); ++c) {
+        b->box.u_lb[c] = d.C_lb[c];
+        b->box.u_ub[c] = d.C_ub[c];
+    }
+    for (int c = 0; c < b->nc && !d.D_lb.empty(); ++c) {
+        b->box.d_lb[c] = d.D_lb[c];
+        b->box.d_ub[c] = d.D_ub[c];
+    }
+    if (!d.param.empty())
+        b->x_init = d.param; // CasADiProblem::param, the initial state (casadi-dll-wrapper.cpp:64)
+    b->u_guess           = d.guess;
+    b->penalty_alm_split = d.penalty_alm_split;
+    HIP_TRY(hipMemcpy(b->d_uinit, b->u_guess.data(), (size_t)b->n * sizeof(double), hipMemcpyHostToDevice));
+    *out = b.release();
     return PANTR_OK;
 }
 
@@ -550,6 +810,23 @@ int pantr_batch_solve_device(pantr_batch_t *b, int32_t B, const double *d_x0, do
     if (!d_x0 || !d_u || !d_stats || (b->al() && !d_y))
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(b->device));
+    // The buffers come from another allocator (e.g. PyTorch).  If that allocator lives in a different
+    // HIP runtime instance than the one this library is bound to (a process that loaded this
+    // library before `import torch`), the runtime here does not know the pointers: fail loudly
+    // instead of launching a kernel on addresses it cannot see.
+    for (const void *p : {(const void *)d_x0, (const void *)d_u, (const void *)d_stats, (const void *)d_y}) {
+        if (!p)
+            continue;
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, p) != hipSuccess || attr.type != hipMemoryTypeDevice ||
+            attr.device != b->device) {
+            (void)hipGetLastError();
+            return fail(PANTR_ERR_NO_DEVICE,
+                        "pantr_batch_solve_device: a buffer is not device memory of this handle's GPU as seen by "
+                        "the HIP runtime this library is bound to (in a process that also uses PyTorch, import "
+                        "torch and initialise torch.cuda before the first call into this library)");
+        }
+    }
     return launch_solve(b, B, d_x0, d_u, d_y, reinterpret_cast<DeviceStats *>(d_stats),
                         static_cast<hipStream_t>(stream));
 }
@@ -657,7 +934,10 @@ extern "C" int pantr_debug_hess_prod_timed(pantr_batch_t *b, int32_t B, const do
     return run_eval(b, B, EVAL_HESS_PROD_TAPE, 0, x0, u, v, scal, Hv, nullptr);
 }
 
-extern "C" void pantr_debug_set_eval_reps(int r) { g_eval_reps = r; }
+extern "C" void pantr_debug_set_eval_reps(pantr_batch_t *b, int r) {
+    if (b)
+        b->eval_reps = r > 0 ? r : 1;
+}
 
 int pantr_batch_eval_prox_grad_step(pantr_batch_t *b, int32_t B, double gamma, const double *x,
                                     const double *grad, double *xhat, double *p, double *scalars) {
@@ -711,7 +991,8 @@ static int run_al_eval(pantr_batch *b, int32_t B, int mode, const double *x0, co
     AlmEvalArgs a{};
     a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj; a.m = b->m; a.mpad = b->mpad; a.mj = b->mj;
     a.mode = mode; a.x0 = b->d_x0; a.u = b->d_u; a.v = v ? b->d_v : nullptr; a.y = b->d_y; a.Sig = b->d_sig;
-    a.out_s = b->d_s; a.out_v = b->d_o1; a.out_m = b->d_om; a.ws = b->d_ws; a.reps = g_eval_reps;
+    a.out_s = b->d_s; a.out_v = b->d_o1; a.out_m = b->d_om; a.ws = b->d_ws; a.reps = b->eval_reps;
+    a.box = b->box;
     with_quad_model(b, [&](auto model) {
         using M = decltype(model);
         hipLaunchKernelGGL(pantr_alm_eval_kernel<M>, dim3(B), dim3(WAVE), b->lds_bytes, 0, a);
@@ -740,10 +1021,51 @@ int pantr_batch_eval_hess_psi_prod_al(pantr_batch_t *b, int32_t B, const double 
     return run_al_eval(b, B, ALM_EVAL_HESS_PROD, x0, u, y, Sigma, v, nullptr, Hv, nullptr);
 }
 
+int pantr_batch_eval_grad_L(pantr_batch_t *b, int32_t B, const double *x0, const double *u, const double *y,
+                            double *grad) {
+    if (int rc = check_batch(b, B))
+        return rc;
+    if (!b->al()) { // m = 0: L = f = psi
+        if (!x0 || !u || !grad)
+            return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+        return run_eval(b, B, EVAL_PSI_GRAD, 0, x0, u, nullptr, nullptr, grad, nullptr);
+    }
+    if (!y)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "this problem has general constraints: y[B][m] is required");
+    const std::vector<double> ones((size_t)B * b->m, 1.0); // the penalties do not enter grad_L
+    return run_al_eval(b, B, ALM_EVAL_GRAD_L, x0, u, y, ones.data(), nullptr, nullptr, grad, nullptr);
+}
+
+int pantr_batch_eval_g(pantr_batch_t *b, int32_t B, const double *x0, const double *u, double *g) {
+    if (int rc = check_batch(b, B))
+        return rc;
+    if (!b->al()) // m = 0: nothing to write
+        return x0 && u ? PANTR_OK : fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    if (!g)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    // g(u) out of the psi sweep: with y = 0, Sigma = 1 and the box D collapsed to {0},
+    // zeta = g, zhat = 0 and yhat = Sigma (zeta - zhat) = g exactly
+    const std::vector<double> zeros((size_t)B * b->m, 0.0), ones((size_t)B * b->m, 1.0);
+    std::vector<double> grad((size_t)B * b->n);
+    const BoxData saved = b->box;
+    for (int c = 0; c < 4; ++c)
+        b->box.d_lb[c] = b->box.d_ub[c] = 0.0;
+    int rc = run_al_eval(b, B, ALM_EVAL_PSI_GRAD, x0, u, zeros.data(), ones.data(), nullptr, nullptr, grad.data(), g);
+    b->box = saved;
+    return rc;
+}
+
 // ---- closed loops on the device -------------------------------------------------------------
 int pantr_batch_mpc(pantr_batch_t *b, int32_t B, int32_t num_sim, int32_t warm, int32_t num_dist,
                     const double *x_init, const double *u_dist, double *states, double *inputs,
                     pantr_stats_t *stats) {
+    return pantr_batch_mpc_record(b, B, num_sim, warm, num_dist, x_init, u_dist, states, inputs, stats, nullptr,
+                                  nullptr, nullptr);
+}
+
+int pantr_batch_mpc_record(pantr_batch_t *b, int32_t B, int32_t num_sim, int32_t warm, int32_t num_dist,
+                           const double *x_init, const double *u_dist, double *states, double *inputs,
+                           pantr_stats_t *stats, double *guesses_u, double *guesses_y, double *multipliers) {
     if (int rc = check_batch(b, B))
         return rc;
     if (!u_dist || !states || !inputs || !stats)
@@ -786,9 +1108,17 @@ int pantr_batch_mpc(pantr_batch_t *b, int32_t B, int32_t num_sim, int32_t warm, 
                            b->d_uinit, b->d_u, b->d_y);
         // record the state this step is solved for, then solve, record, advance the plant
         HIP_TRY(hipMemcpyAsync(states + (size_t)i * B * b->nx, b->d_x0, xb, hipMemcpyDeviceToHost, nullptr));
+        if (guesses_u)
+            HIP_TRY(hipMemcpyAsync(guesses_u + (size_t)i * B * b->n, b->d_u, ub, hipMemcpyDeviceToHost, nullptr));
+        if (guesses_y && b->m > 0)
+            HIP_TRY(hipMemcpyAsync(guesses_y + (size_t)i * B * b->m, b->d_y, (size_t)B * b->m * sizeof(double),
+                                   hipMemcpyDeviceToHost, nullptr));
         if (int rc = launch_solve(b, B, b->d_x0, b->d_u, b->d_y, b->d_stats, nullptr))
             return rc;
         HIP_TRY(hipMemcpyAsync(inputs + (size_t)i * B * b->n, b->d_u, ub, hipMemcpyDeviceToHost, nullptr));
+        if (multipliers && b->m > 0)
+            HIP_TRY(hipMemcpyAsync(multipliers + (size_t)i * B * b->m, b->d_y, (size_t)B * b->m * sizeof(double),
+                                   hipMemcpyDeviceToHost, nullptr));
         HIP_TRY(hipMemcpyAsync(stats + (size_t)i * B, b->d_stats, (size_t)B * sizeof(DeviceStats),
                                hipMemcpyDeviceToHost, nullptr));
         simulate(b->d_u, b->n); // :205

@@ -33,6 +33,16 @@ enum StopCrit : int32_t {
     FPRNorm, FPRNorm2, IpoptCrit, LBFGSBpp,
 };
 
+/// Box C = U tiled N times and box D = D tiled N times + D_N (formulation.hpp:220-238), one period
+/// each: numeric problem data (the reference keeps them in the problem's .csv sidecar,
+/// generate_problem.py:62-69), so they reach the kernels as arguments, not as compiled constants.
+struct BoxData {
+    double u_lb[4], u_ub[4], d_lb[4], d_ub[4];
+};
+__device__ __forceinline__ double box_pick(const double (&a)[4], int c) {
+    return c == 0 ? a[0] : c == 1 ? a[1] : c == 2 ? a[2] : a[3];
+}
+
 /// Solver options as the kernel consumes them (filled from PANTRParams & co. on the host).
 struct KernelParams {
     double L_0, lip_eps, lip_delta, Lgamma_factor, max_time_s, L_min, L_max;
@@ -42,11 +52,14 @@ struct KernelParams {
     double initial_radius, min_radius;
     double hessian_vec_factor, tol_scale, tol_scale_root, tol_max, max_iter_factor;
     double tolerance;
+    double solver_max_time_s; ///< solver.max_time alone (max_time_s above = min(solver.max_time, alm.max_time))
+    double tick_s;            ///< seconds per wall_clock64() tick (hipDeviceAttributeWallClockRate)
     // PANOC line search and L-BFGS (method = panoc, strucpanoc; panoc_kernel.hip.h)
     double min_linesearch_coefficient, linesearch_strictness_factor, linesearch_tolerance_factor;
     double lbfgs_min_div_fac, lbfgs_min_abs_s;
     int32_t max_iter, stop_crit, max_no_progress, disable_acceleration;
     int32_t always_overwrite_results, force_linesearch, lbfgs_memory, lbfgs_force_pos_def;
+    BoxData box;
 };
 
 /// Per-instance result record (mirrors pantr_stats_t in include/pantr_mi355x.h).
@@ -59,7 +72,12 @@ struct DeviceStats {
     int32_t linesearch_failures, linesearch_backtracks, lbfgs_failures, lbfgs_rejected, tau_1_accepted,
         count_tau; ///< PANOC
     double sum_tau;
+    /// Seconds per phase; filled only by the profiling build (-DPANTR_PHASE_TIMING, `make phase`):
+    /// [0] direction (hess_prod | L-BFGS apply), [1] psi_grad(candidate), [2] psi(xhat),
+    /// [3] grad_L(xhat) + tape (PANTR) | L-BFGS update (PANOC).  Zero in the product build.
+    double phase_s[4];
 };
+enum Phase : int { PH_DIRECTION = 0, PH_PSI_GRAD = 1, PH_PSI_XHAT = 2, PH_GRAD_XHAT = 3 };
 
 constexpr int TRACE_COLS = 11;
 constexpr int NUM_VEC    = 20; ///< working vectors of the inner solvers (slots S_* inside them)
@@ -90,6 +108,7 @@ struct WaveProblem {
     using Lane  = typename M::Lane;
     using State = typename M::State;
     const Lane &L;
+    const BoxData &box; ///< bounds of the decision variables (kernel argument)
     double *lds; ///< base of this wavefront's vectors
     int N, n, npad, nj;
     State x0;       ///< this lane's share of the initial state
@@ -283,7 +302,7 @@ struct WaveProblem {
                 int c     = i % M::nu;
                 double xi = x[i], gi = grad[i];
                 double t  = (-gamma) * gi;
-                double pi = fmin(fmax(t, M::u_lb(c) - xi), M::u_ub(c) - xi);
+                double pi = fmin(fmax(t, box_pick(box.u_lb, c) - xi), box_pick(box.u_ub, c) - xi);
                 p[i]      = pi;
                 xh[i]     = xi + pi;
                 a1        = a1 + pi * pi;
@@ -303,7 +322,7 @@ struct WaveProblem {
                 int c     = i % M::nu;
                 double xi = x[i];
                 double t  = (-1.0) * grad[i];
-                double pi = fmin(fmax(t, M::u_lb(c) - xi), M::u_ub(c) - xi);
+                double pi = fmin(fmax(t, box_pick(box.u_lb, c) - xi), box_pick(box.u_ub, c) - xi);
                 r         = fmax(r, fabs(pi));
             }
         }
@@ -321,7 +340,7 @@ struct WaveProblem {
             if (i < n) {
                 int c      = i % M::nu;
                 double xfw = x[i] - gamma * grad[i];
-                in = M::u_lb(c) < xfw && xfw < M::u_ub(c);
+                in = box_pick(box.u_lb, c) < xfw && xfw < box_pick(box.u_ub, c);
             }
             mask |= (in ? 1u : 0u) << j;
             cnt += __builtin_popcountll(__ballot(in ? 1 : 0)); // wave-uniform count, no reduction needed
@@ -347,18 +366,18 @@ __device__ __forceinline__ void swap_iter(IterateRef &a, IterateRef &b) {
 
 __device__ __forceinline__ bool is_finite(double v) { return fabs(v) < __builtin_huge_val(); }
 
-// Profiling build (-DPANTR_PHASE_TIMING): the stats fields final_gamma / final_psi / final_fbe /
-// final_radius return the seconds spent in hess_prod / psi_grad(candidate) / psi(xhat) /
-// grad_L(xhat) instead of their documented values (scripts/phase_timing.sh).
+// Profiling build (-DPANTR_PHASE_TIMING; `make phase` builds it as a separate library, never over
+// the product): stats.phase_s[] receives the seconds spent per phase (scripts/phase_timing.sh);
+// all documented stats fields keep their meaning and pantr_version() reports the build.
 #ifdef PANTR_PHASE_TIMING
-#define PANTR_PHASE(field, ...)                                                                    \
+#define PANTR_PHASE(idx, ...)                                                                      \
     do {                                                                                           \
         long long t0_ = wall_clock64();                                                            \
         __VA_ARGS__;                                                                               \
-        st.field += (double)(wall_clock64() - t0_) * 1e-8;                                         \
+        st.phase_s[idx] += (double)(wall_clock64() - t0_) * P.tick_s;                              \
     } while (0)
 #else
-#define PANTR_PHASE(field, ...)                                                                    \
+#define PANTR_PHASE(idx, ...)                                                                    \
     do {                                                                                           \
         __VA_ARGS__;                                                                               \
     } while (0)
@@ -451,7 +470,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
         // ---- psi(xhat) + quadratic upper bound backtracking on the new current iterate ----
         while (true) {
             // keeps the trajectory (and yhat) for grad_L(xhat)
-            PANTR_PHASE(final_fbe, curr.psi_xh = pb.eval_psi_xhat(XH_(curr), curr.yh));
+            PANTR_PHASE(PH_PSI_XHAT, curr.psi_xh = pb.eval_psi_xhat(XH_(curr), curr.yh));
             ++st.n_psi;
             double margin = (1.0 + fabs(curr.psi_x)) * P.quadratic_upperbound_tolerance_factor;
             bool violated = curr.psi_xh > ((curr.psi_x + curr.gradTp) + (0.5 * curr.L) * curr.pTp) + margin;
@@ -488,7 +507,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
         } else {
             eps_k = __builtin_nan("");
         }
-        double elapsed   = (double)(wall_clock64() - t_start) * 1e-8;
+        double elapsed   = (double)(wall_clock64() - t_start) * P.tick_s;
         bool converged   = eps_k <= tolerance;
         bool out_of_time = elapsed > deadline_s;
         bool out_of_iter = k == P.max_iter;
@@ -509,7 +528,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
         prox.psi_x = curr.psi_xh;
         // grad_L(xhat): xbar = xhat_k was the last point psi was evaluated at (trajectory X is still
         // in the workspace), so only the adjoint sweep runs; it records the tape at xbar
-        PANTR_PHASE(final_radius, pb.eval_grad_xhat(X_(prox), G_(prox), curr.yh));
+        PANTR_PHASE(PH_GRAD_XHAT, pb.eval_grad_xhat(X_(prox), G_(prox), curr.yh));
         ++st.n_grad_L;
         prox.gamma = curr.gamma;
         prox.L     = curr.L;
@@ -569,7 +588,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                     vin       = d;
                 }
                 // the one Hessian-vector product site: work = H(xbar) * vin (tape replay)
-                PANTR_PHASE(final_gamma, pb.hess_prod(X_(prox), vin, work));
+                PANTR_PHASE(PH_DIRECTION, pb.hess_prod(X_(prox), vin, work));
                 ++st.n_hess_psi_prod;
                 if (state == KTERM) {
                     for (int j = 0; j < nj; ++j) {
@@ -693,7 +712,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                     if (i < n)
                         X_(cand)[i] = X_(prox)[i] + q[i];
                 }
-                PANTR_PHASE(final_psi, cand.psi_x = pb.eval_psi_grad(X_(cand), G_(cand)));
+                PANTR_PHASE(PH_PSI_GRAD, cand.psi_x = pb.eval_psi_grad(X_(cand), G_(cand)));
                 ++st.n_psi_grad_psi;
                 cand.gamma = prox.gamma;
                 cand.L     = prox.L;
@@ -759,13 +778,13 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
     const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     if (inst >= a.B)
         return;
-    const long long t_start = wall_clock64(); // 100 MHz constant clock
+    const long long t_start = wall_clock64(); // constant-rate clock, P.tick_s seconds per tick
     const KernelParams &P   = a.prm;
     typename M::Lane L(lane);
 
     __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
     __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
-    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
+    WaveProblem<M> pb{L, a.prm.box, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
     pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
     const int n = a.n, nj = a.nj;
@@ -794,13 +813,11 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
         st.status       = r.status;
         st.iterations   = r.iterations;
         st.eps          = r.eps;
-#ifndef PANTR_PHASE_TIMING
         st.final_gamma  = r.gamma;
         st.final_psi    = r.psi;
         st.final_fbe    = r.fbe;
         st.final_radius = r.radius;
-#endif
-        st.elapsed_s    = (double)(wall_clock64() - t_start) * 1e-8;
+        st.elapsed_s    = (double)(wall_clock64() - t_start) * P.tick_s;
         st.outer_iterations = 1;
         st.inner_convergence_failures = r.status == Converged ? 0 : 1;
         a.stats[inst]   = st;
@@ -823,6 +840,7 @@ struct EvalArgs {
     double *out_v2;   ///< [B][n]  PROX: p
     double *ws;       ///< [B][WaveProblem::workspace_doubles(N)]
     double gamma;
+    BoxData box;
 };
 
 template <class M>
@@ -834,7 +852,7 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
     typename M::Lane L(lane);
     __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
     __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
-    WaveProblem<M> pb{L, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
+    WaveProblem<M> pb{L, a.box, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
     pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
     double *u = pb.vec(0), *v = pb.vec(1), *o = pb.vec(2), *o2 = pb.vec(3);
@@ -857,7 +875,7 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
         for (int r = 0; r < (a.reps > 0 ? a.reps : 1); ++r)
             pb.hess_prod_tape(v, o);
         s1 = (double)(clock64() - c0);      // shader cycles
-        s2 = (double)(wall_clock64() - w0); // 100 MHz ticks
+        s2 = (double)(wall_clock64() - w0); // constant-rate clock ticks
         wait_vmem();                        // the rows left in flight for a successor
     } else {
         pb.prox_grad_step(a.gamma, u, v, o, o2, s0, s1);

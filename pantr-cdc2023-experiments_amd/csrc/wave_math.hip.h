@@ -103,9 +103,6 @@ __device__ __forceinline__ dual select(bool c, dual a, dual b) {
 // ---- cross-lane ----------------------------------------------------------------------------
 /// Value of `v` held by lane `src` (src taken modulo 64 by the hardware).
 __device__ __forceinline__ double lane_read(double v, int src) {
-#ifdef PANTR_TIMING_NO_SHUFFLE // timing-only build: results are wrong
-    return v + (double)src;
-#endif
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo     = __builtin_amdgcn_ds_bpermute(src << 2, lo);
     hi     = __builtin_amdgcn_ds_bpermute(src << 2, hi);
@@ -177,9 +174,6 @@ __device__ __forceinline__ double xor4_partner(double v) {
     return (threadIdx.x & 4) ? down : up;
 }
 __device__ __forceinline__ double wave_sum(double v) {
-#ifdef PANTR_TIMING_NO_SHUFFLE // timing-only build: results are wrong
-    return v * 64.0;
-#endif
     double a, b;
     row_partner<true>(v, a, b);
     v = a + b;
@@ -221,9 +215,7 @@ __device__ __forceinline__ void lds_dma_row(const void *gsrc_lane, void *lds_row
 }
 /// Wait until this wavefront's outstanding global loads/stores and LDS-DMA have completed.
 __device__ __forceinline__ void wait_vmem() {
-#ifndef PANTR_TIMING_NO_VMWAIT // timing-only build without it: results are wrong
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
 }
 
 /// The value lane SRC holds, as a wave-uniform (scalar-register) double: two v_readlane_b32.

@@ -18,6 +18,7 @@
 #include "params.hpp"
 
 #include <chrono>
+#include <cmath>
 #include <memory>
 #include <ostream>
 #include <span>
@@ -109,23 +110,70 @@ class TypeErasedProblem {
         check(pantr_batch_get_initial_guess(handle.get(), u.data()));
         return u;
     }
-    // problem functions (single instance, evaluated on the device)
-    real_t eval_psi(crvec x) const {
+    Box get_box_D() const {
+        Box b{vec(m), vec(m)};
+        check(pantr_batch_get_box_D(handle.get(), b.lowerbound.data(), b.upperbound.data()));
+        return b;
+    }
+    // Problem functions (single instance, evaluated on the device), with alpaqa's argument lists
+    // (problems/problems/formulation.hpp:127-176; y and Sigma have size m, empty for m = 0).
+    /// psi(x) = f + 1/2 dist^2_Sigma(g + y/Sigma, D); yhat receives Sigma (zeta - clamp(zeta))
+    real_t eval_psi(crvec x, crvec y, crvec Sigma, rvec yhat) const {
         real_t v;
-        check(pantr_batch_eval_psi(handle.get(), 1, param.data(), x.data(), &v));
+        if (m == 0) {
+            check(pantr_batch_eval_psi(handle.get(), 1, param.data(), x.data(), &v));
+            return v;
+        }
+        need(y, m, "y"), need(Sigma, m, "Sigma"), need(yhat, m, "yhat");
+        vec grad(n);
+        check(pantr_batch_eval_psi_grad_psi_al(handle.get(), 1, param.data(), x.data(), y.data(), Sigma.data(), &v,
+                                               grad.data(), yhat.data()));
         return v;
     }
-    real_t eval_psi_grad_psi(crvec x, rvec grad) const {
+    real_t eval_psi(crvec x) const { return eval_psi(x, {}, {}, {}); }
+    real_t eval_psi_grad_psi(crvec x, crvec y, crvec Sigma, rvec grad, rvec /*work_n*/, rvec /*work_m*/) const {
         real_t v;
-        check(pantr_batch_eval_psi_grad_psi(handle.get(), 1, param.data(), x.data(), &v, grad.data()));
+        need(grad, n, "grad");
+        if (m == 0) {
+            check(pantr_batch_eval_psi_grad_psi(handle.get(), 1, param.data(), x.data(), &v, grad.data()));
+            return v;
+        }
+        need(y, m, "y"), need(Sigma, m, "Sigma");
+        check(pantr_batch_eval_psi_grad_psi_al(handle.get(), 1, param.data(), x.data(), y.data(), Sigma.data(), &v,
+                                               grad.data(), nullptr));
         return v;
     }
-    void eval_grad_L(crvec x, crvec /*y*/, rvec grad, rvec /*work*/) const {
-        real_t v;
-        check(pantr_batch_eval_psi_grad_psi(handle.get(), 1, param.data(), x.data(), &v, grad.data()));
+    real_t eval_psi_grad_psi(crvec x, rvec grad) const { return eval_psi_grad_psi(x, {}, {}, grad, {}, {}); }
+    /// grad_x L(x, y) = grad f(x) + grad g(x)' y
+    void eval_grad_L(crvec x, crvec y, rvec grad, rvec /*work_n*/) const {
+        need(grad, n, "grad"), need(y, m, "y");
+        check(pantr_batch_eval_grad_L(handle.get(), 1, param.data(), x.data(), m ? y.data() : nullptr, grad.data()));
     }
-    void eval_hess_psi_prod(crvec x, crvec v, rvec Hv) const {
-        check(pantr_batch_eval_hess_psi_prod(handle.get(), 1, param.data(), x.data(), v.data(), Hv.data()));
+    /// Hessian-vector product of psi; only scale = 1 exists on the device (formulation.hpp:166 passes 1)
+    void eval_hess_psi_prod(crvec x, crvec y, crvec Sigma, real_t scale, crvec v, rvec Hv) const {
+        if (scale != 1)
+            throw std::invalid_argument("eval_hess_psi_prod: only scale = 1 is available");
+        need(v, n, "v"), need(Hv, n, "Hv");
+        if (m == 0) {
+            check(pantr_batch_eval_hess_psi_prod(handle.get(), 1, param.data(), x.data(), v.data(), Hv.data()));
+            return;
+        }
+        need(y, m, "y"), need(Sigma, m, "Sigma");
+        check(pantr_batch_eval_hess_psi_prod_al(handle.get(), 1, param.data(), x.data(), y.data(), Sigma.data(),
+                                                v.data(), Hv.data()));
+    }
+    void eval_hess_psi_prod(crvec x, crvec v, rvec Hv) const { eval_hess_psi_prod(x, {}, {}, 1, v, Hv); }
+    /// g(x)
+    void eval_g(crvec x, rvec g) const {
+        need(g, m, "g");
+        check(pantr_batch_eval_g(handle.get(), 1, param.data(), x.data(), g.data()));
+    }
+    /// p = z - Pi_D(z)
+    void eval_proj_diff_g(crvec z, rvec p) const {
+        need(z, m, "z"), need(p, m, "p");
+        const Box D = get_box_D();
+        for (length_t j = 0; j < m; ++j)
+            p[j] = z[j] - std::fmax(D.lowerbound[j], std::fmin(z[j], D.upperbound[j]));
     }
     real_t eval_prox_grad_step(real_t gamma, crvec x, crvec grad, rvec xh, rvec p) const {
         real_t s[4];
@@ -140,6 +188,15 @@ class TypeErasedProblem {
     }
 
     pantr_batch_t *get() const { return handle.get(); }
+
+  private:
+    template <class V>
+    static void need(const V &v, length_t size, const char *what) {
+        if (static_cast<length_t>(v.size()) != size)
+            throw std::invalid_argument(std::string("TypeErasedProblem: ") + what + " has the wrong dimension");
+    }
+
+  public:
     length_t n = 0, m = 0, nx = 0, nu = 0, nc = 0, nc_N = 0;
     vec param; ///< initial state: CasADiProblem::param in the reference (casadi-dll-wrapper.cpp:64)
     std::shared_ptr<EvalCounter> evaluations;

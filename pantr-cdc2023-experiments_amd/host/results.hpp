@@ -147,6 +147,29 @@ inline void print_results(std::ostream &os, const MPCBenchmarkResults &r) {
        << std::endl;
 }
 
+/// KKT residuals of (x, y), drivers/results.hpp:258-286: stationarity ||Pi_C(x - grad L) - x||_inf,
+/// constraint violation ||g - Pi_D(g)||_inf, complementarity max |y_j v_j|.
+struct KKTError {
+    double stationarity, constr_violation, complementarity;
+};
+template <class Problem>
+KKTError compute_kkt_error(const Problem &problem, std::span<const double> x, std::span<const double> y) {
+    const size_t n = x.size(), m = y.size();
+    std::vector<double> z(n), grad_Lx(n), work(n), g(m), v(m);
+    problem.eval_grad_L(x, y, grad_Lx, work);
+    problem.eval_prox_grad_step(1, x, grad_Lx, work, z);
+    double stationarity = 0, constr_violation = 0, complementarity = 0;
+    for (double zi : z)
+        stationarity = std::fmax(stationarity, std::fabs(zi));
+    problem.eval_g(x, g);
+    problem.eval_proj_diff_g(g, v);
+    for (size_t j = 0; j < m; ++j) {
+        constr_violation = std::fmax(constr_violation, std::fabs(v[j]));
+        complementarity  = std::fmax(complementarity, std::fabs(y[j] * v[j]));
+    }
+    return {stationarity, constr_violation, complementarity};
+}
+
 inline std::string random_hex_string() {
     std::random_device rd;
     char buf[9];

@@ -18,7 +18,9 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libpantr_mi355x.so")
+# PANTR_LIB_PATH: load another build of the library (e.g. the profiling build `make phase` writes to
+# lib/libpantr_mi355x_phase.so) without ever overwriting the product library.
+LIB_PATH = os.environ.get("PANTR_LIB_PATH") or os.path.join(PKG_DIR, "lib", "libpantr_mi355x.so")
 
 _dbl, _i32 = C.c_double, C.c_int32
 
@@ -60,7 +62,7 @@ class PantrStats(C.Structure):
                [(k, _dbl) for k in ("delta", "penalty_norm")] + \
                [(k, _i32) for k in ("linesearch_failures", "linesearch_backtracks", "lbfgs_failures",
                                     "lbfgs_rejected", "tau_1_accepted", "count_tau")] + \
-               [("sum_tau", _dbl)]
+               [("sum_tau", _dbl), ("phase_s", _dbl * 4)]
 
 
 STATS_DTYPE = np.dtype([(k, np.float64) for k in ("eps", "final_gamma", "final_psi", "final_fbe",
@@ -74,7 +76,7 @@ STATS_DTYPE = np.dtype([(k, np.float64) for k in ("eps", "final_gamma", "final_p
                        [(k, np.int32) for k in ("linesearch_failures", "linesearch_backtracks",
                                                 "lbfgs_failures", "lbfgs_rejected", "tau_1_accepted",
                                                 "count_tau")] +
-                       [("sum_tau", np.float64)])
+                       [("sum_tau", np.float64), ("phase_s", np.float64, (4,))])
 assert STATS_DTYPE.itemsize == C.sizeof(PantrStats)
 
 # every symbol include/pantr_mi355x.h declares
@@ -88,7 +90,10 @@ EXPORTS = (
     "pantr_batch_get_trace", "pantr_batch_eval_psi", "pantr_batch_eval_psi_grad_psi",
     "pantr_batch_eval_hess_psi_prod", "pantr_batch_eval_prox_grad_step",
     "pantr_batch_simulate_dynamics", "pantr_batch_mpc", "pantr_last_error", "pantr_version", "pantr_device_count",
-    "pantr_batch_footprint",
+    "pantr_batch_footprint", "pantr_batch_eval_grad_L", "pantr_batch_create_from_files",
+    "pantr_batch_get_penalty_alm_split", "pantr_problem_data_load", "pantr_problem_data_destroy",
+    "pantr_problem_data_get", "pantr_problem_dims", "pantr_problem_defaults", "pantr_batch_eval_g",
+    "pantr_batch_mpc_record", "pantr_device_copy_bandwidth",
 )
 
 
@@ -150,6 +155,18 @@ def lib():
         L.pantr_batch_simulate_dynamics.argtypes = [vp, _i32, vp, vp, vp]
         L.pantr_batch_mpc.argtypes = [vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp, vp]
         L.pantr_batch_footprint.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.pantr_batch_eval_grad_L.argtypes = [vp, _i32, vp, vp, vp, vp]
+        L.pantr_batch_eval_g.argtypes = [vp, _i32, vp, vp, vp]
+        L.pantr_batch_mpc_record.argtypes = [vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.pantr_device_copy_bandwidth.argtypes = [_i32, C.c_int64, _i32, pd]
+        L.pantr_batch_create_from_files.argtypes = [cp, cp, _i32, _i32, _i32, C.POINTER(vp)]
+        L.pantr_batch_get_penalty_alm_split.argtypes = [vp, C.POINTER(_i32)]
+        L.pantr_problem_data_load.argtypes = [cp, cp, _i32, C.POINTER(vp)]
+        L.pantr_problem_data_destroy.argtypes = [vp]
+        L.pantr_problem_data_destroy.restype = None
+        L.pantr_problem_data_get.argtypes = [vp, C.POINTER(_i32), vp, vp, vp, vp, vp, vp, C.POINTER(_i32)]
+        L.pantr_problem_dims.argtypes = [cp, _i32] + [C.POINTER(_i32)] * 6
+        L.pantr_problem_defaults.argtypes = [cp, _i32, vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -193,13 +210,82 @@ class PantrParams:
             self._h = None
 
 
+def problem_dims(problem, horizon):
+    """(n, m, nx, nu, nc, nc_N) of a compiled-in problem; no device needed."""
+    d = [_i32() for _ in range(6)]
+    _check(lib().pantr_problem_dims(problem.encode(), horizon, *[C.byref(x) for x in d]))
+    return tuple(x.value for x in d)
+
+
+def problem_defaults(problem, horizon):
+    """Compiled-in numeric data of a problem (what problems/generate_problem.py:62-73 would write into
+    its sidecar files): dict with C_lb, C_ub (n), D_lb, D_ub (m), param (nx), guess (n)."""
+    n, m, nx = problem_dims(problem, horizon)[:3]
+    out = dict(C_lb=np.zeros(n), C_ub=np.zeros(n), D_lb=np.zeros(m), D_ub=np.zeros(m),
+               param=np.zeros(nx), guess=np.zeros(n))
+    _check(lib().pantr_problem_defaults(problem.encode(), horizon, *[_ptr(out[k]) for k in
+                                        ("C_lb", "C_ub", "D_lb", "D_ub", "param", "guess")]))
+    return out
+
+
+def write_problem_files(directory, problem, formulation, horizon, data=None):
+    """Write "<dir>/<problem>_<formulation>_<N>.csv" and ".guess.csv" in the reference's format:
+    the seven rows of alpaqa.casadi_generator.write_casadi_problem_data (called at
+    problems/generate_problem.py:62-69) and the two rows of generate_problem.py:71-73, each row one
+    numpy.savetxt call with delimiter "," as there.  `data` defaults to the compiled-in values."""
+    d = dict(problem_defaults(problem, horizon))
+    d.update(data or {})
+    n, m = problem_dims(problem, horizon)[:2]
+    stem = os.path.join(directory, f"{problem}_{formulation}_{horizon}")
+    opt = dict(delimiter=",", newline="\n")
+    row = lambda x: np.reshape(np.asarray(x, dtype=np.float64), (1, -1))
+    with open(stem + ".csv", "w") as f:
+        for key in ("C_lb", "C_ub", "D_lb", "D_ub", "param"):
+            np.savetxt(f, row(d[key]), **opt)
+        np.savetxt(f, row(d.get("l1_reg", [])), **opt)
+        np.savetxt(f, row([d.get("penalty_alm_split_csv", 0)]), **opt)  # generate_problem.py:68
+    with open(stem + ".guess.csv", "w") as f:
+        np.savetxt(f, [np.asarray(d["guess"], dtype=np.float64)], **opt)
+        np.savetxt(f, [d.get("penalty_alm_split", m)], **opt)          # generate_problem.py:32,73
+    return stem
+
+
+def load_problem_files(path, formulation, horizon):
+    """Read and check the sidecar files of "[<dir>/]<name>" (no device needed).  Returns a dict with
+    has_csv, C_lb, C_ub, D_lb, D_ub, param, guess, penalty_alm_split; raises PantrError as the C ABI
+    documents (missing guess file, malformed rows, dimensions that disagree with the problem)."""
+    h = C.c_void_p()
+    _check(lib().pantr_problem_data_load(path.encode(), formulation.encode(), horizon, C.byref(h)))
+    try:
+        n, m, nx = problem_dims(os.path.basename(path), horizon)[:3]
+        out = dict(C_lb=np.zeros(n), C_ub=np.zeros(n), D_lb=np.zeros(m), D_ub=np.zeros(m),
+                   param=np.zeros(nx), guess=np.zeros(n))
+        has_csv, split = _i32(), _i32()
+        _check(lib().pantr_problem_data_get(h, C.byref(has_csv), *[_ptr(out[k]) for k in
+                                            ("C_lb", "C_ub", "D_lb", "D_ub", "param", "guess")],
+                                            C.byref(split)))
+        out["has_csv"], out["penalty_alm_split"] = bool(has_csv.value), split.value
+        return out
+    finally:
+        lib().pantr_problem_data_destroy(h)
+
+
 class PantrBatch:
     """A problem (name, horizon) with device resources for up to max_instances solves."""
 
-    def __init__(self, problem="hanging_chain", horizon=60, max_instances=1, device=0, opts=()):
+    def __init__(self, problem="hanging_chain", horizon=60, max_instances=1, device=0, opts=(),
+                 files=None):
+        """files=(path, formulation): load_benchmark_casadi_problem's data half - `path` =
+        "[<dir>/]<name>" names the problem and its sidecar files, whose bounds, initial state and
+        initial guess replace the compiled-in values (`problem` is ignored)."""
         self._h = C.c_void_p()
-        _check(lib().pantr_batch_create(problem.encode(), horizon, max_instances, device,
-                                        C.byref(self._h)))
+        if files is not None:
+            path, formulation = files
+            _check(lib().pantr_batch_create_from_files(path.encode(), formulation.encode(), horizon,
+                                                       max_instances, device, C.byref(self._h)))
+        else:
+            _check(lib().pantr_batch_create(problem.encode(), horizon, max_instances, device,
+                                            C.byref(self._h)))
         d = [_i32() for _ in range(6)]
         _check(lib().pantr_batch_dims(self._h, *[C.byref(x) for x in d]))
         self.n, self.m, self.nx, self.nu, self.nc, self.nc_N = [x.value for x in d]
@@ -244,6 +330,11 @@ class PantrBatch:
         x = np.zeros(self.nx)
         _check(lib().pantr_batch_get_initial_state(self._h, _ptr(x)))
         return x
+
+    def penalty_alm_split(self):
+        v = _i32()
+        _check(lib().pantr_batch_get_penalty_alm_split(self._h, C.byref(v)))
+        return v.value
 
     def footprint(self):
         a, b = C.c_int64(), C.c_int64()
@@ -307,16 +398,27 @@ class PantrBatch:
         return out
 
     # ---- problem functions ---------------------------------------------------------------
-    def eval_psi(self, x0, u):
-        x0, u = _f64(x0), _f64(u)
+    def _rows(self, x0, *vecs, width=None):
+        """x0: (B, width); every further array (B, n) (or, as a (array, width) pair, (B, width)).
+        Returns B and the validated contiguous fp64 arrays: the C side trusts these shapes."""
+        x0 = _f64(x0)
+        if x0.ndim != 2:
+            raise ValueError(f"expected a 2-D batch (B, {width or self.nx}), got shape {x0.shape}")
         B = x0.shape[0]
+        out = [_f64(x0, (B, self.nx if width is None else width))]
+        for v in vecs:
+            v, w = v if isinstance(v, tuple) else (v, self.n)
+            out.append(_f64(v, (B, w)))
+        return [B] + out
+
+    def eval_psi(self, x0, u):
+        B, x0, u = self._rows(x0, u)
         psi = np.zeros(B)
         _check(lib().pantr_batch_eval_psi(self._h, B, _ptr(x0), _ptr(u), _ptr(psi)))
         return psi
 
     def eval_psi_grad_psi(self, x0, u):
-        x0, u = _f64(x0), _f64(u)
-        B = x0.shape[0]
+        B, x0, u = self._rows(x0, u)
         psi, grad = np.zeros(B), np.zeros((B, self.n))
         _check(lib().pantr_batch_eval_psi_grad_psi(self._h, B, _ptr(x0), _ptr(u), _ptr(psi),
                                                    _ptr(grad)))
@@ -324,60 +426,79 @@ class PantrBatch:
 
     def eval_hess_psi_prod(self, x0, u, v):
         """Hv: records the second-order tape at u, then replays it for v (the solver's path)."""
-        x0, u, v = _f64(x0), _f64(u), _f64(v)
-        B = x0.shape[0]
+        B, x0, u, v = self._rows(x0, u, v)
         Hv = np.zeros((B, self.n))
         _check(lib().pantr_batch_eval_hess_psi_prod(self._h, B, _ptr(x0), _ptr(u), _ptr(v), _ptr(Hv)))
         return Hv
 
     def eval_psi_grad_psi_al(self, x0, u, y, Sigma):
         """psi, grad psi and yhat with multipliers y and penalties Sigma (formulation.hpp:145-161)."""
-        x0, u, y, Sigma = _f64(x0), _f64(u), _f64(y), _f64(Sigma)
-        B = x0.shape[0]
+        B, x0, u, y, Sigma = self._rows(x0, u, (y, self.m), (Sigma, self.m))
         psi, grad, yhat = np.zeros(B), np.zeros((B, self.n)), np.zeros((B, self.m))
         _check(lib().pantr_batch_eval_psi_grad_psi_al(self._h, B, _ptr(x0), _ptr(u), _ptr(y), _ptr(Sigma),
                                                       _ptr(psi), _ptr(grad), _ptr(yhat)))
         return psi, grad, yhat
 
+    def eval_grad_L(self, x0, u, y):
+        """grad_x L(x, y) = grad f + grad g' y (formulation.hpp:170-176), m > 0 problems."""
+        B, x0, u, y = self._rows(x0, u, (y, self.m))
+        grad = np.zeros((B, self.n))
+        _check(lib().pantr_batch_eval_grad_L(self._h, B, _ptr(x0), _ptr(u), _ptr(y), _ptr(grad)))
+        return grad
+
+    def eval_g(self, x0, u):
+        """g(u): the stage constraints along the trajectory, then the terminal ones (ss.py:39-40)."""
+        B, x0, u = self._rows(x0, u)
+        g = np.zeros((B, self.m))
+        _check(lib().pantr_batch_eval_g(self._h, B, _ptr(x0), _ptr(u), _ptr(g)))
+        return g
+
     def eval_hess_psi_prod_al(self, x0, u, y, Sigma, v):
-        x0, u, y, Sigma, v = _f64(x0), _f64(u), _f64(y), _f64(Sigma), _f64(v)
-        B = x0.shape[0]
+        B, x0, u, y, Sigma, v = self._rows(x0, u, (y, self.m), (Sigma, self.m), v)
         Hv = np.zeros((B, self.n))
         _check(lib().pantr_batch_eval_hess_psi_prod_al(self._h, B, _ptr(x0), _ptr(u), _ptr(y), _ptr(Sigma),
                                                        _ptr(v), _ptr(Hv)))
         return Hv
 
     def eval_prox_grad_step(self, gamma, x, grad):
-        x, grad = _f64(x), _f64(grad)
-        B = x.shape[0]
+        B, x, grad = self._rows(x, grad, width=self.n)
         xh, p, s = np.zeros((B, self.n)), np.zeros((B, self.n)), np.zeros((B, 4))
         _check(lib().pantr_batch_eval_prox_grad_step(self._h, B, gamma, _ptr(x), _ptr(grad),
                                                      _ptr(xh), _ptr(p), _ptr(s)))
         return xh, p, s
 
     def simulate_dynamics(self, x, u):
-        x, u = _f64(x), _f64(u)
-        B = x.shape[0]
+        B, x, u = self._rows(x, (u, self.nu))
         xn = np.zeros((B, self.nx))
         _check(lib().pantr_batch_simulate_dynamics(self._h, B, _ptr(x), _ptr(u), _ptr(xn)))
         return xn
 
-
-    def mpc(self, num_sim, warm, u_dist, num_dist=5, x_init=None):
+    def mpc(self, num_sim, warm, u_dist, num_dist=5, x_init=None, record=False):
         """B closed loops in lock-step on the device (do_mpc_experiment, mpc-driver.cpp:123-210).
 
         u_dist: (B, nu) disturbance per trajectory.  Returns states (num_sim+1, B, nx),
-        inputs (num_sim, B, n), stats (num_sim, B)."""
+        inputs (num_sim, B, n), stats (num_sim, B); with record=True also a dict with the guesses
+        every step was solved from (guess_u, guess_y) and the multipliers it returned."""
         u_dist = _f64(u_dist)
+        if u_dist.ndim != 2 or u_dist.shape[1] != self.nu:
+            raise ValueError(f"expected u_dist shape (B, {self.nu}), got {u_dist.shape}")
         B = u_dist.shape[0]
         states = np.zeros((num_sim + 1, B, self.nx))
         inputs = np.zeros((num_sim, B, self.n))
         stats = np.zeros((num_sim, B), dtype=STATS_DTYPE)
         xi = None if x_init is None else _f64(x_init, (B, self.nx))
-        _check(lib().pantr_batch_mpc(self._h, B, num_sim, int(bool(warm)), num_dist,
-                                     None if xi is None else _ptr(xi), _ptr(u_dist), _ptr(states),
-                                     _ptr(inputs), _ptr(stats)))
-        return states, inputs, stats
+        if not record:
+            _check(lib().pantr_batch_mpc(self._h, B, num_sim, int(bool(warm)), num_dist,
+                                         None if xi is None else _ptr(xi), _ptr(u_dist), _ptr(states),
+                                         _ptr(inputs), _ptr(stats)))
+            return states, inputs, stats
+        rec = dict(guess_u=np.zeros((num_sim, B, self.n)), guess_y=np.zeros((num_sim, B, self.m)),
+                   multipliers=np.zeros((num_sim, B, self.m)))
+        _check(lib().pantr_batch_mpc_record(self._h, B, num_sim, int(bool(warm)), num_dist,
+                                            None if xi is None else _ptr(xi), _ptr(u_dist), _ptr(states),
+                                            _ptr(inputs), _ptr(stats), _ptr(rec["guess_u"]),
+                                            _ptr(rec["guess_y"]), _ptr(rec["multipliers"])))
+        return states, inputs, stats, rec
 
 
 def device_count():
@@ -386,6 +507,32 @@ def device_count():
 
 def version():
     return lib().pantr_version().decode()
+
+
+def source_hash():
+    """sha256 over the kernel sources (csrc/, sorted by name): ties a committed profile summary to the
+    code it was taken at (bench.py refuses PMC traffic numbers from another version)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(PKG_DIR, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def copy_bandwidth(device=0, nbytes=2 << 30, reps=5):
+    """Achievable HBM bandwidth (GB/s, read + written) from the library's 16 B/lane device copy."""
+    v = _dbl()
+    _check(lib().pantr_device_copy_bandwidth(device, nbytes, reps, C.byref(v)))
+    return v.value
+
+
+def is_product_build():
+    """False for a library built with a switch that changes what it reports (pantr_version())."""
+    return "+" not in version()
 
 
 def algorithmic_bytes(stats, N, nx, nu, m=0):

@@ -94,3 +94,69 @@ def config5_disturbances(B=1024, seed=12345):
     """d_j in [-1,1]^3, three draws per instance in order."""
     g = MT19937_64(seed)
     return np.array([[g.uniform(-1.0, 1.0) for _ in range(3)] for _ in range(B)])
+
+
+# ---- replay batches of BASELINE.json's configs, produced by the product's own closed loops --------
+# Each returns a dict: problem, horizon, x0 (B, nx), u0 (B, n), y0 (B, m) or None, sol (B, n) the
+# solutions the closed loops recorded (a replay must reproduce them bit for bit), warm (B,) flags,
+# opts (solver options), label.
+
+def _quad_solver_opts(problem):
+    """dodo.py:12-33 + :96-105, solver options only."""
+    t = dodo_pantr_tasks(problem, horizons=(10,))[0]
+    return tuple(o for o in t["argv"][3:] if o.startswith(("solver.", "alm.", "dir.", "accel.")))
+
+
+def closed_loop_batch(problem, horizon, num_sim=NUM_SIM, starts=(True, False), device=0, opts=None):
+    """The timed steps of the closed loops of one (problem, horizon) for the given starts (True =
+    warm), recorded on the device with PantrBatch.mpc: the replay batch of SURVEY.md 8(d)."""
+    from . import PantrBatch, DODO_PANTR_OPTS
+    chain = problem == "hanging_chain"
+    opts = tuple(opts) if opts is not None else (tuple(DODO_PANTR_OPTS) if chain else _quad_solver_opts(problem))
+    b = PantrBatch(problem, horizon, 1, device=device, opts=opts)
+    u_dist = np.array([[-1.0, 1.0, 1.0]]) if chain else np.zeros((1, b.nu))      # dodo.py:94-100
+    num_dist = 5 if chain else 0
+    x0, u0, y0, sol, warm_flags = [], [], [], [], []
+    for warm in starts:
+        states, inputs, stats, rec = b.mpc(num_sim, warm, u_dist, num_dist=num_dist, record=True)
+        if not np.all(stats["status"] == 1):
+            raise RuntimeError(f"{problem} N={horizon} {'warm' if warm else 'cold'}: a closed-loop step did not converge")
+        x0.append(states[:num_sim, 0]); u0.append(rec["guess_u"][:, 0]); y0.append(rec["guess_y"][:, 0])
+        sol.append(inputs[:, 0]); warm_flags += [warm] * num_sim
+    m = b.m
+    b.close()
+    return dict(problem=problem, horizon=horizon, x0=np.vstack(x0), u0=np.vstack(u0),
+                y0=np.vstack(y0) if m else None, sol=np.vstack(sol), warm=np.array(warm_flags), opts=opts,
+                label=f"{problem} N={horizon}: {num_sim} time steps x {len(starts)} starts")
+
+
+def headline_batch(device=0, num_sim=300, horizon=60):
+    """BASELINE.json configs[1] + its cold twin: the num_sim timed steps of ONE warm-started closed
+    loop (num_dist=5, u_dist=-1,1,1), each to be solved from its warm guess and from the cold guess
+    u = 0 (mpc-driver.cpp:168-175 | 192-197): 2 num_sim instances, warm half first."""
+    w = closed_loop_batch("hanging_chain", horizon, num_sim, starts=(True,), device=device)
+    B = len(w["x0"])
+    return dict(w, x0=np.vstack([w["x0"], w["x0"]]), u0=np.vstack([w["u0"], np.zeros_like(w["u0"])]),
+                sol=w["sol"], warm=np.r_[np.ones(B, bool), np.zeros(B, bool)],
+                label=f"hanging_chain N={horizon}: {num_sim} time steps of one warm closed loop, each solved warm and cold")
+
+
+def stress_batch(B=1024, device=0, horizon=120):
+    """BASELINE.json configs[4]: synthetic initial states x0_j = f_d^5(x_rest, d_j), cold starts."""
+    from . import PantrBatch, DODO_PANTR_OPTS
+    d = config5_disturbances(1024)[:B]
+    b = PantrBatch("hanging_chain", horizon, B, device=device)
+    x0 = np.tile(b.initial_state(), (B, 1))
+    for _ in range(5):
+        x0 = b.simulate_dynamics(x0, d)
+    n = b.n
+    b.close()
+    return dict(problem="hanging_chain", horizon=horizon, x0=x0, u0=np.zeros((B, n)), y0=None, sol=None,
+                warm=np.zeros(B, bool), opts=tuple(DODO_PANTR_OPTS),
+                label=f"hanging_chain N={horizon}: {B} synthetic initial states (mt19937_64(12345)), cold")
+
+
+def expected_cost(horizon, warm):
+    """Relative cost of one instance for longest-first dealing: the published mean
+    solver times grow like N^2.7 and a cold start costs about 2.5 warm ones."""
+    return float(horizon) ** 2.7 * (1.0 if warm else 2.5)

@@ -14,7 +14,7 @@ L = pa.lib()
 b = pa.PantrBatch("hanging_chain", 60, B)
 res = {}
 for reps in (1, 101):
-    L.pantr_debug_set_eval_reps(reps)
+    L.pantr_debug_set_eval_reps(b._h, reps)
     b.eval_hess_psi_prod(x0, u, v)
     t = time.perf_counter(); Hv = b.eval_hess_psi_prod(x0, u, v); res[reps] = time.perf_counter() - t
 import ctypes as C

@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
-"""Per-phase solve time from a -DPANTR_PHASE_TIMING build (run through scripts/phase_timing.sh)."""
+"""Per-phase solve time from the profiling build of the library (run through scripts/phase_timing.sh,
+which builds it to its own file and points PANTR_LIB_PATH at it)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pantr-cdc2023-experiments_amd"))
 import pantr_amd as pa
 from pantr_amd import workloads
+
+if "+phase-timing" not in pa.version():
+    raise SystemExit(f"{pa.LIB_PATH} is not the profiling build ({pa.version()}): run scripts/phase_timing.sh")
 
 
 def report(name, st):
@@ -15,9 +19,9 @@ def report(name, st):
     print(f"{name}: {len(st)} solves, mean {el/len(st)*1e3:.2f} ms, {it/len(st):.1f} iterations, "
           f"{st['n_hess_psi_prod'].sum()/len(st):.1f} Hv")
     rest = el
-    for label, field, cnt in (("hess_prod", "final_gamma", "n_hess_psi_prod"), ("psi_grad(cand)", "final_psi", "n_psi_grad_psi"),
-                              ("psi(xhat)", "final_fbe", "n_psi"), ("grad_L(xhat)+tape", "final_radius", "n_grad_L")):
-        t, c = st[field].sum(), st[cnt].sum()
+    for label, field, cnt in (("hess_prod", 0, "n_hess_psi_prod"), ("psi_grad(cand)", 1, "n_psi_grad_psi"),
+                              ("psi(xhat)", 2, "n_psi"), ("grad_L(xhat)+tape", 3, "n_grad_L")):
+        t, c = st["phase_s"][:, field].sum(), st[cnt].sum()
         rest -= t
         print(f"   {label:18s} {100*t/el:5.1f} %   {t/max(c,1)*1e6:8.1f} us per call ({c/len(st):.1f} calls)")
     print(f"   {'everything else':18s} {100*rest/el:5.1f} %   {rest/max(it,1)*1e6:8.1f} us per iteration")
@@ -28,9 +32,9 @@ def report_panoc(name, st):
     el, it = st["elapsed_s"].sum(), st["iterations"].sum()
     print(f"{name}: {len(st)} solves, mean {el/len(st)*1e3:.2f} ms, {it/len(st):.1f} iterations")
     rest = el
-    for label, field, cnt in (("L-BFGS apply", "final_gamma", "iterations"), ("psi_grad", "final_psi", "n_psi_grad_psi"),
-                              ("psi(xhat)", "final_fbe", "n_psi"), ("L-BFGS update", "final_radius", "iterations")):
-        t, c = st[field].sum(), st[cnt].sum()
+    for label, field, cnt in (("L-BFGS apply", 0, "iterations"), ("psi_grad", 1, "n_psi_grad_psi"),
+                              ("psi(xhat)", 2, "n_psi"), ("L-BFGS update", 3, "iterations")):
+        t, c = st["phase_s"][:, field].sum(), st[cnt].sum()
         rest -= t
         print(f"   {label:18s} {100*t/el:5.1f} %   {t/max(c,1)*1e6:8.1f} us per call")
     print(f"   {'everything else':18s} {100*rest/el:5.1f} %   {rest/max(it,1)*1e6:8.1f} us per iteration")

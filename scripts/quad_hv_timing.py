@@ -15,10 +15,10 @@ for N in (20, 60):
         y, Sig, v = np.zeros((B, m)), np.full((B, m), 1e4), rng.standard_normal((B, n))
         res = {}
         for reps in (1, 201):
-            L.pantr_debug_set_eval_reps(reps)
+            L.pantr_debug_set_eval_reps(b._h, reps)
             b.eval_hess_psi_prod_al(x0, u, y, Sig, v)
             t = time.perf_counter(); b.eval_hess_psi_prod_al(x0, u, y, Sig, v); res[reps] = time.perf_counter() - t
-        L.pantr_debug_set_eval_reps(1)
+        L.pantr_debug_set_eval_reps(b._h, 1)
         per = (res[201] - res[1]) / 200
         print(f"N={N} B={B}: {per*1e6:.2f} us per product = {per/N*1e9:.0f} ns per stage")
         b.close()

@@ -7,6 +7,8 @@ on gfx950 FETCH_SIZE counts 64 B per 128-B read request, so it is doubled before
 (an upper bound for this kernel's 8-B-per-lane row reads, which are uncalibrated).
 """
 import csv, glob, json, os, shutil, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pantr-cdc2023-experiments_amd"))
+import pantr_amd as pa
 
 
 def newest(pattern):
@@ -14,14 +16,16 @@ def newest(pattern):
     return max(files, key=os.path.getmtime) if files else None
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 KERNEL = "pantr_solve_kernel"
 
-summary = {"tag": tag, "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
-           "kernel": "pantr::pantr_solve_kernel<pantr::ChainModel, 0>"}
+summary = {"tag": tag, "command": "python3 bench.py --steps 3 --warmup 1 --headline-only",
+           "kernel": "pantr::pantr_solve_kernel<pantr::ChainModel, 0>",
+           # the code these numbers describe: bench.py prints roofline.traffic only while csrc/ still hashes to this
+           "csrc_sha256": pa.source_hash()}
 stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 for r in csv.DictReader(open(stats)):

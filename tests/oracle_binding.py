@@ -123,6 +123,8 @@ def lib():
         L.oracle_quad_solve.restype = C.c_int
         L.oracle_quad_mpc.argtypes = [C.c_int, C.c_int, C.POINTER(OracleParams), C.c_int, C.c_int,
                                       C.c_int, _pd, _pd, _pd, C.POINTER(OracleStats)]
+        L.oracle_quad_mpc_full.argtypes = [C.c_int, C.c_int, C.POINTER(OracleParams), C.c_int, C.c_int,
+                                           C.c_int, _pd, _pd, _pd, C.POINTER(OracleStats), _pd, _pd, _pd]
         L.oracle_steihaug_dense.argtypes = [C.c_int, _pd, _pd, _dbl, _dbl, _dbl, _dbl, _pd,
                                             C.POINTER(C.c_int)]
         L.oracle_steihaug_dense.restype = _dbl
@@ -334,3 +336,18 @@ def quad_mpc(problem, N, num_sim, warm, num_dist=0, u_dist=(0.0, 0.0, 0.0, 0.0),
     lib().oracle_quad_mpc(QUAD[problem], N, C.byref(params), num_sim, int(warm), num_dist,
                           np.ascontiguousarray(u_dist, float), states, inputs, stats)
     return states, inputs, [s.as_dict() for s in stats]
+
+
+def quad_mpc_full(problem, N, num_sim, warm, num_dist=0, u_dist=(0.0, 0.0, 0.0, 0.0), params=None):
+    """quad_mpc plus what a replay batch needs: returns a dict with states, inputs, stats, and the
+    guesses (guess_u, guess_y) every step was solved from and the multipliers it returned."""
+    params = params or quad_dodo_params(problem)
+    n, m = 4 * N, 4 * N + 4
+    r = dict(states=np.zeros((num_sim + 1, 9)), inputs=np.zeros((num_sim, n)), guess_u=np.zeros((num_sim, n)),
+             guess_y=np.zeros((num_sim, m)), multipliers=np.zeros((num_sim, m)))
+    stats = (OracleStats * num_sim)()
+    lib().oracle_quad_mpc_full(QUAD[problem], N, C.byref(params), num_sim, int(warm), num_dist,
+                               np.ascontiguousarray(u_dist, float), r["states"], r["inputs"], stats,
+                               r["guess_u"], r["guess_y"], r["multipliers"])
+    r["stats"] = [s.as_dict() for s in stats]
+    return r

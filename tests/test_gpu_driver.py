@@ -17,6 +17,7 @@ from pantr_amd import workloads
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "pantr-cdc2023-experiments_amd", "bin", "benchmark-mpc-driver")
+SELFTEST = os.path.join(ROOT, "pantr-cdc2023-experiments_amd", "bin", "facade-selftest")
 
 
 def load_results(path, name):
@@ -104,3 +105,58 @@ def test_driver_quadcopter_closed_loop_matches_oracle(tmp_path, problem):
     assert np.array_equal(res["states"].T, states) and np.array_equal(res["inputs"].T, inputs)
     assert res["nvar"] == 4 * N and res["ncon"] == 4 * N + 4 and np.all(res["runtimes"] > 0)
     assert res["evaluations"]["hess_ψ_prod"] == sum(s["n_hess_psi_prod"] for s in stats)
+
+
+@pytest.mark.parametrize("problem", ["quadcopter", "realistic_quadcopter", "hanging_chain"])
+def test_cpp_facade_eval_functions_match_ctypes_path(tmp_path, problem):
+    """Every TypeErasedProblem::eval_* of host/alpaqa_compat.hpp, called once by bin/facade-selftest,
+    against the ctypes path on the same inputs (and eval_grad_L against its definition: for m > 0 it
+    must use y: grad_L(x, yhat(x; y, Sigma)) = grad psi(x; y, Sigma), formulation.hpp:79-99)."""
+    N = 7
+    rng = np.random.default_rng(11)
+    b = pa.PantrBatch(problem, N, 1)
+    n, m, nx, nu = b.n, b.m, b.nx, b.nu
+    param = b.initial_state() + 0.03 * rng.standard_normal(nx)
+    x = b.initial_guess() + 0.05 * rng.standard_normal(n)
+    y, Sigma, v = rng.standard_normal(m), 10 ** rng.uniform(0, 3, m), rng.standard_normal(n)
+    with open(tmp_path / "in.csv", "w") as f:
+        for row in (param, x, y, Sigma, v):
+            f.write(",".join(repr(float(t)) for t in row) + "\n")
+    r = subprocess.run([SELFTEST, problem, str(N), str(tmp_path / "in.csv")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = {ln.split()[0]: np.array([float(t) for t in ln.split()[1:]]) for ln in r.stdout.splitlines() if ln}
+    P, X, Y, S, V = param[None], x[None], y[None], Sigma[None], v[None]
+    if m:
+        psi, grad, yhat = b.eval_psi_grad_psi_al(P, X, Y, S)
+        Hv = b.eval_hess_psi_prod_al(P, X, Y, S, V)
+        g = b.eval_g(P, X)
+        lbD, ubD = b.box_D()
+        assert np.array_equal(out["yhat"], yhat[0]) and np.array_equal(out["g"], g[0])
+        assert np.array_equal(out["proj_diff_g"], g[0] - np.clip(g[0], lbD, ubD))
+        # eval_g against the oracle's constraint function
+        f_o, g_o = ob.quad_f_g(problem, N, param, x)
+        assert np.array_equal(g[0], g_o)
+        # grad_L uses y: with y := yhat it reproduces grad psi, with another y it does not
+        assert np.array_equal(b.eval_grad_L(P, X, yhat)[0], grad[0])
+        assert not np.array_equal(out["grad_L"], grad[0])
+    else:
+        psi, grad = b.eval_psi_grad_psi(P, X)
+        Hv = b.eval_hess_psi_prod(P, X, V)
+        assert out["yhat"].size == 0 and out["g"].size == 0
+    grad_L = b.eval_grad_L(P, X, Y)
+    xh, p, sc = b.eval_prox_grad_step(0.05, X, grad)
+    assert out["psi"][0] == psi[0] == out["psi2"][0]
+    assert np.array_equal(out["grad_psi"], grad[0]) and np.array_equal(out["hess_psi_prod"], Hv[0])
+    assert np.array_equal(out["grad_L"], grad_L[0])
+    assert np.array_equal(out["xhat"], xh[0]) and np.array_equal(out["p"], p[0])
+    assert np.array_equal(out["simulate"], b.simulate_dynamics(P, X[:, :nu])[0])
+    lb, ub = b.box_C()
+    assert np.array_equal(out["C_lb"], lb) and np.array_equal(out["C_ub"], ub)
+    # KKT residuals with the semantics of drivers/results.hpp:258-286
+    z = np.clip(x - grad_L[0], lb, ub) - x
+    kkt = [np.max(np.abs(z)), 0.0, 0.0]
+    if m:
+        vv = g[0] - np.clip(g[0], lbD, ubD)
+        kkt[1:] = [np.max(np.abs(vv)), np.max(np.abs(y * vv))]
+    assert np.allclose(out["kkt"], kkt, rtol=1e-13, atol=0)
+    b.close()

@@ -146,39 +146,76 @@ def test_closed_loops_in_lock_step_match_oracle(rng, warm):
         assert np.all(stats["status"][:, b] == 1)
 
 
-def test_config5_stress_horizon_120(rng):
-    """BASELINE.json configs[4]: N=120 (n=360), synthetic initial states x0_j = f_d^5(x_rest, d_j)."""
+def test_config5_stress_horizon_120():
+    """BASELINE.json configs[4], one GPU's shard: N=120 (n=360), 128 of the 1024 synthetic initial
+    states x0_j = f_d^5(x_rest, d_j), d_j from mt19937_64(12345).  All 128 are
+    certified (status, eps, box), 16 are compared with the oracle bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
     from pantr_amd import workloads
-    N, B = 120, 16
-    d = workloads.config5_disturbances(B)
+    N, B = 120, 128
+    d = workloads.config5_disturbances(1024)[:B]
     batch = pa.PantrBatch("hanging_chain", N, B, opts=pa.DODO_PANTR_OPTS)
     x0 = np.tile(batch.initial_state(), (B, 1))
     for _ in range(5):
         x0 = batch.simulate_dynamics(x0, d)
     u, st = batch.solve(x0, np.zeros((B, NU * N)))
     lds, ws = batch.footprint()
-    batch.close()
     assert lds <= 160 * 1024 and np.all(st["status"] == 1) and np.all(st["eps"] <= 1e-8)
     assert np.all(np.abs(u) <= 1.0)
-    for b in (0, 7, 15):
+    _, grad = batch.eval_psi_grad_psi(x0, u)           # ProjGradUnitNorm of the returned points
+    assert np.max(np.abs(np.clip(u - grad, -1, 1) - u)) <= 1e-8
+    batch.close()
+    pick = list(range(0, B, 8))
+
+    def oracle(b):
         xo = ob.initial_state()
         for _ in range(5):
             xo = ob.simulate(xo, d[b])
-        assert np.array_equal(xo, x0[b])
-        u_o, st_o, _ = ob.solve(N, xo, np.zeros(NU * N))
-        assert np.array_equal(u[b], u_o) and st["iterations"][b] == st_o["iterations"]
+        return (xo,) + ob.solve(N, xo, np.zeros(NU * N))[:2]
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+        res = list(ex.map(oracle, pick))
+    for b, (xo, u_o, st_o) in zip(pick, res):
+        assert np.array_equal(xo, x0[b]) and np.array_equal(u[b], u_o)
+        for key in ("iterations", "cg_iterations", "n_hess_psi_prod", "n_psi", "n_psi_grad_psi", "n_grad_L"):
+            assert st[key][b] == st_o[key], key
 
 
-def test_config4_horizon_sweep(rng):
-    """BASELINE.json configs[3] in miniature: horizons x {cold, warm} closed loops == oracle."""
-    num_sim = 4
-    for N in (10, 20, 30):
-        for warm in (True, False):
+def test_config4_horizon_sweep():
+    """BASELINE.json configs[3] at its stated size: hanging_chain N in {10,...,60} x {cold, warm} x 60
+    timed MPC steps = 720 instances (dodo.py:10,69-95).  Every device closed loop equals the
+    oracle's, and each horizon's 120 steps replayed as one batch reproduce the solutions and
+    counters (one launch per horizon: the form bench.py measures)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from pantr_amd import workloads
+    num_sim = workloads.NUM_SIM
+    combos = [(N, warm) for N in workloads.HORIZONS for warm in (True, False)]
+    with ThreadPoolExecutor(min(12, os.cpu_count() or 1)) as ex:
+        fut = {c: ex.submit(ob.mpc, c[0], num_sim, c[1]) for c in combos}
+        dev = {}
+        for N in workloads.HORIZONS:
             batch = pa.PantrBatch("hanging_chain", N, 1, opts=pa.DODO_PANTR_OPTS)
-            states, inputs, stats = batch.mpc(num_sim, warm, np.array([[-1.0, 1.0, 1.0]]))
+            for warm in (True, False):
+                dev[(N, warm)] = batch.mpc(num_sim, warm, np.array([[-1.0, 1.0, 1.0]]), num_dist=5)
             batch.close()
-            st_o, in_o, _, _ = ob.mpc(N, num_sim, warm)
-            assert np.array_equal(states[:, 0], st_o) and np.array_equal(inputs[:, 0], in_o)
+        orc = {c: fut[c].result() for c in combos}
+    total = 0
+    for N in workloads.HORIZONS:
+        x0s, guesses, sols, stats_o = [], [], [], []
+        for warm in (True, False):
+            states, inputs, stats = dev[(N, warm)]
+            st_o, in_o, gs_o, so = orc[(N, warm)]
+            assert np.array_equal(states[:, 0], st_o) and np.array_equal(inputs[:, 0], in_o), (N, warm)
+            assert np.all(stats["status"][:, 0] == 1) and np.all(stats["eps"] <= 1e-8)
+            assert stats["iterations"][:, 0].tolist() == [s["iterations"] for s in so]
+            x0s.append(st_o[:num_sim]); guesses.append(gs_o); sols.append(in_o); stats_o += so
+        batch = pa.PantrBatch("hanging_chain", N, 2 * num_sim, opts=pa.DODO_PANTR_OPTS)
+        u, st = batch.solve(np.vstack(x0s), np.vstack(guesses))
+        batch.close()
+        assert np.array_equal(u, np.vstack(sols)), N
+        for key in ("iterations", "cg_iterations", "n_hess_psi_prod", "n_psi", "n_psi_grad_psi", "n_grad_L", "status"):
+            assert st[key].tolist() == [s[key] for s in stats_o], (N, key)
+        total += len(u)
+    assert total == 720
 
 
 def test_bench_workload_matches_oracle_at_full_occupancy():
@@ -199,3 +236,49 @@ def test_bench_workload_matches_oracle_at_full_occupancy():
     for key in ("iterations", "n_hess_psi_prod", "cg_iterations", "status"):
         assert np.array_equal(st[key], np.array([s[key] for s in st_o])), key
 
+
+
+def test_problem_created_from_sidecar_files(tmp_path, rng):
+    """load_benchmark_casadi_problem's data half (casadi-dll-wrapper.cpp:25-67): files in the layout of
+    generate_problem.py:62-73.  Unmodified files give the compiled-in problem bit for bit; a tighter
+    box C, another initial state and another initial guess are honoured by the solver."""
+    N, B = 20, 3
+    d = str(tmp_path)
+    pa.write_problem_files(d, "hanging_chain", "ss2p", N)
+    x0, u0 = random_states(rng, B, 0.02), random_inputs(rng, B, N, -0.3, 0.3)
+    ref = pa.PantrBatch("hanging_chain", N, B, opts=pa.DODO_PANTR_OPTS)
+    same = pa.PantrBatch(horizon=N, max_instances=B, opts=pa.DODO_PANTR_OPTS,
+                         files=(os.path.join(d, "hanging_chain"), "ss2p"))
+    u_ref, st_ref = ref.solve(x0, u0)
+    u_same, st_same = same.solve(x0, u0)
+    assert np.array_equal(u_ref, u_same) and np.array_equal(st_ref["iterations"], st_same["iterations"])
+    assert same.penalty_alm_split() == 0 and ref.penalty_alm_split() == 0   # m = 0 (generate_problem.py:32)
+    same.close()
+    bound = np.tile([0.4, 0.25, 0.6], N)
+    guess = np.tile([0.1, -0.1, 0.05], N)
+    param = disturbed_state(3)
+    pa.write_problem_files(d, "hanging_chain", "ss2p", N, dict(C_lb=-bound, C_ub=bound, guess=guess, param=param))
+    tight = pa.PantrBatch(horizon=N, max_instances=B, opts=pa.DODO_PANTR_OPTS,
+                          files=(os.path.join(d, "hanging_chain"), "ss2p"))
+    lb, ub = tight.box_C()
+    assert np.array_equal(ub, bound) and np.array_equal(lb, -bound)
+    assert np.array_equal(tight.initial_guess(), guess) and np.array_equal(tight.initial_state(), param)
+    u_t, st_t = tight.solve(x0, u0)
+    assert np.all(st_t["status"] == 1) and np.all(st_t["eps"] <= 1e-8)
+    assert np.all(np.abs(u_t) <= bound[None, :]) and np.any(np.abs(u_t) == bound[None, :])   # the new box binds
+    assert np.any(np.abs(u_ref) > bound[None, :])                                           # and the old one did not
+    # optimality in the new box: ||Pi_C(u - grad) - u||_inf <= tolerance
+    _, grad = tight.eval_psi_grad_psi(x0, u_t)
+    assert np.max(np.abs(np.clip(u_t - grad, -bound, bound) - u_t)) <= 1e-8
+    # the closed loop starts from the file's state and resets to the file's guess (cold)
+    states, inputs, stats = tight.mpc(2, False, np.zeros((1, NU)), num_dist=0)
+    assert np.array_equal(states[0, 0], ref.simulate_dynamics(param[None], inputs_first(tight, param, guess))[0])
+    tight.close()
+    ref.close()
+
+
+def inputs_first(batch, x0, guess):
+    """First input block of the solve from (x0, guess): what the closed loop applies before step 0."""
+    u, st = batch.solve(x0[None], guess[None])
+    assert st["status"][0] == 1
+    return u[:, :NU]

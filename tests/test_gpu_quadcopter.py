@@ -92,3 +92,36 @@ def test_closed_loop_with_multipliers(warm):
     st_o, in_o, stats_o = ob.quad_mpc(problem, N, num_sim, warm)
     assert np.array_equal(states[:, 0], st_o) and np.array_equal(inputs[:, 0], in_o)
     assert [s["iterations"] for s in stats_o] == stats["iterations"][:, 0].tolist()
+
+
+def test_config3_realistic_quadcopter_horizon_60():
+    """BASELINE.json configs[2] at its stated size: realistic_quadcopter N=60 (n=240, m=244, 64 KB of
+    LDS per instance), all 60 warm + 60 cold time steps (dodo.py:10,70,96-105).  The device closed
+    loops equal the oracle's step for step, and the 120 recorded steps replayed as ONE batch (the
+    form bench.py measures) reproduce u, y and every counter of the oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+    problem, N, num_sim = "realistic_quadcopter", 60, 60
+    keys = ("iterations", "outer_iterations", "cg_iterations", "n_hess_psi_prod", "n_psi", "n_psi_grad_psi",
+            "n_grad_L", "inner_convergence_failures")
+    with ThreadPoolExecutor(2) as ex:   # the oracle's two closed loops run beside the device's
+        fut = {w: ex.submit(ob.quad_mpc_full, problem, N, num_sim, w) for w in (True, False)}
+        b = pa.PantrBatch(problem, N, 2 * num_sim, opts=quad_opts(problem))
+        assert (b.n, b.m) == (240, 244) and b.footprint()[0] > 64 * 1024
+        dev = {w: b.mpc(num_sim, w, np.zeros((1, 4)), num_dist=0) for w in (True, False)}
+        orc = {w: fut[w].result() for w in (True, False)}
+    for warm in (True, False):
+        states, inputs, stats = dev[warm]
+        o = orc[warm]
+        assert np.array_equal(states[:, 0], o["states"]) and np.array_equal(inputs[:, 0], o["inputs"])
+        assert np.all(stats["status"][:, 0] == 1) and all(s["status"] == 1 for s in o["stats"])
+        for k in keys:
+            assert stats[k][:, 0].tolist() == [s[k] for s in o["stats"]], (warm, k)
+        assert np.all(stats["eps"] <= 1e-8) and np.all(stats["delta"] <= 1e-8)
+    cat = lambda k: np.vstack([orc[True][k], orc[False][k]])
+    u, y, st = b.solve_al(cat("states")[np.r_[0:num_sim, num_sim + 1:2 * num_sim + 1]], cat("guess_u"), cat("guess_y"))
+    b.close()
+    assert np.array_equal(u, cat("inputs")) and np.array_equal(y, cat("multipliers"))
+    stats_o = orc[True]["stats"] + orc[False]["stats"]
+    for k in keys + ("status",):
+        assert st[k].tolist() == [s[k] for s in stats_o], k
+    assert st["eps"].tolist() == [s["eps"] for s in stats_o] and st["delta"].tolist() == [s["delta"] for s in stats_o]

@@ -37,8 +37,9 @@ def test_stats_struct_layout():
         decl = decl.strip()
         if decl:
             names += [x.strip() for x in decl.split(None, 1)[1].split(",")]
+    names = [x.split('[')[0] for x in names]   # phase_s[4]
     assert tuple(names) == pa.STATS_DTYPE.names
-    assert pa.STATS_DTYPE.itemsize == 6 * 8 + 14 * 4 + 2 * 8 + 6 * 4 + 8
+    assert pa.STATS_DTYPE.itemsize == 6 * 8 + 14 * 4 + 2 * 8 + 6 * 4 + 8 + 4 * 8
 
 
 def test_driver_defaults_and_dodo_options():
@@ -180,3 +181,102 @@ def test_dodo_enumeration():
     assert "solver.radius_factor_good=10" in t["argv"] and "alm.max_time=30s" in t["argv"]
     q = workloads.dodo_pantr_tasks("realistic_quadcopter")[0]["argv"]
     assert q.index("accel.tol_scale=1") > q.index("accel.tol_scale=1e-2")  # later option overrides
+
+
+# ---- the data half of the problem-side boundary (sidecar files) -----------------------------------
+def test_problem_defaults_match_the_reference_models():
+    """Compiled-in data against problems/problems/hanging_chain.cpp:107-135 and quadcopter.py:55-111."""
+    import oracle_binding as ob
+    assert pa.problem_dims("hanging_chain", 60) == (180, 0, 57, 3, 0, 0)
+    assert pa.problem_dims("dl:realistic_quadcopter", 60) == (240, 244, 9, 4, 4, 4)
+    d = pa.problem_defaults("hanging_chain", 7)
+    assert np.all(d["C_lb"] == -1) and np.all(d["C_ub"] == 1) and np.all(d["guess"] == 0)
+    assert np.array_equal(d["param"], ob.initial_state())
+    q = pa.problem_defaults("quadcopter", 5)
+    assert np.array_equal(q["C_lb"][:4], [0, -0.1, -0.1, -0.1]) and np.array_equal(q["C_ub"][:4], [9.81 * 5, 0.1, 0.1, 0.1])
+    assert q["D_lb"][3] == -np.inf and q["D_ub"][2] == np.inf and q["D_lb"].shape == (24,)
+    assert np.array_equal(q["param"], ob.quad_initial_state()) and np.array_equal(q["guess"], ob.quad_initial_guess(5))
+    with pytest.raises(pa.PantrError):
+        pa.problem_dims("lasso", 5)
+
+
+@pytest.mark.parametrize("problem,N", [("hanging_chain", 12), ("quadcopter", 7)])
+def test_sidecar_files_round_trip(tmp_path, problem, N):
+    """Files in the layout of generate_problem.py:62-73 (incl. inf bounds and the empty rows of a
+    problem without constraints) are read back exactly; modified data are honoured."""
+    n, m, nx, nu = pa.problem_dims(problem, N)[:4]
+    stem = pa.write_problem_files(str(tmp_path), problem, "ss2p", N)
+    assert os.path.exists(stem + ".csv") and os.path.exists(stem + ".guess.csv")
+    assert len(open(stem + ".csv").read().split("\n")) == 8          # seven rows + final newline
+    d, ref = pa.load_problem_files(os.path.join(str(tmp_path), problem), "ss2p", N), pa.problem_defaults(problem, N)
+    assert d["has_csv"] and d["penalty_alm_split"] == m               # generate_problem.py:32
+    for k in ref:
+        assert np.array_equal(d[k], ref[k]), k
+    rng = np.random.default_rng(5)
+    mod = dict(C_lb=np.tile(-rng.uniform(0.2, 0.9, nu), N), C_ub=np.tile(rng.uniform(0.2, 0.9, nu), N),
+               param=rng.standard_normal(nx), guess=rng.standard_normal(n), penalty_alm_split=0)
+    pa.write_problem_files(str(tmp_path), problem, "ss2p", N, mod)
+    d = pa.load_problem_files(os.path.join(str(tmp_path), problem), "ss2p", N)
+    for k in ("C_lb", "C_ub", "param", "guess"):
+        assert np.array_equal(d[k], mod[k]), k
+    assert d["penalty_alm_split"] == 0 and np.array_equal(d["D_lb"], ref["D_lb"])
+    # only the guess file (alpaqa loads the .csv only when it exists): compiled-in bounds and state
+    os.remove(stem + ".csv")
+    d = pa.load_problem_files(os.path.join(str(tmp_path), problem), "ss2p", N)
+    assert not d["has_csv"] and np.array_equal(d["guess"], mod["guess"]) and np.array_equal(d["C_lb"], ref["C_lb"])
+
+
+def test_sidecar_files_fail_loudly(tmp_path):
+    problem, N, d = "quadcopter", 6, str(tmp_path)
+    path = os.path.join(d, problem)
+    with pytest.raises(pa.PantrError, match="Failed to open guess file"):   # casadi-dll-wrapper.cpp:58-59
+        pa.load_problem_files(path, "ss2p", N)
+    pa.write_problem_files(d, problem, "ss2p", N)
+    pa.load_problem_files(path, "ss2p", N)
+    with pytest.raises(pa.PantrError, match="Failed to open guess file"):   # another horizon: other files
+        pa.load_problem_files(path, "ss2p", N + 1)
+    with pytest.raises(pa.PantrError, match="not available"):
+        pa.load_problem_files(path, "ms2p", N)
+    ref = pa.problem_defaults(problem, N)
+    bad = {
+        "needs 24": dict(guess=np.zeros(20)),                                  # n = 4 N
+        "box C \\(lower\\) has": dict(C_lb=ref["C_lb"][:-1]),
+        "param \\(the initial state\\) has": dict(param=np.zeros(8)),
+        "not the stage box tiled": dict(C_ub=np.r_[ref["C_ub"][:-1], 0.05]),
+        "box D .* not the stage box tiled": dict(D_lb=np.r_[ref["D_lb"][:-1], -1.0]),
+        "box C is empty": dict(C_lb=np.tile([0, 0.2, -0.1, -0.1], N)),
+        "l1 regularisation": dict(l1_reg=[0.5]),
+        "penalty_alm_split exceeds": dict(penalty_alm_split=1000),
+    }
+    for msg, mod in bad.items():
+        pa.write_problem_files(d, problem, "ss2p", N, mod)
+        with pytest.raises(pa.PantrError, match=msg):
+            pa.load_problem_files(path, "ss2p", N)
+    pa.write_problem_files(d, problem, "ss2p", N)
+    with open(os.path.join(d, f"{problem}_ss2p_{N}.guess.csv"), "w") as f:
+        f.write("1.0,abc\n28\n")
+    with pytest.raises(pa.PantrError, match="cannot parse 'abc'"):
+        pa.load_problem_files(path, "ss2p", N)
+    # a problem this library has no device code for
+    for ext in (".csv", ".guess.csv"):
+        os.replace(os.path.join(d, f"{problem}_ss2p_{N}{ext}"), os.path.join(d, f"lasso_ss2p_{N}{ext}"))
+    with open(os.path.join(d, f"lasso_ss2p_{N}.guess.csv"), "w") as f:
+        f.write("0\n0\n")
+    with pytest.raises(pa.PantrError, match="unknown problem 'lasso'"):
+        pa.load_problem_files(os.path.join(d, "lasso"), "ss2p", N)
+
+
+def test_eval_wrappers_validate_shapes():
+    """A 1-D x0 must not be read as a batch of nx instances (no device call is reached)."""
+    class Dummy(pa.PantrBatch):
+        def __init__(self):
+            self._h, self.n, self.m, self.nx, self.nu = None, 9, 0, 57, 3
+    b = Dummy()
+    with pytest.raises(ValueError):
+        b.eval_psi(np.zeros(57), np.zeros(9))
+    with pytest.raises(ValueError):
+        b.eval_psi_grad_psi(np.zeros((2, 57)), np.zeros((2, 8)))
+    with pytest.raises(ValueError):
+        b.simulate_dynamics(np.zeros((2, 57)), np.zeros((2, 2)))
+    with pytest.raises(ValueError):
+        b.eval_prox_grad_step(1.0, np.zeros((1, 9)), np.zeros((1, 57)))
