@@ -775,7 +775,7 @@ namespace pantr {
 // ---------------------------------------------------------------------------------------
 // Stand-alone problem-function kernels for the scalar AL problems (row-level parity tests)
 // ---------------------------------------------------------------------------------------
-enum AlmEvalMode : int32_t { ALM_EVAL_PSI_GRAD = 0, ALM_EVAL_HESS_PROD = 1, ALM_EVAL_GRAD_L = 2 };
+enum AlmEvalMode : int32_t { ALM_EVAL_PSI_GRAD = 0, ALM_EVAL_HESS_PROD = 1, ALM_EVAL_GRAD_L = 2, ALM_EVAL_PROX = 3 };
 
 struct AlmEvalArgs {
     int32_t B, N, n, npad, nj, m, mpad, mj, mode, reps; ///< reps: development aid (timing), normally 1
@@ -788,6 +788,9 @@ struct AlmEvalArgs {
     double *out_v;     ///< [B][n] grad | Hv
     double *out_m;     ///< [B][m] yhat
     double *ws;        ///< [B][ScalarALProblem::workspace_doubles(N)]
+    double *out_v2;    ///< [B][n] PROX: p
+    double *out_s4;    ///< [B][4] PROX: p'p, grad'p, ||Pi_C(x - grad) - x||_inf, |J(gamma)|
+    double gamma;      ///< PROX: step size (u = x, v = grad)
     BoxData box;
 };
 
@@ -829,6 +832,20 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
         pb.eval_grad_xhat(u, o, 0);
         for (int j = lane; j < a.m; j += WAVE)
             a.out_m[(size_t)inst * a.m + j] = pb.mvec(PB::MV_YH)[j];
+    } else if (a.mode == ALM_EVAL_PROX) {
+        double pTp, gTp;
+        double *p = pb.vec(3);
+        pb.prox_grad_step(a.gamma, u, v, o, p, pTp, gTp);
+        const double eps = pb.proj_grad_unit_norm(u, v);
+        int nJ;
+        pb.inactive_mask(a.gamma, u, v, nJ);
+        wave_sync();
+        for (int i = lane; i < a.n; i += WAVE)
+            a.out_v2[(size_t)inst * a.n + i] = p[i];
+        if (lane == 0) {
+            double *os = a.out_s4 + (size_t)inst * 4;
+            os[0] = pTp; os[1] = gTp; os[2] = eps; os[3] = nJ;
+        }
     } else if (a.mode == ALM_EVAL_GRAD_L) {
         // grad_x L(x, y) = grad f + grad g' y (formulation.hpp:98,170-174): the trajectory at u, then
         // the adjoint sweep with the caller's y as the multipliers (Sigma plays no role)

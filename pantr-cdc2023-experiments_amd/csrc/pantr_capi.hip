@@ -338,10 +338,33 @@ int run_eval(pantr_batch *b, int32_t B, int mode, double gamma, const double *x0
              const double *v, double *out_s, double *out_v, double *out_v2) {
     if (int rc = check_batch(b, B))
         return rc;
-    if (b->al())
+    if (b->al() && mode != EVAL_PROX)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "this problem has general constraints: use the *_al evaluation entry points");
     HIP_TRY(hipSetDevice(b->device));
     const size_t nb = (size_t)B * b->n * sizeof(double);
+    if (b->al()) { // the prox step of a problem with general constraints: same box code, nu of that model
+        HIP_TRY(hipMemcpy(b->d_u, u, nb, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_v, v, nb, hipMemcpyHostToDevice));
+        AlmEvalArgs a{};
+        a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj; a.m = 0; a.mpad = b->mpad; a.mj = 0;
+        a.mode = ALM_EVAL_PROX; a.x0 = b->d_x0; a.u = b->d_u; a.v = b->d_v; a.y = b->d_y; a.Sig = b->d_sig;
+        a.out_s = b->d_s; a.out_v = b->d_o1; a.out_m = b->d_om; a.ws = b->d_ws; a.reps = 1;
+        a.out_v2 = b->d_o2; a.out_s4 = b->d_s; a.gamma = gamma; a.box = b->box;
+        with_quad_model(b, [&](auto model) {
+            using M = decltype(model);
+            hipLaunchKernelGGL(pantr_alm_eval_kernel<M>, dim3(B), dim3(WAVE), b->lds_bytes, 0, a);
+            return 0;
+        });
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        if (out_s)
+            HIP_TRY(hipMemcpy(out_s, b->d_s, (size_t)B * 4 * sizeof(double), hipMemcpyDeviceToHost));
+        if (out_v)
+            HIP_TRY(hipMemcpy(out_v, b->d_o1, nb, hipMemcpyDeviceToHost));
+        if (out_v2)
+            HIP_TRY(hipMemcpy(out_v2, b->d_o2, nb, hipMemcpyDeviceToHost));
+        return PANTR_OK;
+    }
     if (x0)
         HIP_TRY(hipMemcpy(b->d_x0, x0, (size_t)B * b->nx * sizeof(double), hipMemcpyHostToDevice));
     else
@@ -391,11 +414,24 @@ int pantr_device_count(void) {
 
 // ---- achievable HBM bandwidth (the yardstick next to the 8 TB/s spec peak) --------
 namespace {
-/// 16 bytes per lane per access, grid-stride: dst[i] = src[i].
+/// 16 bytes per lane per access, four independent accesses in flight per lane, grid-stride,
+/// streaming (non-temporal) loads and stores: dst[i] = src[i].
 __global__ __launch_bounds__(256) void copy16_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst,
                                                      size_t count) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < count; i += 4 * stride) {
+        double2 a, b, c, d;
+        a.x = __builtin_nontemporal_load(&src[i].x);              a.y = __builtin_nontemporal_load(&src[i].y);
+        b.x = __builtin_nontemporal_load(&src[i + stride].x);     b.y = __builtin_nontemporal_load(&src[i + stride].y);
+        c.x = __builtin_nontemporal_load(&src[i + 2 * stride].x); c.y = __builtin_nontemporal_load(&src[i + 2 * stride].y);
+        d.x = __builtin_nontemporal_load(&src[i + 3 * stride].x); d.y = __builtin_nontemporal_load(&src[i + 3 * stride].y);
+        __builtin_nontemporal_store(a.x, &dst[i].x);              __builtin_nontemporal_store(a.y, &dst[i].y);
+        __builtin_nontemporal_store(b.x, &dst[i + stride].x);     __builtin_nontemporal_store(b.y, &dst[i + stride].y);
+        __builtin_nontemporal_store(c.x, &dst[i + 2 * stride].x); __builtin_nontemporal_store(c.y, &dst[i + 2 * stride].y);
+        __builtin_nontemporal_store(d.x, &dst[i + 3 * stride].x); __builtin_nontemporal_store(d.y, &dst[i + 3 * stride].y);
+    }
+    for (; i < count; i += stride)
         dst[i] = src[i];
 }
 } // namespace
@@ -421,7 +457,7 @@ int pantr_device_copy_bandwidth(int32_t device, int64_t bytes, int32_t reps, dou
     float best_ms = 0;
     for (int r = 0; e == hipSuccess && r < reps + 1; ++r) { // first pass untimed (page faults, clocks)
         (void)hipEventRecord(e0, nullptr);
-        hipLaunchKernelGGL(copy16_kernel, dim3(256 * 16), dim3(256), 0, nullptr, src, dst, count);
+        hipLaunchKernelGGL(copy16_kernel, dim3(256 * 8), dim3(256), 0, nullptr, src, dst, count);
         (void)hipEventRecord(e1, nullptr);
         e = hipEventSynchronize(e1);
         float ms = 0;
