@@ -187,14 +187,15 @@ struct QuadcopterT {
             // a = c1 u1 + s1 u3 ; cc = (c1 u3 - s1 u1)/c0 ; b = u2 - s0 cc
             const T ka = kb[6], kb_ = kb[7], kc = kb[8];
             const T num = (t.c1 * u[3]) - (t.s1 * u[1]);
-            const T cc  = num / t.c0;
+            const T ic  = 1.0 / t.c0;          // one reciprocal serves the three quotients by cos(phi)
+            const T cc  = num * ic;
             const T kcc = kc - (t.s0 * kb_);   // total adjoint of cc
-            const T q   = kcc / t.c0;          // adjoint of num
+            const T q   = kcc * ic;            // adjoint of num
             ub[1] = (t.c1 * ka) - (t.s1 * q);
             ub[2] = kb_;
             ub[3] = (t.s1 * ka) + (t.c1 * q);
             // d/dphi (s[6]): b -> -c0 cc kb_ ; cc = num/c0 -> num s0/c0^2 = cc s0/c0
-            sb[6] = sb[6] + (((cc * t.s0) / t.c0) * kcc - ((t.c0 * cc) * kb_));
+            sb[6] = sb[6] + ((((cc * t.s0) * ic) * kcc) - ((t.c0 * cc) * kb_));
             // d/dtheta (s[7]): a -> (-s1 u1 + c1 u3) ka = num ka ; num -> (-s1 u3 - c1 u1) q
             sb[7] = sb[7] + ((num * ka) - (((t.s1 * u[3]) + (t.c1 * u[1])) * q));
         }

@@ -16,6 +16,7 @@
 // lane l owning component l, streamed from the HBM tape one stage ahead of the arithmetic.
 #pragma once
 #include "pantr_kernel.hip.h"
+#include <type_traits>
 
 namespace pantr {
 
@@ -53,7 +54,8 @@ struct ScalarALProblem {
     double x0[nx];
     double *mv;  ///< m-vectors: y, Sigma, e1, e2, yh0, yh1, yh2, y/Sigma, mpad doubles each
     double *X;   ///< LDS: primal trajectory (N+1) x nx
-    double *Xt;  ///< LDS: tangent trajectory (N+1) x nx
+    double *Xt;  ///< LDS: tangent trajectory (N+1) x nx of a product | adjoints lam_k while the tape is recorded
+    double2 *TG; ///< LDS: trig store, 12 (sin, cos) pairs per stage (QuadModelT::trig_load)
     double *tape; ///< HBM: this instance's second-order tape (see workspace_doubles)
     enum { MV_Y = 0, MV_SIG = 1, MV_E1 = 2, MV_E2 = 3, MV_YH = 4, MV_YS = 7, MV_COUNT = 8 };
 
@@ -66,10 +68,13 @@ struct ScalarALProblem {
     __host__ __device__ static size_t workspace_doubles(int N) { return (size_t)N * STAGE + BLOCK; }
     __device__ static __forceinline__ int elem(int r, int e) { return ((e >> 1) * ROW + r) * 2 + (e & 1); }
 
+    static constexpr int CG_BASE = NUM_ITER_VEC; ///< all 20 vectors in LDS: iterates first, then the CG block
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
+    __device__ __forceinline__ double *ivec(int slot) const { return lds + slot * npad; }
     __device__ __forceinline__ double *mvec(int slot) const { return mv + slot * mpad; }
     __host__ __device__ static size_t lds_doubles(int N, int npad, int mpad) {
-        return (size_t)NUM_VEC * npad + (size_t)MV_COUNT * mpad + (size_t)2 * (N + 1) * nx;
+        return (size_t)NUM_VEC * npad + (size_t)MV_COUNT * mpad + (size_t)2 * (N + 1) * nx +
+               (size_t)(N + 1) * M::TRIG_DOUBLES_PER_STAGE;
     }
 
     __device__ __forceinline__ void load_u(const double *u, const double *, int k, double (&uk)[nu]) const {
@@ -99,84 +104,58 @@ struct ScalarALProblem {
     }
 
     /// One RK4 step.  UNIFORM: the state's values are the same on every lane (Trig by trig_uniform);
-    /// t1 = Trig of s, which the caller usually needs as well.
+    /// t1 = Trig of s, which the caller usually needs as well.  tg (UNIFORM only, may be null): the
+    /// stage's trig store; the values of substages 1..3 are written to tg[3], tg[6], tg[9] ...
     template <bool UNIFORM, class T>
     __device__ __forceinline__ void rk4(const typename M::template Trig<T> &t1, const T (&s)[nx], const T (&u)[nu],
-                                        T (&xn)[nx]) const {
+                                        T (&xn)[nx], double2 *tg = nullptr) const {
         T k1[nx], k2[nx], k3[nx], k4[nx], w[nx];
+        auto trig_sub = [&](int j) {
+            if constexpr (UNIFORM)
+                return M::trig_uniform(w, tg ? tg + 3 * j : nullptr);
+            else
+                return M::trig(w);
+        };
         M::fc(t1, s, u, k1);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             w[l] = madd(M::hTs, k1[l], s[l]);
-        M::fc(M::template trig_of<UNIFORM>(w), w, u, k2);
+        M::fc(trig_sub(1), w, u, k2);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             w[l] = madd(M::hTs, k2[l], s[l]);
-        M::fc(M::template trig_of<UNIFORM>(w), w, u, k3);
+        M::fc(trig_sub(2), w, u, k3);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             w[l] = madd(M::Ts, k3[l], s[l]);
-        M::fc(M::template trig_of<UNIFORM>(w), w, u, k4);
+        M::fc(trig_sub(3), w, u, k4);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             xn[l] = madd(M::c6, madd(2.0, k3[l], madd(2.0, k2[l], k1[l])) + k4[l], s[l]);
     }
-    /// Adjoint of one RK4 step (wave-uniform values).  The Trig of each substage state is evaluated
-    /// once and serves the recomputed forward pass and the adjoint (kept in its compact form in
-    /// between: with dual numbers the full form of three substages would hold 72 VGPRs).  WITH_XN: also returns the
-    /// step itself (x_next), whose tangent parts are a column of the stage Jacobian.
-    template <bool WITH_XN, class T>
-    __device__ __forceinline__ void rk4_adj(const typename M::template Trig<T> &t1, const T (&s)[nx],
-                                            const T (&u)[nu], const T (&mu)[nx], T (&sbar)[nx], T (&ubar)[nu],
-                                            T (&xn)[nx]) const {
-        T k[nx], w2[nx], w3[nx], w4[nx], ksum[nx];
-        M::fc(t1, s, u, k);
+    /// Adjoint of one RK4 step over the stored trigonometric values of its four substage states
+    /// (tg: the stage's entries of the trig store, written by the forward sweep at the same point):
+    /// fc_adj needs only those, the input and the incoming adjoints, so nothing of the forward pass
+    /// is evaluated again.  Values are the same on every lane.
+    __device__ __forceinline__ void rk4_adj_stored(const double2 *tg, const double (&u)[nu], const double (&mu)[nx],
+                                                   double (&sbar)[nx], double (&ubar)[nu]) const {
+        double kb1[nx], kb2[nx], kb3[nx], kb4[nx], a[nx], ua[nu];
 #pragma unroll
         for (int l = 0; l < nx; ++l) {
-            w2[l] = madd(M::hTs, k[l], s[l]);
-            if (WITH_XN)
-                ksum[l] = k[l];
+            double sg = M::c6 * mu[l];
+            kb1[l]    = sg;
+            kb2[l]    = 2.0 * sg;
+            kb3[l]    = 2.0 * sg;
+            kb4[l]    = sg;
+            sbar[l]   = mu[l];
         }
-        const auto c2 = M::trig_seed(w2);
-        M::fc(M::expand(c2), w2, u, k);
-#pragma unroll
-        for (int l = 0; l < nx; ++l) {
-            w3[l] = madd(M::hTs, k[l], s[l]);
-            if (WITH_XN)
-                ksum[l] = madd(2.0, k[l], ksum[l]);
-        }
-        const auto c3 = M::trig_seed(w3);
-        M::fc(M::expand(c3), w3, u, k);
-#pragma unroll
-        for (int l = 0; l < nx; ++l) {
-            w4[l] = madd(M::Ts, k[l], s[l]);
-            if (WITH_XN)
-                ksum[l] = madd(2.0, k[l], ksum[l]);
-        }
-        const auto c4 = M::trig_seed(w4);
-        if (WITH_XN) {
-            M::fc(M::expand(c4), w4, u, k);
-#pragma unroll
-            for (int l = 0; l < nx; ++l)
-                xn[l] = madd(M::c6, ksum[l] + k[l], s[l]);
-        }
-        T kb1[nx], kb2[nx], kb3[nx], kb4[nx], a[nx], ua[nu];
-#pragma unroll
-        for (int l = 0; l < nx; ++l) {
-            T sg    = M::c6 * mu[l];
-            kb1[l]  = sg;
-            kb2[l]  = 2.0 * sg;
-            kb3[l]  = 2.0 * sg;
-            kb4[l]  = sg;
-            sbar[l] = mu[l];
-        }
-        M::fc_adj(M::expand(c4), u, kb4, a, ubar);
+        M::fc_adj(M::trig_load(tg + 9), u, kb4, a, ubar);
 #pragma unroll
         for (int l = 0; l < nx; ++l) {
             sbar[l] = sbar[l] + a[l];
             kb3[l]  = madd(M::Ts, a[l], kb3[l]);
         }
-        M::fc_adj(M::expand(c3), u, kb3, a, ua);
+        M::fc_adj(M::trig_load(tg + 6), u, kb3, a, ua);
 #pragma unroll
         for (int c = 0; c < nu; ++c)
             ubar[c] = ubar[c] + ua[c];
@@ -185,7 +164,92 @@ struct ScalarALProblem {
             sbar[l] = sbar[l] + a[l];
             kb2[l]  = madd(M::hTs, a[l], kb2[l]);
         }
-        M::fc_adj(M::expand(c2), u, kb2, a, ua);
+        M::fc_adj(M::trig_load(tg + 3), u, kb2, a, ua);
+#pragma unroll
+        for (int c = 0; c < nu; ++c)
+            ubar[c] = ubar[c] + ua[c];
+#pragma unroll
+        for (int l = 0; l < nx; ++l) {
+            sbar[l] = sbar[l] + a[l];
+            kb1[l]  = madd(M::hTs, a[l], kb1[l]);
+        }
+        M::fc_adj(M::trig_load(tg), u, kb1, a, ua);
+#pragma unroll
+        for (int c = 0; c < nu; ++c)
+            ubar[c] = ubar[c] + ua[c];
+#pragma unroll
+        for (int l = 0; l < nx; ++l)
+            sbar[l] = sbar[l] + a[l];
+    }
+    /// The same step and its adjoint on dual numbers whose values and tangents differ per lane (one
+    /// (stage, direction) pair per lane): the substage states are rebuilt for their tangents, the
+    /// trigonometric VALUES come from the trig store.  Also returns the step itself (x_next), whose
+    /// tangent parts are a column of the stage Jacobian.
+    __device__ __forceinline__ void rk4_adj_dual(const double2 *tg, const typename M::template Trig<dual> &t1,
+                                                 const dual (&s)[nx], const dual (&u)[nu], const dual (&mu)[nx],
+                                                 dual (&sbar)[nx], dual (&ubar)[nu], dual (&xn)[nx]) const {
+        dual k[nx], ksum[nx];
+        double a2[3], a3[3], a4[3]; // angle tangents of the substage states (all the adjoint needs of them)
+        M::fc(t1, s, u, k);
+        {
+            dual w[nx];
+#pragma unroll
+            for (int l = 0; l < nx; ++l) {
+                w[l]    = madd(M::hTs, k[l], s[l]);
+                ksum[l] = k[l];
+            }
+            a2[0] = w[6].t; a2[1] = w[7].t; a2[2] = w[8].t;
+            M::fc(M::trig_load(tg + 3, a2[0], a2[1], a2[2]), w, u, k);
+        }
+        {
+            dual w[nx];
+#pragma unroll
+            for (int l = 0; l < nx; ++l) {
+                w[l]    = madd(M::hTs, k[l], s[l]);
+                ksum[l] = madd(2.0, k[l], ksum[l]);
+            }
+            a3[0] = w[6].t; a3[1] = w[7].t; a3[2] = w[8].t;
+            M::fc(M::trig_load(tg + 6, a3[0], a3[1], a3[2]), w, u, k);
+        }
+        {
+            dual w[nx];
+#pragma unroll
+            for (int l = 0; l < nx; ++l) {
+                w[l]    = madd(M::Ts, k[l], s[l]);
+                ksum[l] = madd(2.0, k[l], ksum[l]);
+            }
+            a4[0] = w[6].t; a4[1] = w[7].t; a4[2] = w[8].t;
+            M::fc(M::trig_load(tg + 9, a4[0], a4[1], a4[2]), w, u, k);
+#pragma unroll
+            for (int l = 0; l < nx; ++l)
+                xn[l] = madd(M::c6, ksum[l] + k[l], s[l]);
+        }
+        dual kb1[nx], kb2[nx], kb3[nx], kb4[nx], a[nx], ua[nu];
+#pragma unroll
+        for (int l = 0; l < nx; ++l) {
+            dual sg = M::c6 * mu[l];
+            kb1[l]  = sg;
+            kb2[l]  = 2.0 * sg;
+            kb3[l]  = 2.0 * sg;
+            kb4[l]  = sg;
+            sbar[l] = mu[l];
+        }
+        M::fc_adj(M::trig_load(tg + 9, a4[0], a4[1], a4[2]), u, kb4, a, ubar);
+#pragma unroll
+        for (int l = 0; l < nx; ++l) {
+            sbar[l] = sbar[l] + a[l];
+            kb3[l]  = madd(M::Ts, a[l], kb3[l]);
+        }
+        M::fc_adj(M::trig_load(tg + 6, a3[0], a3[1], a3[2]), u, kb3, a, ua);
+#pragma unroll
+        for (int c = 0; c < nu; ++c)
+            ubar[c] = ubar[c] + ua[c];
+#pragma unroll
+        for (int l = 0; l < nx; ++l) {
+            sbar[l] = sbar[l] + a[l];
+            kb2[l]  = madd(M::hTs, a[l], kb2[l]);
+        }
+        M::fc_adj(M::trig_load(tg + 3, a2[0], a2[1], a2[2]), u, kb2, a, ua);
 #pragma unroll
         for (int c = 0; c < nu; ++c)
             ubar[c] = ubar[c] + ua[c];
@@ -203,27 +267,27 @@ struct ScalarALProblem {
             sbar[l] = sbar[l] + a[l];
     }
 
-    /// Forward sweep: psi, trajectory, yhat.
-    template <class T>
-    __device__ __forceinline__ T forward(const double *u, const double *v, double *yh) const {
+    /// Forward sweep: psi, trajectory, yhat, and the trig store of every substage state.
+    __device__ __forceinline__ double forward(const double *u, double *yh) const {
         wave_sync();
         const double *yS = mvec(MV_YS), *Sig = mvec(MV_SIG);
-        T s[nx], xn[nx], c[nc], uk[nu], yhv[nc];
+        double s[nx], xn[nx], c[nc], uk[nu], yhv[nc];
 #pragma unroll
         for (int l = 0; l < nx; ++l)
-            s[l] = T{} + x0[l];
-        T accf = T{}, accal = T{};
+            s[l] = x0[l];
+        double accf = 0.0, accal = 0.0;
         for (int k = 0; k <= N; ++k) {
-            const auto t1 = M::trig_uniform(s);
+            double2 *tg  = TG + 12 * k;
+            const auto t1 = M::trig_uniform(s, tg);
             M::constr(t1, s, c);
 #pragma unroll
             for (int i = 0; i < nc; ++i) {
-                int j  = nc * k + i;
-                T zeta = c[i] + yS[j]; // y / Sigma: set_al()
-                T zhat = tmax(tmin(zeta, box->d_ub[i]), box->d_lb[i]);
-                T d    = zeta - zhat;
-                yhv[i] = Sig[j] * d;
-                accal  = accal + (yhv[i] * d);
+                int j       = nc * k + i;
+                double zeta = c[i] + yS[j]; // y / Sigma: set_al()
+                double zhat = tmax(tmin(zeta, box->d_ub[i]), box->d_lb[i]);
+                double d    = zeta - zhat;
+                yhv[i]      = Sig[j] * d;
+                accal       = accal + (yhv[i] * d);
             }
             store_x(k, s); // one lane-0 block per stage: state row and multiplier estimates
 #pragma unroll
@@ -231,9 +295,9 @@ struct ScalarALProblem {
                 store_yh(yh, nc * k + i, yhv[i]);
             if (k == N)
                 break;
-            load_u(u, v, k, uk);
+            load_u(u, nullptr, k, uk);
             accf = accf + M::stage_cost(s, uk);
-            rk4<true>(t1, s, uk, xn);
+            rk4<true>(t1, s, uk, xn, tg);
 #pragma unroll
             for (int l = 0; l < nx; ++l)
                 s[l] = xn[l];
@@ -242,23 +306,29 @@ struct ScalarALProblem {
         wave_sync();
         return accf + (0.5 * accal);
     }
-    /// Adjoint sweep over the stored trajectory with multipliers yh; OUT(i, value) receives grad_i.
-    template <class T, class OUT>
-    __device__ __forceinline__ void reverse(const double *u, const double *v, const double *yh, OUT &&out) const {
+    /// Adjoint sweep over the stored trajectory and trig store with multipliers yh; OUT(i, value)
+    /// receives grad_i.  STORE_LAM: the adjoints lam_{k+1} every stage receives are kept (rows of LAM,
+    /// which shares the tangent trajectory's LDS) for the second-order recording.
+    template <bool STORE_LAM, class OUT>
+    __device__ __forceinline__ void reverse(const double *u, const double *yh, OUT &&out) const {
         wave_sync();
-        T lam[nx], sbar[nx], ubar[nu], gu[nu], s[nx], uk[nu], yk[nc], xn[nx];
+        double lam[nx], sbar[nx], ubar[nu], gu[nu], s[nx], uk[nu], yk[nc];
 #pragma unroll
         for (int l = 0; l < nx; ++l)
-            lam[l] = T{};
+            lam[l] = 0.0;
         load_x(N, s);
-        M::cost_grad(s, static_cast<const T *>(nullptr), lam, gu);
+        M::cost_grad(s, static_cast<const double *>(nullptr), lam, gu);
         load_yh(yh, N, yk);
-        M::constr_adj(M::trig_uniform(s), s, yk, lam);
+        M::constr_adj(M::trig_load(TG + 12 * N), s, yk, lam);
         for (int k = N - 1; k >= 0; --k) {
+            if (STORE_LAM && lane == 0)
+#pragma unroll
+                for (int l = 0; l < nx; ++l)
+                    Xt[(k + 1) * nx + l] = lam[l];
             load_x(k, s);
-            load_u(u, v, k, uk);
-            const auto t1 = M::trig_uniform(s);
-            rk4_adj<false>(t1, s, uk, lam, sbar, ubar, xn);
+            load_u(u, nullptr, k, uk);
+            const double2 *tg = TG + 12 * k;
+            rk4_adj_stored(tg, uk, lam, sbar, ubar);
 #pragma unroll
             for (int l = 0; l < nx; ++l)
                 lam[l] = sbar[l];
@@ -267,7 +337,7 @@ struct ScalarALProblem {
             for (int c = 0; c < nu; ++c)
                 out(nu * k + c, ubar[c] + gu[c]);
             load_yh(yh, k, yk);
-            M::constr_adj(t1, s, yk, lam);
+            M::constr_adj(M::trig_load(tg), s, yk, lam);
         }
         wave_sync();
     }
@@ -275,15 +345,15 @@ struct ScalarALProblem {
     // ---- the interface pantr_inner() drives ----------------------------------------------------
     __device__ __forceinline__ double eval_psi_grad(const double *u, double *grad) const {
         double *yh = mvec(MV_E2); // scratch (e2 is rewritten at the end of the inner solve)
-        double psi = forward<double>(u, nullptr, yh);
-        reverse<double>(u, nullptr, yh, [&](int i, double g) {
+        double psi = forward(u, yh);
+        reverse<false>(u, yh, [&](int i, double g) {
             if (lane == 0)
                 grad[i] = g;
         });
         return psi;
     }
     __device__ __forceinline__ double eval_psi_xhat(const double *u, int yh_slot) const {
-        return forward<double>(u, nullptr, mvec(MV_YH + yh_slot));
+        return forward(u, mvec(MV_YH + yh_slot));
     }
     /// yhat_k(x_k) on dual numbers (the value part repeats forward()'s arithmetic).
     __device__ __forceinline__ void stage_multipliers(const typename M::template Trig<dual> &t1,
@@ -300,53 +370,64 @@ struct ScalarALProblem {
             yk[i]     = Sig[j] * d;
         }
     }
-    /// grad psi at the point eval_psi_xhat() was last called at (trajectory still stored), and the
-    /// second-order tape there.  The adjoint sweep runs on dual numbers; lane d < nz seeds direction
-    /// e_d of (x_k, u_k), so its tangent parts are column d of J_k and H_k; the value parts are the
-    /// ordinary adjoint sweep on every lane.
-    __device__ __forceinline__ void eval_grad_xhat(const double *u, double *grad, int) const {
-        wave_sync();
-        const bool owner = lane < nz;
-        const int r      = lane & (ROW - 1);
-        double lam[nx];
-        {
+    /// grad psi at the point eval_psi_xhat(., yh_slot) was last called at (trajectory, multiplier
+    /// estimates and trig store still in LDS), and the second-order tape there, in two steps:
+    ///   1. the ordinary adjoint sweep (stage after stage, values the same on every lane): grad and the
+    ///      adjoints lam_{k+1} of every stage;
+    ///   2. the tape: with lam_{k+1} known, the stage Jacobian J_k and Hessian H_k of every stage are
+    ///      independent of each other.  One (stage k, direction d of z = (x_k, u_k)) pair per lane: the
+    ///      stage's step and adjoint on dual numbers seeded with e_d give column d of J_k (tangents of
+    ///      x_next) and of H_k (tangents of the adjoint outputs) - N (nx + nu) independent evaluations,
+    ///      64 at a time, instead of one sweep of N dependent ones.
+    /// The arithmetic of every entry is the one of the sweep it replaces (value parts = step 1).
+    __device__ __forceinline__ void eval_grad_xhat(const double *u, double *grad, int yh_slot) const {
+        reverse<true>(u, mvec(MV_YH + yh_slot), [&](int i, double g) {
+            if (lane == 0)
+                grad[i] = g;
+        });
+        // terminal block: lane d < nx seeds direction e_d of x_N
+        if (lane < nx) {
+            const int d = lane;
             dual s[nx], yk[nc], lt[nx], gu[nu];
 #pragma unroll
             for (int l = 0; l < nx; ++l) {
-                s[l]  = {X[N * nx + l], lane == l ? 1.0 : 0.0};
+                s[l]  = {X[N * nx + l], d == l ? 1.0 : 0.0};
                 lt[l] = dual{};
             }
-            const auto tN = M::trig_uniform(s);
+            const auto tN = M::trig_load(TG + 12 * N, s[6].t, s[7].t, s[8].t);
             stage_multipliers(tN, s, N, yk);
             M::cost_grad(s, static_cast<const dual *>(nullptr), lt, gu);
             M::constr_adj(tN, s, yk, lt);
             double *HN = tape + (size_t)N * STAGE;
 #pragma unroll
-            for (int l = 0; l < nx; ++l) {
-                if (lane < nx)
-                    HN[elem(r, l)] = lt[l].t;
-                lam[l] = lt[l].v;
-            }
+            for (int l = 0; l < nx; ++l)
+                HN[elem(d, l)] = lt[l].t;
         }
-        for (int k = N - 1; k >= 0; --k) {
+        const int tasks = N * nz;
+        for (int base = 0; base < tasks; base += WAVE) {
+            const int task  = base + lane;
+            const bool live = task < tasks;
+            const int tt    = live ? task : tasks - 1; // idle lanes of the last round repeat a task, unstored
+            const int k = tt / nz, d = tt - k * nz;
             dual s[nx], uk[nu], xn[nx], yk[nc], mu[nx], sbar[nx], ubar[nu], gu[nu];
 #pragma unroll
             for (int l = 0; l < nx; ++l) {
-                s[l]  = {X[k * nx + l], lane == l ? 1.0 : 0.0};
-                mu[l] = {lam[l], 0.0};
+                s[l]  = {X[k * nx + l], d == l ? 1.0 : 0.0};
+                mu[l] = {Xt[(k + 1) * nx + l], 0.0}; // lam_{k+1} (reverse<true>)
             }
 #pragma unroll
             for (int c = 0; c < nu; ++c)
-                uk[c] = {u[nu * k + c], lane == nx + c ? 1.0 : 0.0};
-            double *stage = tape + (size_t)k * STAGE;
-            const auto t1 = M::trig_uniform(s);
+                uk[c] = {u[nu * k + c], d == nx + c ? 1.0 : 0.0};
+            const double2 *tg = TG + 12 * k;
+            double *stage     = tape + (size_t)k * STAGE;
+            const auto t1     = M::trig_load(tg, s[6].t, s[7].t, s[8].t);
             stage_multipliers(t1, s, k, yk);
-            rk4_adj<true>(t1, s, uk, mu, sbar, ubar, xn);
-            if (owner) {
+            rk4_adj_dual(tg, t1, s, uk, mu, sbar, ubar, xn);
+            if (live) {
 #pragma unroll
                 for (int i = 0; i < nx; ++i) {
-                    stage[elem(i, lane)]      = xn[i].t; // JT
-                    stage[BLOCK + elem(r, i)] = xn[i].t; // JC
+                    stage[elem(i, d)]         = xn[i].t; // JT
+                    stage[BLOCK + elem(d, i)] = xn[i].t; // JC
                 }
             }
             M::cost_grad(s, uk, sbar, gu);
@@ -354,18 +435,14 @@ struct ScalarALProblem {
 #pragma unroll
             for (int c = 0; c < nu; ++c) {
                 dual g = ubar[c] + gu[c];
-                if (owner)
-                    HC[elem(r, nx + c)] = g.t;
-                if (lane == 0)
-                    grad[nu * k + c] = g.v;
+                if (live)
+                    HC[elem(d, nx + c)] = g.t;
             }
             M::constr_adj(t1, s, yk, sbar);
+            if (live)
 #pragma unroll
-            for (int l = 0; l < nx; ++l) {
-                if (owner)
-                    HC[elem(r, l)] = sbar[l].t;
-                lam[l] = sbar[l].v;
-            }
+                for (int l = 0; l < nx; ++l)
+                    HC[elem(d, l)] = sbar[l].t;
         }
         wave_sync();
         wait_vmem(); // the products read the tape back through global loads
@@ -437,52 +514,71 @@ struct ScalarALProblem {
     /// every component is one Dot4 over its terms in index order.  The quantity each stage hands to
     /// the next (x_t, lam_t: one component per lane) enters the next stage's fmas as a DPP row
     /// broadcast; everything else a stage needs does not depend on the previous stage and is
-    /// loaded ahead: v_k and the stored x_t from LDS, the tape rows of the next DEPTH stages from
-    /// HBM (DEPTH register sets, the stage loops unrolled by DEPTH so that no set is ever copied: a
-    /// copy would make the wavefront wait for the youngest load every stage).
-    static constexpr int DEPTH = 4;
+    /// loaded ahead: v_k and the stored x_t from LDS one stage ahead (two alternating register
+    /// sets), the tape rows from HBM/L2 DF (forward) or DB (backward) stages ahead: that many
+    /// register sets, the stage loops unrolled by the depth so that no set is ever copied (a copy
+    /// would make the wavefront wait for the youngest load every stage).  A stage is ~100 cycles of
+    /// arithmetic and a tape row takes ~1000 cycles to arrive, so the depth is what bounds a
+    /// product; the forward rows are the smaller ones (13 doubles against 22) and get the deeper
+    /// pipeline.
+    static constexpr int DF = 8, DB = 4;
     __device__ __forceinline__ const double *stage_block(int k, int block) const {
         k = k < 0 ? 0 : (k >= N ? N - 1 : k); // clamped: the prefetch runs past the ends
         return tape + (size_t)k * STAGE + block * BLOCK;
     }
     __device__ __forceinline__ void hess_prod(const double *, const double *v, double *Hv) const {
         wave_sync();
-        const int rem = N % DEPTH, Nfull = N - rem; // full groups run branch-free, the rest one by one
+        static_assert(DF % 2 == 0 && DB % 2 == 0, "the LDS register sets alternate inside a group");
         // ---- forward: lane i < nx owns x_t[i] ----
         {
             double xt = 0.0;
-            auto stage = [&](int k, const double (&Arow)[nz]) {
+            auto load_v = [&](int k, double (&vk)[nu]) {
+                k = k >= N ? N - 1 : k;
+#pragma unroll
+                for (int c = 0; c < nu; ++c)
+                    vk[c] = v[nu * k + c];
+            };
+            auto stage = [&](int k, const double (&Arow)[nz], const double (&vk)[nu]) {
                 if (lane < nx)
                     Xt[k * nx + lane] = xt; // for the backward sweep
                 Dot4 acc;
                 add_bcast_all<0>(acc, Arow, xt);
-                add_all<nx, nu>(acc, Arow + nx, v + nu * k);
+                add_all<nx, nu>(acc, Arow + nx, vk);
                 xt = acc.sum();
             };
-            double A[DEPTH][nz];
+            double A[DF][nz], va[nu], vb[nu];
 #pragma unroll
-            for (int j = 0; j < DEPTH; ++j)
+            for (int j = 0; j < DF; ++j)
                 load_row(stage_block(j, 0), A[j]);
-            for (int k0 = 0; k0 < Nfull; k0 += DEPTH) {
+            load_v(0, va);
+            auto group = [&](int k0, auto guarded) { // full groups run branch-free, the last one guarded
 #pragma unroll
-                for (int j = 0; j < DEPTH; ++j) {
-                    stage(k0 + j, A[j]);
-                    load_row(stage_block(k0 + j + DEPTH, 0), A[j]);
+                for (int j = 0; j < DF; ++j) {
+                    const int k = k0 + j;
+                    if (!decltype(guarded)::value || k < N) {
+                        if (j % 2 == 0) {
+                            load_v(k + 1, vb);
+                            stage(k, A[j], va);
+                        } else {
+                            load_v(k + 1, va);
+                            stage(k, A[j], vb);
+                        }
+                    }
+                    load_row(stage_block(k + DF, 0), A[j]);
                 }
-            }
-            for (int k = Nfull; k < N; ++k) {
-                double T[nz];
-                load_row(stage_block(k, 0), T);
-                stage(k, T);
-            }
+            };
+            int k0 = 0;
+            for (; k0 + DF <= N; k0 += DF)
+                group(k0, std::false_type{});
+            if (k0 < N)
+                group(k0, std::true_type{});
             if (lane < nx)
                 Xt[N * nx + lane] = xt;
             wait_vmem(); // the clamped prefetches past the last stage
             wave_sync();
         }
         // ---- backward: lane l < nz owns component l of [lam_t ; Hv_k] ----
-        // z = (x_t of the stage, v_k) does not depend on the previous stage: it is read from LDS one
-        // stage ahead into the other of two register sets
+        // z = (x_t of the stage, v_k) does not depend on the previous stage
         double lt;
         auto load_z = [&](int k, double (&z)[nz]) {
             k = k < 0 ? 0 : k;
@@ -502,11 +598,11 @@ struct ScalarALProblem {
                 Hv[nu * k + (lane - nx)] = w;
             lt = w;
         };
-        double C[DEPTH][nz], Bc[DEPTH][nx];
+        double C[DB][nz], Bc[DB][nx];
 #pragma unroll
-        for (int j = 0; j < DEPTH; ++j) { // the full groups start below the remainder stages
-            load_row(stage_block(Nfull - 1 - j, 2), C[j]);
-            load_row(stage_block(Nfull - 1 - j, 1), Bc[j]);
+        for (int j = 0; j < DB; ++j) {
+            load_row(stage_block(N - 1 - j, 2), C[j]);
+            load_row(stage_block(N - 1 - j, 1), Bc[j]);
         }
         {
             double HN[nx];
@@ -515,30 +611,30 @@ struct ScalarALProblem {
             add_all<0, nx>(acc, HN, Xt + N * nx);
             lt = acc.sum();
         }
-        for (int k = N - 1; k >= Nfull; --k) {
-            double TC[nz], TB[nx], z[nz];
-            load_row(stage_block(k, 2), TC);
-            load_row(stage_block(k, 1), TB);
-            load_z(k, z);
-            stage(k, TC, TB, z);
-        }
-        static_assert(DEPTH % 2 == 0, "the z register sets alternate inside a group");
         double z0[nz], z1[nz];
-        load_z(Nfull - 1, z0);
-        for (int k0 = Nfull - 1; k0 >= 0; k0 -= DEPTH) {
+        load_z(N - 1, z0);
+        auto group = [&](int k0, auto guarded) { // stages k0, k0 - 1, ... k0 - DB + 1
 #pragma unroll
-            for (int j = 0; j < DEPTH; ++j) {
-                if (j % 2 == 0) {
-                    load_z(k0 - j - 1, z1);
-                    stage(k0 - j, C[j], Bc[j], z0);
-                } else {
-                    load_z(k0 - j - 1, z0);
-                    stage(k0 - j, C[j], Bc[j], z1);
+            for (int j = 0; j < DB; ++j) {
+                const int k = k0 - j;
+                if (!decltype(guarded)::value || k >= 0) {
+                    if (j % 2 == 0) {
+                        load_z(k - 1, z1);
+                        stage(k, C[j], Bc[j], z0);
+                    } else {
+                        load_z(k - 1, z0);
+                        stage(k, C[j], Bc[j], z1);
+                    }
                 }
-                load_row(stage_block(k0 - j - DEPTH, 2), C[j]);
-                load_row(stage_block(k0 - j - DEPTH, 1), Bc[j]);
+                load_row(stage_block(k - DB, 2), C[j]);
+                load_row(stage_block(k - DB, 1), Bc[j]);
             }
-        }
+        };
+        int k0 = N - 1;
+        for (; k0 - DB + 1 >= 0; k0 -= DB)
+            group(k0, std::false_type{});
+        if (k0 >= 0)
+            group(k0, std::true_type{});
         wait_vmem(); // the clamped prefetches past the first stage
         wave_sync();
     }
@@ -662,6 +758,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
     pb.mv = lds + (size_t)NUM_VEC * a.npad;
     pb.X  = pb.mv + (size_t)PB::MV_COUNT * a.mpad;
     pb.Xt = pb.X + (size_t)(a.N + 1) * M::nx;
+    pb.TG = reinterpret_cast<double2 *>(pb.Xt + (size_t)(a.N + 1) * M::nx);
     pb.tape = a.ws + (size_t)inst * PB::workspace_doubles(a.N);
 #pragma unroll
     for (int l = 0; l < M::nx; ++l)
@@ -807,6 +904,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
     pb.mv = lds + (size_t)NUM_VEC * a.npad;
     pb.X  = pb.mv + (size_t)PB::MV_COUNT * a.mpad;
     pb.Xt = pb.X + (size_t)(a.N + 1) * M::nx;
+    pb.TG = reinterpret_cast<double2 *>(pb.Xt + (size_t)(a.N + 1) * M::nx);
     pb.tape = a.ws + (size_t)inst * PB::workspace_doubles(a.N);
 #pragma unroll
     for (int l = 0; l < M::nx; ++l)
@@ -850,7 +948,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
         // grad_x L(x, y) = grad f + grad g' y (formulation.hpp:98,170-174): the trajectory at u, then
         // the adjoint sweep with the caller's y as the multipliers (Sigma plays no role)
         pb.eval_psi_xhat(u, 0);
-        pb.template reverse<double>(u, nullptr, pb.mvec(PB::MV_Y), [&](int i, double g) {
+        pb.template reverse<false>(u, pb.mvec(PB::MV_Y), [&](int i, double g) {
             if (lane == 0)
                 o[i] = g;
         });

@@ -55,7 +55,8 @@ struct pantr_batch {
     int32_t N = 0, n = 0, m = 0, nx = 0, nu = 0, nc = 0, nc_N = 0;
     int32_t npad = 0, nj = 0, maxB = 0, device = 0;
     size_t ws_per_instance = 0; ///< doubles
-    size_t lds_bytes       = 0;
+    size_t lds_bytes       = 0; ///< dynamic LDS with all vectors in LDS (scalar models; the comparators on the chain)
+    size_t lds_bytes_pantr = 0; ///< hanging chain, method=pantr: CG block + staging slot only (iterates in HBM)
     SolverOptions opts = SolverOptions::driver_defaults();
     // device memory
     double *d_x0 = nullptr, *d_u = nullptr, *d_v = nullptr, *d_o1 = nullptr, *d_o2 = nullptr,
@@ -312,9 +313,11 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
     a.trace = b->trace_instances > 0 ? b->d_trace : nullptr;
     a.order = b->have_order ? b->d_order : nullptr;
     a.prm   = to_kernel_params(b->opts, b->tick_s, b->box);
+    if (method != 0 && b->lds_bytes + WaveProblem<ChainModel>::tape_lds_bytes() > 160 * 1024)
+        return fail(PANTR_ERR_OUT_OF_RANGE, "horizon too long for method=panoc|strucpanoc: their vectors do not fit the 160 KiB LDS");
     HIP_TRY(hipEventRecord(b->ev_start, stream));
     if (method == 0)
-        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 0>), dim3(B), dim3(WAVE), b->lds_bytes_pantr, stream, a);
     else if (method == 1)
         hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 1>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
     else
@@ -403,6 +406,13 @@ const char *pantr_version(void) {
     return "pantr-mi355x 0.2 (gfx950) +phase-timing";
 #else
     return "pantr-mi355x 0.2 (gfx950)";
+#endif
+}
+const char *pantr_source_hash(void) {
+#ifdef PANTR_SOURCE_HASH
+    return PANTR_SOURCE_HASH;
+#else
+    return "";
 #endif
 }
 int pantr_device_count(void) {
@@ -540,10 +550,11 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
         b->lds_bytes       = ScalarALProblem<QuadModelT<false>>::lds_doubles(b->N, b->npad, b->mpad) * sizeof(double);
     } else {
         b->ws_per_instance = WaveProblem<ChainModel>::workspace_doubles(b->N);
-        b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double); // dynamic part (vectors)
+        b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double); // dynamic part: all vectors (comparators)
+        b->lds_bytes_pantr = (size_t)NUM_CG_VEC * b->npad * sizeof(double);
         static_lds         = WaveProblem<ChainModel>::tape_lds_bytes();
     }
-    if (b->lds_bytes + static_lds > 160 * 1024)
+    if ((b->al() ? b->lds_bytes : b->lds_bytes_pantr) + static_lds > 160 * 1024)
         return fail(PANTR_ERR_OUT_OF_RANGE, "decision vectors do not fit the 160 KiB LDS");
     if (b->al()) {
         for (const void *k : {(const void *)&pantr_alm_kernel<QuadModelT<false>, 0>,
@@ -557,11 +568,13 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
             if (int rc = raise_dynamic_lds(k, b->lds_bytes))
                 return rc;
     } else {
-        for (const void *k : {(const void *)&pantr_solve_kernel<ChainModel, 0>,
-                              (const void *)&pantr_solve_kernel<ChainModel, 1>,
-                              (const void *)&pantr_solve_kernel<ChainModel, 2>})
-            if (int rc = raise_dynamic_lds(k, b->lds_bytes))
-                return rc;
+        if (int rc = raise_dynamic_lds((const void *)&pantr_solve_kernel<ChainModel, 0>, b->lds_bytes_pantr))
+            return rc;
+        if (b->lds_bytes + static_lds <= 160 * 1024) // else the comparators are refused at launch
+            for (const void *k : {(const void *)&pantr_solve_kernel<ChainModel, 1>,
+                                  (const void *)&pantr_solve_kernel<ChainModel, 2>})
+                if (int rc = raise_dynamic_lds(k, b->lds_bytes))
+                    return rc;
         if (int rc = raise_dynamic_lds((const void *)&pantr_eval_kernel<ChainModel>, 4 * (size_t)b->npad * sizeof(double)))
             return rc;
     }
@@ -809,7 +822,11 @@ int pantr_batch_get_param(const pantr_batch_t *b, const char *key, double *value
 int pantr_batch_footprint(const pantr_batch_t *b, int64_t *lds_bytes, int64_t *ws_bytes_per_instance) {
     if (!b)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
-    if (lds_bytes) *lds_bytes = (int64_t)(b->lds_bytes + (b->al() ? 0 : WaveProblem<ChainModel>::tape_lds_bytes()));
+    if (lds_bytes) { // of the solve kernel the handle's current method selects
+        const bool pantr_chain = !b->al() && b->opts.method == host::Method::PANTR;
+        *lds_bytes = (int64_t)((pantr_chain ? b->lds_bytes_pantr : b->lds_bytes) +
+                               (b->al() ? 0 : WaveProblem<ChainModel>::tape_lds_bytes()));
+    }
     if (ws_bytes_per_instance) *ws_bytes_per_instance = (int64_t)(b->ws_per_instance * sizeof(double));
     return PANTR_OK;
 }

@@ -81,11 +81,20 @@ enum Phase : int { PH_DIRECTION = 0, PH_PSI_GRAD = 1, PH_PSI_XHAT = 2, PH_GRAD_X
 
 constexpr int TRACE_COLS = 11;
 constexpr int NUM_VEC    = 20; ///< working vectors of the inner solvers (slots S_* inside them)
+constexpr int NUM_ITER_VEC = 12; ///< three iterates x {x, xhat, grad, p}
+/// PANTR on the hanging chain keeps only the vectors of the trust-region subproblem in LDS (q, Hv,
+/// r_J, z, r, d, Bd, step) plus one staging slot for the decision vector a sweep reads stage by
+/// stage; the three iterates live in HBM/L2 (WaveProblem<M, true>): they are touched by
+/// element-wise passes only, every lane reading and writing its own elements as coalesced
+/// 512-byte rows.  9 slots x 192 doubles + the 10 KiB landing buffers = 23.5 KiB at N = 60 (six
+/// instances per CU) and 37 KiB at N = 120 (four per CU: all 1024 instances of the stress
+/// configuration resident at once); with everything in LDS it was 40 KiB and 70 KiB.
+constexpr int NUM_CG_VEC = 9;
 /// The in/out vector of an inner solve shares the slot of the direction's scratch vector (PANTR:
 /// the CG step; PANOC: unused): it is read before the first and written after the last use of
-/// that scratch.  20 slots x 192 doubles + the 10 KiB landing buffers = 40 KiB at N = 60: four
-/// hanging-chain instances per CU, one per SIMD.
-constexpr int S_XIO      = 19;
+/// that scratch.  Offset inside the CG block (slot PB::CG_BASE + C_XIO).
+constexpr int C_XIO      = 7;
+constexpr int S_XIO      = NUM_ITER_VEC + C_XIO; ///< with all 20 vectors in LDS (PANOC, scalar models)
 
 struct SolveArgs {
     int32_t B, N, n, npad, nj;
@@ -103,13 +112,13 @@ struct SolveArgs {
 // ---------------------------------------------------------------------------------------
 // Wave-cooperative problem functions of the single-shooting problem
 // ---------------------------------------------------------------------------------------
-template <class M>
+template <class M, bool ITER_GLOBAL = false>
 struct WaveProblem {
     using Lane  = typename M::Lane;
     using State = typename M::State;
     const Lane &L;
     const BoxData &box; ///< bounds of the decision variables (kernel argument)
-    double *lds; ///< base of this wavefront's vectors
+    double *lds; ///< base of this wavefront's LDS vectors
     int N, n, npad, nj;
     State x0;       ///< this lane's share of the initial state
     double *X;      ///< global: primal trajectory rows, M::TRAJ_DOUBLES per stage
@@ -121,21 +130,48 @@ struct WaveProblem {
     /// product leaves them there for the next one, so only the first product after a recording
     /// waits for them.
     mutable bool primed = false;
+    double *giter = nullptr; ///< ITER_GLOBAL: this instance's NUM_ITER_VEC iterate vectors in the HBM workspace
 
+    /// LDS vector `slot`; the CG block starts at CG_BASE.
+    static constexpr int CG_BASE   = ITER_GLOBAL ? 0 : NUM_ITER_VEC;
+    static constexpr int LDS_SLOTS = ITER_GLOBAL ? NUM_CG_VEC : NUM_VEC;
+    static constexpr int S_STAGE   = CG_BASE + 8; ///< ITER_GLOBAL: staging copy of a sweep's decision vector
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
+    /// Iterate vector `slot` (0..11): HBM (ITER_GLOBAL) or the first twelve LDS slots.
+    __device__ __forceinline__ double *ivec(int slot) const {
+        if constexpr (ITER_GLOBAL)
+            return giter + (size_t)slot * npad;
+        else
+            return lds + slot * npad;
+    }
+    /// The decision vector of a sweep where the stage loops can read it at LDS latency.
+    __device__ __forceinline__ const double *staged(const double *u) const {
+        if constexpr (!ITER_GLOBAL)
+            return u;
+        double *s = vec(S_STAGE);
+        for (int j = 0; j < nj; ++j) { // each lane copies the elements it owns (and wrote)
+            int i = j * WAVE + L.l;
+            if (i < n)
+                s[i] = u[i];
+        }
+        return s;
+    }
 
     /// Static LDS of a kernel using this problem: the two landing buffers.
     __host__ __device__ static size_t tape_lds_bytes() { return 2 * (size_t)M::LDS_STAGE_BYTES; }
-    /// Doubles of HBM workspace one instance needs: X and Xt rows, the tape, the tangent tape.
+    /// Doubles of HBM workspace one instance needs: X and Xt rows, the tape, the tangent tape, and
+    /// (used by the ITER_GLOBAL layout) the iterate vectors.
     __host__ __device__ static size_t workspace_doubles(int N) {
+        const size_t npad_ = (size_t)((M::nu * N + WAVE - 1) / WAVE) * WAVE;
         return (size_t)(N + 1) * (M::TRAJ_DOUBLES + M::XT_DOUBLES) +
-               (size_t)N * (M::TAPE_D4_PER_STAGE + M::ST_D4_PER_STAGE) * 4;
+               (size_t)N * (M::TAPE_D4_PER_STAGE + M::ST_D4_PER_STAGE) * 4 + NUM_ITER_VEC * npad_;
     }
     __device__ __forceinline__ void bind_workspace(double *ws, int inst) {
-        X    = ws + (size_t)inst * workspace_doubles(N);
-        Xt   = X + (size_t)(N + 1) * M::TRAJ_DOUBLES;
-        tape = reinterpret_cast<double4 *>(Xt + (size_t)(N + 1) * M::XT_DOUBLES);
-        st   = tape + (size_t)N * M::TAPE_D4_PER_STAGE;
+        X     = ws + (size_t)inst * workspace_doubles(N);
+        Xt    = X + (size_t)(N + 1) * M::TRAJ_DOUBLES;
+        tape  = reinterpret_cast<double4 *>(Xt + (size_t)(N + 1) * M::XT_DOUBLES);
+        st    = tape + (size_t)N * M::TAPE_D4_PER_STAGE;
+        giter = reinterpret_cast<double *>(st + (size_t)N * M::ST_D4_PER_STAGE);
     }
 
     // ---- the interface pantr_inner() drives (m = 0: no multipliers) ----------------------------
@@ -150,7 +186,8 @@ struct WaveProblem {
 
     /// psi(u) = sum_k l(x_k,u_k) + l_N(x_N); optionally stores the trajectory.
     template <bool STORE>
-    __device__ __forceinline__ double psi_forward(const double *u) const {
+    __device__ __forceinline__ double psi_forward(const double *u_in) const {
+        const double *u = staged(u_in);
         wave_sync(); // u was written by its owner lanes
         State s = x0, acc{0.0, 0.0};
         for (int k = 0; k < N; ++k) {
@@ -176,7 +213,8 @@ struct WaveProblem {
     }
     /// The adjoint sweep alone, over the trajectory the last psi_forward<true>(u) stored (same u).
     template <bool RECORD = false>
-    __device__ __forceinline__ void grad_reverse(const double *u, double *grad) const {
+    __device__ __forceinline__ void grad_reverse(const double *u_in, double *grad) const {
+        const double *u = staged(u_in);
         wave_sync(); // the sweep below re-reads rows this wavefront has just written
         State lam{0.0, 0.0};
         M::cost_grad_x_add(L, M::traj_load(L, X + (size_t)N * M::TRAJ_DOUBLES), lam);
@@ -399,13 +437,15 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                                                    DeviceStats &st, double *trace, int trace_cap) {
     const int lane = threadIdx.x;
     const int n = pb.n, nj = pb.nj;
-    enum { S_IT0 = 0, S_IT1 = 4, S_IT2 = 8, S_Q = 12, S_WORK = 13, S_RJ = 14, S_Z = 15, S_R = 16,
-           S_D = 17, S_BD = 18, S_STEP = 19 };
+    // iterate vectors (pb.ivec: HBM or LDS, the problem decides) and the CG block in LDS
+    enum { S_IT0 = 0, S_IT1 = 4, S_IT2 = 8, S_Q = PB::CG_BASE + 0, S_WORK = PB::CG_BASE + 1, S_RJ = PB::CG_BASE + 2,
+           S_Z = PB::CG_BASE + 3, S_R = PB::CG_BASE + 4, S_D = PB::CG_BASE + 5, S_BD = PB::CG_BASE + 6,
+           S_STEP = PB::CG_BASE + C_XIO };
     IterateRef curr{S_IT0, 0}, prox{S_IT1, 1}, cand{S_IT2, 2};
-    auto X_  = [&](const IterateRef &it) { return pb.vec(it.base + 0); };
-    auto XH_ = [&](const IterateRef &it) { return pb.vec(it.base + 1); };
-    auto G_  = [&](const IterateRef &it) { return pb.vec(it.base + 2); };
-    auto P_  = [&](const IterateRef &it) { return pb.vec(it.base + 3); };
+    auto X_  = [&](const IterateRef &it) { return pb.ivec(it.base + 0); };
+    auto XH_ = [&](const IterateRef &it) { return pb.ivec(it.base + 1); };
+    auto G_  = [&](const IterateRef &it) { return pb.ivec(it.base + 2); };
+    auto P_  = [&](const IterateRef &it) { return pb.ivec(it.base + 3); };
 
     int status    = Busy;
     double eps_k  = __builtin_nan("");
@@ -485,7 +525,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
         }
         if (which != 0) {
             // did x move at all?  (the previous iterate now sits in cand or prox)
-            const double *xo = pb.vec(which == 1 ? cand.base : prox.base);
+            const double *xo = pb.ivec(which == 1 ? cand.base : prox.base);
             const double *xn = X_(curr);
             bool same = true;
             for (int j = 0; j < nj; ++j) {
@@ -772,7 +812,7 @@ __device__ __forceinline__ InnerResult inner_solve(PB &pb, const KernelParams &P
 // The solve kernel for problems without general constraints (m = 0: ALM = one inner solve)
 // ---------------------------------------------------------------------------------------
 template <class M, int METHOD>
-__global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
+__global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // <= 256 VGPRs: two wavefronts per SIMD
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
@@ -784,14 +824,18 @@ __global__ __launch_bounds__(WAVE) void pantr_solve_kernel(SolveArgs a) {
 
     __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
     __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
-    WaveProblem<M> pb{L, a.prm.box, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
+    using PB = WaveProblem<M, METHOD == 0>; // PANTR: iterates in HBM; the comparators: everything in LDS
+    PB pb{L, a.prm.box, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
     pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
     const int n = a.n, nj = a.nj;
-    for (int i = lane; i < NUM_VEC * a.npad; i += WAVE)
+    for (int i = lane; i < PB::LDS_SLOTS * a.npad; i += WAVE)
         lds[i] = 0.0;
+    if (METHOD == 0)
+        for (int i = lane; i < NUM_ITER_VEC * a.npad; i += WAVE)
+            pb.giter[i] = 0.0;
     wave_sync();
-    double *x_io = pb.vec(S_XIO);
+    double *x_io = pb.vec(PB::CG_BASE + C_XIO);
     for (int j = 0; j < nj; ++j) {
         int i = j * WAVE + lane;
         if (i < n)

@@ -53,43 +53,37 @@ struct QuadModelT {
         sincos_t(s[8], t.s2, t.c2);
         return t;
     }
-    /// The state's values are the same on all 64 lanes (all active): lane j < 3 evaluates angle j,
-    /// the six results are broadcast.  Same routine, same inputs: bit-identical to trig().
-    __device__ static __forceinline__ Trig<double> trig_uniform(double a0, double a1, double a2) {
-        const int lane = threadIdx.x & 63;
+    /// The state's values are the same on all 64 lanes (all active): lane j < 3 of every 16-lane row
+    /// evaluates angle j, the six results are broadcast inside the rows (v_mov_b64_dpp row_newbcast).  Same routine, same inputs: bit-identical to trig().
+    /// `store` (LDS, or nullptr): the three (sin, cos) pairs are also kept for the sweeps that revisit
+    /// this state (the adjoint sweep and the second-order recording read them instead of evaluating
+    /// sin/cos again: TrigStore below).
+    __device__ static __forceinline__ Trig<double> trig_uniform(double a0, double a1, double a2,
+                                                                double2 *store = nullptr) {
+        const int lane = threadIdx.x & 63, j = lane & 15; // lane j of every 16-lane row: angle j
         double sv, cv;
-        sincos_det(lane == 1 ? a1 : lane == 2 ? a2 : a0, sv, cv);
-        return {read_lane<0>(sv), read_lane<0>(cv), read_lane<1>(sv), read_lane<1>(cv), read_lane<2>(sv),
-                read_lane<2>(cv)};
+        sincos_det(j == 1 ? a1 : j == 2 ? a2 : a0, sv, cv);
+        if (store && lane < 3)
+            store[lane] = make_double2(sv, cv);
+        return {row_bcast<0>(sv), row_bcast<0>(cv), row_bcast<1>(sv), row_bcast<1>(cv), row_bcast<2>(sv),
+                row_bcast<2>(cv)};
     }
-    __device__ static __forceinline__ Trig<double> trig_uniform(const double *s) {
-        return trig_uniform(s[6], s[7], s[8]);
+    __device__ static __forceinline__ Trig<double> trig_uniform(const double *s, double2 *store = nullptr) {
+        return trig_uniform(s[6], s[7], s[8], store);
     }
-    /// Dual numbers with wave-uniform values and per-lane tangents.
-    __device__ static __forceinline__ Trig<dual> trig_uniform(const dual *s) {
-        const Trig<double> v = trig_uniform(s[6].v, s[7].v, s[8].v);
-        return {{v.s0, v.c0 * s[6].t}, {v.c0, -(v.s0 * s[6].t)}, {v.s1, v.c1 * s[7].t},
-                {v.c1, -(v.s1 * s[7].t)}, {v.s2, v.c2 * s[8].t}, {v.c2, -(v.s2 * s[8].t)}};
+    /// Trigonometric values of the four Runge-Kutta substage states of every stage, written by the
+    /// forward sweep: entry (4 k + j) holds the three (sin, cos) pairs of substage j of stage k
+    /// (j = 0: the stage state itself; stage N has only j = 0).
+    static constexpr int TRIG_DOUBLES_PER_STAGE = 4 * 3 * 2;
+    __device__ static __forceinline__ Trig<double> trig_load(const double2 *e) {
+        const double2 a = e[0], b = e[1], c = e[2];
+        return {a.x, a.y, b.x, b.y, c.x, c.y};
     }
-    /// Compact form of a Trig that is kept alive across the substages of a Runge-Kutta adjoint: the
-    /// wave-uniform values (scalar registers) and, for dual numbers, the three angle tangents; the
-    /// six tangent parts are rebuilt by expand() where the Trig is used (same products, same bits).
-    struct TrigSeedD {
-        Trig<double> v;
-    };
-    struct TrigSeedT {
-        Trig<double> v;
-        double a0, a1, a2;
-    };
-    __device__ static __forceinline__ TrigSeedD trig_seed(const double *s) { return {trig_uniform(s)}; }
-    __device__ static __forceinline__ TrigSeedT trig_seed(const dual *s) {
-        return {trig_uniform(s[6].v, s[7].v, s[8].v), s[6].t, s[7].t, s[8].t};
-    }
-    __device__ static __forceinline__ Trig<double> expand(const TrigSeedD &c) { return c.v; }
-    __device__ static __forceinline__ Trig<dual> expand(const TrigSeedT &c) {
-        const Trig<double> &v = c.v;
-        return {{v.s0, v.c0 * c.a0}, {v.c0, -(v.s0 * c.a0)}, {v.s1, v.c1 * c.a1},
-                {v.c1, -(v.s1 * c.a1)}, {v.s2, v.c2 * c.a2}, {v.c2, -(v.s2 * c.a2)}};
+    /// Dual numbers from stored values and the three angle tangents (same products as sincos_t(dual)).
+    __device__ static __forceinline__ Trig<dual> trig_load(const double2 *e, double t0, double t1, double t2) {
+        const Trig<double> v = trig_load(e);
+        return {{v.s0, v.c0 * t0}, {v.c0, -(v.s0 * t0)}, {v.s1, v.c1 * t1},
+                {v.c1, -(v.s1 * t1)}, {v.s2, v.c2 * t2}, {v.c2, -(v.s2 * t2)}};
     }
     template <bool UNIFORM, class T>
     __device__ static __forceinline__ Trig<T> trig_of(const T *s) {
@@ -183,14 +177,15 @@ struct QuadModelT {
             // a = c1 u1 + s1 u3 ; cc = (c1 u3 - s1 u1)/c0 ; b = u2 - s0 cc
             const T ka = kb[6], kb_ = kb[7], kc = kb[8];
             const T num = (t.c1 * u[3]) - (t.s1 * u[1]);
-            const T cc  = num / t.c0;
+            const T ic  = 1.0 / t.c0;          // one reciprocal serves the three quotients by cos(phi)
+            const T cc  = num * ic;
             const T kcc = kc - (t.s0 * kb_);   // total adjoint of cc
-            const T q   = kcc / t.c0;          // adjoint of num
+            const T q   = kcc * ic;            // adjoint of num
             ub[1] = (t.c1 * ka) - (t.s1 * q);
             ub[2] = kb_;
             ub[3] = (t.s1 * ka) + (t.c1 * q);
             // d/dphi (s[6]): b -> -c0 cc kb_ ; cc = num/c0 -> num s0/c0^2 = cc s0/c0
-            sb[6] = sb[6] + (((cc * t.s0) / t.c0) * kcc - ((t.c0 * cc) * kb_));
+            sb[6] = sb[6] + ((((cc * t.s0) * ic) * kcc) - ((t.c0 * cc) * kb_));
             // d/dtheta (s[7]): a -> (-s1 u1 + c1 u3) ka = num ka ; num -> (-s1 u3 - c1 u1) q
             sb[7] = sb[7] + ((num * ka) - (((t.s1 * u[3]) + (t.c1 * u[1])) * q));
         }

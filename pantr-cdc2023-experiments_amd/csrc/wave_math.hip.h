@@ -226,6 +226,15 @@ __device__ __forceinline__ double read_lane(double v) {
     return __hiloint2double(hi, lo);
 }
 
+/// The value lane SRC of this lane's 16-lane row holds: one v_mov_b64_dpp row_newbcast (the only DPP
+/// form the 64-bit ALU has), against two v_readlane_b32 + the scalar-to-vector hop of read_lane().
+template <int SRC>
+__device__ __forceinline__ double row_bcast(double v) {
+    static_assert(SRC >= 0 && SRC < 16, "row_newbcast selects a lane of the 16-lane row");
+    long long r = __builtin_amdgcn_update_dpp(0ll, __builtin_bit_cast(long long, v), 0x150 + SRC, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, r);
+}
+
 /// Move a wave-uniform double into scalar registers (lets the compiler branch on SCC).
 __device__ __forceinline__ double uniform(double v) {
     int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));

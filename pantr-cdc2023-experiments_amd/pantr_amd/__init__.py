@@ -93,7 +93,7 @@ EXPORTS = (
     "pantr_batch_footprint", "pantr_batch_eval_grad_L", "pantr_batch_create_from_files",
     "pantr_batch_get_penalty_alm_split", "pantr_problem_data_load", "pantr_problem_data_destroy",
     "pantr_problem_data_get", "pantr_problem_dims", "pantr_problem_defaults", "pantr_batch_eval_g",
-    "pantr_batch_mpc_record", "pantr_device_copy_bandwidth",
+    "pantr_batch_mpc_record", "pantr_device_copy_bandwidth", "pantr_source_hash",
 )
 
 
@@ -125,6 +125,11 @@ def lib():
         pd = C.POINTER(_dbl)
         L.pantr_last_error.restype = cp
         L.pantr_version.restype = cp
+        L.pantr_source_hash.restype = cp
+        built, tree = L.pantr_source_hash().decode(), source_hash()
+        if built != tree and not os.environ.get("PANTR_ALLOW_STALE_LIB"):
+            raise ImportError(f"{LIB_PATH} was built from other kernel sources than this tree's csrc/ "
+                              f"(library {built[:12]}..., tree {tree[:12]}...): run `make -C {PKG_DIR}`")
         L.pantr_params_create.argtypes = [C.POINTER(vp)]
         L.pantr_params_destroy.argtypes = [vp]
         L.pantr_params_destroy.restype = None
@@ -510,16 +515,15 @@ def version():
 
 
 def source_hash():
-    """sha256 over the kernel sources (csrc/, sorted by name): ties a committed profile summary to the
-    code it was taken at (bench.py refuses PMC traffic numbers from another version)."""
+    """sha256 over the kernel sources (csrc/*.h and csrc/*.hip, concatenated in name order; the Makefile
+    compiles the same digest into the library): ties a library, and a committed profile summary, to
+    the code they were made from."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(PKG_DIR, "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".h", ".hip")):
-            h.update(name.encode())
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(f.read())
+    for name in sorted(n for n in os.listdir(d) if n.endswith((".h", ".hip"))):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(f.read())
     return h.hexdigest()
 
 
