@@ -51,7 +51,7 @@ struct ScalarALProblem {
     const BoxData *box; ///< bounds of u (box C) and of the constraints (box D), kernel argument
     double *lds; ///< n-vectors: NUM_VEC slots of npad doubles
     int N, n, npad, nj, m, mpad, mj;
-    double x0[nx];
+    const double *x0; ///< LDS: the initial state (problem parameter) of this instance, nx doubles
     double *mv;  ///< m-vectors: y, Sigma, e1, e2, yh0, yh1, yh2, y/Sigma, mpad doubles each
     double *X;   ///< LDS: primal trajectory (N+1) x nx
     double *Xt;  ///< LDS: tangent trajectory (N+1) x nx of a product | adjoints lam_k while the tape is recorded
@@ -59,22 +59,34 @@ struct ScalarALProblem {
     double *tape; ///< HBM: this instance's second-order tape (see workspace_doubles)
     enum { MV_Y = 0, MV_SIG = 1, MV_E1 = 2, MV_E2 = 3, MV_YH = 4, MV_YS = 7, MV_COUNT = 8 };
 
-    // Second-order tape, per stage three blocks of 16 rows x 16 doubles: JT row i = (dx+_i/dz_d)_d,
-    // JC row d = (dx+_i/dz_d)_i, HC row l = column l of H_k.  After the N stages one block with the
-    // terminal Hessian (row l = column l).  Lane r < 16 reads row r; a block stores element e of
-    // row r at elem(r, e) = pair-major [e/2][r][e%2], so that one 16-byte load per lane covers 256
-    // contiguous bytes across the 16 reading lanes.
-    static constexpr int nz = nx + nu, ROW = 16, BLOCK = 16 * ROW, STAGE = 3 * BLOCK;
-    __host__ __device__ static size_t workspace_doubles(int N) { return (size_t)N * STAGE + BLOCK; }
-    __device__ static __forceinline__ int elem(int r, int e) { return ((e >> 1) * ROW + r) * 2 + (e & 1); }
+    // Second-order tape.  With z = (x_k, u_k) (nz = 13 directions), J[d][i] = d x_{k+1,i} / d z_d and
+    // H[l][d] the stage Hessian (oracle: SingleShootingAL::StageTape), a product needs per stage
+    //   forward : x_t'[i] = sum_{d<13} J[d][i] z_d                               (13 terms per component)
+    //   backward: w[l]    = sum_{t<13} H[l][t] z_t + sum_{i<9} J[l][i] lam_t'[i]  (22 terms, t = 13 + i)
+    // each a Dot4: term t goes to partial t mod 4, result (p0 + p1) + (p2 + p3).  The four partial sums
+    // are the four 16-lane rows of the wavefront: lane (g, c) = 16 g + c owns partial g of component c,
+    // so a stage is 4 (forward) or 6 (backward) fused multiply-adds per lane and one cross-row sum
+    // instead of 13 or 22 multiply-adds on 16 of the 64 lanes.  The tape stores, per stage, what each
+    // lane multiplies by, in lane order:
+    //   FWD block (256 doubles): lane (g, i), j = 0..3: J[g + 4j][i]               (0 beyond the 13 terms)
+    //   BWD block (384 doubles): lane (g, l), j = 0..5: term t = g + 4j: H[l][t] | J[l][t - 13]
+    // and after the N stages the terminal block (256 doubles): lane (g, l), j = 0..2: H_N[l][g + 4j].
+    // Padding entries are zero (the workspace is zero-filled when the handle is created and never
+    // written there): a lane with nothing to add multiplies by 0.
+    static constexpr int nz = nx + nu, ROW = 16, FWD = 4 * WAVE, BWD = 6 * WAVE, STAGE = FWD + BWD, HNB = 4 * WAVE;
+    __host__ __device__ static size_t workspace_doubles(int N) { return (size_t)N * STAGE + HNB; }
+    __device__ static __forceinline__ int fwd_index(int i, int d) { return ((d & 3) * ROW + i) * 4 + (d >> 2); }
+    __device__ static __forceinline__ int bwd_index(int l, int t) { return FWD + ((t & 3) * ROW + l) * 6 + (t >> 2); }
+    __device__ static __forceinline__ int hn_index(int l, int t) { return ((t & 3) * ROW + l) * 4 + (t >> 2); }
 
     static constexpr int CG_BASE = NUM_ITER_VEC; ///< all 20 vectors in LDS: iterates first, then the CG block
+    static constexpr int X0_DOUBLES = 16;        ///< the initial state, at the end of the dynamic LDS
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
     __device__ __forceinline__ double *ivec(int slot) const { return lds + slot * npad; }
     __device__ __forceinline__ double *mvec(int slot) const { return mv + slot * mpad; }
     __host__ __device__ static size_t lds_doubles(int N, int npad, int mpad) {
         return (size_t)NUM_VEC * npad + (size_t)MV_COUNT * mpad + (size_t)2 * (N + 1) * nx +
-               (size_t)(N + 1) * M::TRIG_DOUBLES_PER_STAGE;
+               (size_t)(N + 1) * M::TRIG_DOUBLES_PER_STAGE + X0_DOUBLES;
     }
 
     __device__ __forceinline__ void load_u(const double *u, const double *, int k, double (&uk)[nu]) const {
@@ -398,10 +410,10 @@ struct ScalarALProblem {
             stage_multipliers(tN, s, N, yk);
             M::cost_grad(s, static_cast<const dual *>(nullptr), lt, gu);
             M::constr_adj(tN, s, yk, lt);
-            double *HN = tape + (size_t)N * STAGE;
+            double *HN = tape + (size_t)N * STAGE; // row d of H_N (direction d's column, H_N is symmetric)
 #pragma unroll
             for (int l = 0; l < nx; ++l)
-                HN[elem(d, l)] = lt[l].t;
+                HN[hn_index(d, l)] = lt[l].t;
         }
         const int tasks = N * nz;
         for (int base = 0; base < tasks; base += WAVE) {
@@ -426,145 +438,132 @@ struct ScalarALProblem {
             if (live) {
 #pragma unroll
                 for (int i = 0; i < nx; ++i) {
-                    stage[elem(i, d)]         = xn[i].t; // JT
-                    stage[BLOCK + elem(d, i)] = xn[i].t; // JC
+                    stage[fwd_index(i, d)]      = xn[i].t; // J[d][i]: term d of forward component i
+                    stage[bwd_index(d, nz + i)] = xn[i].t; //          term 13 + i of backward component d
                 }
             }
             M::cost_grad(s, uk, sbar, gu);
-            double *HC = stage + 2 * BLOCK;
 #pragma unroll
             for (int c = 0; c < nu; ++c) {
                 dual g = ubar[c] + gu[c];
                 if (live)
-                    HC[elem(d, nx + c)] = g.t;
+                    stage[bwd_index(d, nx + c)] = g.t; // H[d][9 + c] (row d = direction d's column)
             }
             M::constr_adj(t1, s, yk, sbar);
             if (live)
 #pragma unroll
                 for (int l = 0; l < nx; ++l)
-                    HC[elem(d, l)] = sbar[l].t;
+                    stage[bwd_index(d, l)] = sbar[l].t;
         }
         wave_sync();
         wait_vmem(); // the products read the tape back through global loads
     }
 
-    /// The first CNT elements of this lane's row (lane & 15) of a tape block.  Lanes 16..63 own
-    /// nothing and fetch the same bytes as lanes 0..15 (same cache lines; masking them off would
-    /// put a branch around every group of loads and split the stage bodies into separate
-    /// scheduling regions).
-    template <int CNT>
-    __device__ __forceinline__ void load_row(const double *block, double (&o)[CNT]) const {
-        const double2 *p = reinterpret_cast<const double2 *>(block) + (lane & (ROW - 1));
-#pragma unroll
-        for (int i = 0; i < (CNT + 1) / 2; ++i) {
-            double2 t = p[i * ROW];
-            o[2 * i]  = t.x;
-            if (2 * i + 1 < CNT)
-                o[2 * i + 1] = t.y;
-        }
+    /// acc += (the value lane SRC of this lane's 16-lane row holds in `own`) * coef, the broadcast fused
+    /// into the fma (v_fmac_f64 with a row_newbcast DPP source; the only DPP form the fp64 ALU has).
+    /// FIRST: `own` was written by the instruction just before (DPP reads need two wait states after a
+    /// VALU write; inline asm is outside the compiler's hazard pass).
+    template <int SRC, bool FIRST = false>
+    __device__ static __forceinline__ void fmac_bcast(double &acc, double own, double coef) {
+        if (FIRST)
+            asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                         : "+v"(acc)
+                         : "v"(own), "v"(coef), "n"(SRC));
+        else
+            asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                         : "+v"(acc)
+                         : "v"(own), "v"(coef), "n"(SRC));
     }
-    /// Sum of products in four partial sums (term t goes to partial t mod 4, each an fma chain from
-    /// 0), combined as (p0 + p1) + (p2 + p3): four independent chains keep a lone wavefront's fp64
-    /// pipe busy (a dependent v_fma_f64 costs ~12 cycles, independent ones ~5).
-    struct Dot4 {
-        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-        template <int T>
-        __device__ __forceinline__ double &part() {
-            return (T & 3) == 0 ? p0 : (T & 3) == 1 ? p1 : (T & 3) == 2 ? p2 : p3;
-        }
-        /// term T: a * b
-        template <int T>
-        __device__ __forceinline__ void add(double a, double b) {
-            part<T>() = __builtin_fma(a, b, part<T>());
-        }
-        /// term T: coef * (the value lane SRC of this 16-lane row holds in `own`), the broadcast
-        /// fused into the fma (v_fmac_f64 with a row_newbcast DPP source; the only DPP form the
-        /// fp64 ALU has).  FIRST: `own` was written by the instruction just before (DPP reads need
-        /// two wait states after a VALU write; inline asm is outside the compiler's hazard pass).
-        template <int T, int SRC, bool FIRST = false>
-        __device__ __forceinline__ void add_bcast(double coef, double own) {
-            if (FIRST)
-                asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                             : "+v"(part<T>())
-                             : "v"(own), "v"(coef), "n"(SRC));
-            else
-                asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                             : "+v"(part<T>())
-                             : "v"(own), "v"(coef), "n"(SRC));
-        }
-        __device__ __forceinline__ double sum() const { return (p0 + p1) + (p2 + p3); }
-    };
-    /// acc.add_bcast<T0 + i, i>(coef[i], own) for i = 0..nx-1
-    template <int T0, int I = 0>
-    __device__ static __forceinline__ void add_bcast_all(Dot4 &acc, const double *coef, double own) {
-        if constexpr (I < nx) {
-            acc.template add_bcast<T0 + I, I, I == 0>(coef[I], own);
-            add_bcast_all<T0, I + 1>(acc, coef, own);
-        }
+    /// `src` rotated inside the 16-lane rows selected by ROWMASK (lane m <- lane m - N mod 16, i.e.
+    /// row_ror:N); the other rows keep `old`  (scripts/microbench/dpp_row_rotate_test.hip).
+    template <int N, int ROWMASK>
+    __device__ static __forceinline__ double row_ror_masked(double old, double src) {
+        int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), 0x120 + N, ROWMASK, 0xF, false);
+        int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), 0x120 + N, ROWMASK, 0xF, false);
+        return __hiloint2double(hi, lo);
     }
-    template <int T0, int CNT, int I = 0>
-    __device__ static __forceinline__ void add_all(Dot4 &acc, const double *a, const double *b) {
-        if constexpr (I < CNT) {
-            acc.template add<T0 + I>(a[I], b[I]);
-            add_all<T0, CNT, I + 1>(acc, a, b);
-        }
+    /// (row 0 + row 1) + (row 2 + row 3) of the same lane position, the same bits on all four rows:
+    /// the Dot4 sum (p0 + p1) + (p2 + p3) of partials held one per row.
+    __device__ static __forceinline__ double rows_sum(double v) {
+        double a, b;
+        row_partner<false>(v, a, b); // v_permlane16_swap: a = the even row's value, b = the odd row's
+        v = a + b;
+        row_partner<true>(v, a, b);  // v_permlane32_swap: a = rows 0/1, b = rows 2/3
+        return a + b;
     }
-    /// Hessian-vector product over the tape recorded by eval_grad_xhat(): x_t' = J z forward, then
-    /// [lam_t ; Hv_k] = H z + J' lam_t' backward; lane l (of the first 16-lane row) owns component l,
-    /// every component is one Dot4 over its terms in index order.  The quantity each stage hands to
-    /// the next (x_t, lam_t: one component per lane) enters the next stage's fmas as a DPP row
-    /// broadcast; everything else a stage needs does not depend on the previous stage and is
-    /// loaded ahead: v_k and the stored x_t from LDS one stage ahead (two alternating register
-    /// sets), the tape rows from HBM/L2 DF (forward) or DB (backward) stages ahead: that many
-    /// register sets, the stage loops unrolled by the depth so that no set is ever copied (a copy
-    /// would make the wavefront wait for the youngest load every stage).  A stage is ~100 cycles of
-    /// arithmetic and a tape row takes ~1000 cycles to arrive, so the depth is what bounds a
-    /// product; the forward rows are the smaller ones (13 doubles against 22) and get the deeper
-    /// pipeline.
-    static constexpr int DF = 8, DB = 4;
-    __device__ __forceinline__ const double *stage_block(int k, int block) const {
+
+    /// Hessian-vector product over the tape recorded by eval_grad_xhat() (layout above).  Lane (g, c)
+    /// accumulates partial g of component c; what a stage hands to the next (x_t forward, lam_t
+    /// backward: component c on lane c of every row after the cross-row sum) reaches the multiply-adds
+    /// as DPP row broadcasts: row g needs components g, g + 4, g + 8 of x_t (terms g, g + 4, g + 8) -
+    /// one row-masked rotation per row puts them on lanes 0, 4, 8 of that row, and the lanes in
+    /// between take the v_k entries of the remaining terms from LDS.  Everything else a stage needs
+    /// does not depend on the previous stage and is loaded ahead: LDS operands one stage ahead, the
+    /// tape rows DF / DB stages ahead (32 and 48 bytes per lane and stage, 5 KiB per stage in all:
+    /// the whole wavefront reads contiguous rows).
+    static constexpr int DF = 8, DB = 8;
+    __device__ __forceinline__ const double *stage_rows(int k) const {
         k = k < 0 ? 0 : (k >= N ? N - 1 : k); // clamped: the prefetch runs past the ends
-        return tape + (size_t)k * STAGE + block * BLOCK;
+        return tape + (size_t)k * STAGE;
+    }
+    __device__ __forceinline__ void load_fwd(int k, double (&e)[4]) const {
+        const double2 *p = reinterpret_cast<const double2 *>(stage_rows(k)) + 2 * lane;
+        const double2 a = p[0], b = p[1];
+        e[0] = a.x; e[1] = a.y; e[2] = b.x; e[3] = b.y;
+    }
+    __device__ __forceinline__ void load_bwd(int k, double (&c)[6]) const {
+        const double2 *p = reinterpret_cast<const double2 *>(stage_rows(k) + FWD) + 3 * lane;
+        const double2 a = p[0], b = p[1], d = p[2];
+        c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = d.x; c[5] = d.y;
     }
     __device__ __forceinline__ void hess_prod(const double *, const double *v, double *Hv) const {
         wave_sync();
         static_assert(DF % 2 == 0 && DB % 2 == 0, "the LDS register sets alternate inside a group");
-        // ---- forward: lane i < nx owns x_t[i] ----
+        const int g = lane >> 4, c = lane & (ROW - 1);
+        // ---- forward: x_t' = J z, z = (x_t, v_k); lane (g, i) adds terms g, g + 4, g + 8, (12) ----
         {
-            double xt = 0.0;
-            auto load_v = [&](int k, double (&vk)[nu]) {
+            // the lane whose row_newbcast slot carries a v term: rows 1..3 lane 8 (terms 9..11 = v[0..2]),
+            // row 0 lane 12 (term 12 = v[3])
+            const bool isv = g == 0 ? c == 12 : c == 8;
+            const int vidx = g == 0 ? 3 : g - 1;
+            double y = 0.0; // x_t: component i on lane i of every row
+            auto load_v = [&](int k) {
                 k = k >= N ? N - 1 : k;
-#pragma unroll
-                for (int c = 0; c < nu; ++c)
-                    vk[c] = v[nu * k + c];
+                return v[nu * k + vidx];
             };
-            auto stage = [&](int k, const double (&Arow)[nz], const double (&vk)[nu]) {
+            auto stage = [&](int k, const double (&e)[4], double vv) {
                 if (lane < nx)
-                    Xt[k * nx + lane] = xt; // for the backward sweep
-                Dot4 acc;
-                add_bcast_all<0>(acc, Arow, xt);
-                add_all<nx, nu>(acc, Arow + nx, vk);
-                xt = acc.sum();
+                    Xt[k * nx + lane] = y; // for the backward sweep
+                double R = row_ror_masked<15, 0x2>(y, y);
+                R        = row_ror_masked<14, 0x4>(R, y);
+                R        = row_ror_masked<13, 0x8>(R, y);
+                const double X = isv ? vv : R;
+                double acc = 0.0;
+                fmac_bcast<0, true>(acc, X, e[0]);
+                fmac_bcast<4>(acc, X, e[1]);
+                fmac_bcast<8>(acc, X, e[2]);
+                fmac_bcast<12>(acc, X, e[3]);
+                y = rows_sum(acc);
             };
-            double A[DF][nz], va[nu], vb[nu];
+            double E[DF][4], va, vb;
 #pragma unroll
             for (int j = 0; j < DF; ++j)
-                load_row(stage_block(j, 0), A[j]);
-            load_v(0, va);
+                load_fwd(j, E[j]);
+            va = load_v(0);
             auto group = [&](int k0, auto guarded) { // full groups run branch-free, the last one guarded
 #pragma unroll
                 for (int j = 0; j < DF; ++j) {
                     const int k = k0 + j;
                     if (!decltype(guarded)::value || k < N) {
                         if (j % 2 == 0) {
-                            load_v(k + 1, vb);
-                            stage(k, A[j], va);
+                            vb = load_v(k + 1);
+                            stage(k, E[j], va);
                         } else {
-                            load_v(k + 1, va);
-                            stage(k, A[j], vb);
+                            va = load_v(k + 1);
+                            stage(k, E[j], vb);
                         }
                     }
-                    load_row(stage_block(k + DF, 0), A[j]);
+                    load_fwd(k + DF, E[j]);
                 }
             };
             int k0 = 0;
@@ -573,61 +572,72 @@ struct ScalarALProblem {
             if (k0 < N)
                 group(k0, std::true_type{});
             if (lane < nx)
-                Xt[N * nx + lane] = xt;
+                Xt[N * nx + lane] = y;
             wait_vmem(); // the clamped prefetches past the last stage
             wave_sync();
         }
-        // ---- backward: lane l < nz owns component l of [lam_t ; Hv_k] ----
-        // z = (x_t of the stage, v_k) does not depend on the previous stage
-        double lt;
-        auto load_z = [&](int k, double (&z)[nz]) {
-            k = k < 0 ? 0 : k;
-#pragma unroll
-            for (int d = 0; d < nx; ++d)
-                z[d] = Xt[k * nx + d];
-#pragma unroll
-            for (int c = 0; c < nu; ++c)
-                z[nx + c] = v[nu * k + c];
+        // ---- backward: w = H z + J' lam_t'; lane (g, l) adds terms g + 4 j, j = 0..5 ----
+        // terms t < 13 multiply z_t = (x_t of the stage, v_k)_t: lane-dependent LDS operands, read one
+        // stage ahead; terms t >= 13 multiply lam_t'[t - 13] = the previous stage's w: row broadcasts.
+        // Row 0: terms 0, 4, 8, 12 | 16, 20; rows 1..3: g, g + 4, g + 8 | g + 12, g + 16, (21 for g = 1).
+        const double *z2p = g == 0 ? Xt + 8 : v + (g - 1); // term g + 8: x_t[8] (row 0) or v[g - 1]
+        const int z2s     = g == 0 ? nx : nu;
+        struct Z {
+            double z0, z1, z2, z3;
         };
-        auto stage = [&](int k, const double (&Crow)[nz], const double (&Brow)[nx], const double (&z)[nz]) {
-            Dot4 acc;
-            add_all<0, nz>(acc, Crow, z);
-            add_bcast_all<nz>(acc, Brow, lt);
-            double w = acc.sum();
+        auto load_z = [&](int k) {
+            k = k < 0 ? 0 : k;
+            return Z{Xt[k * nx + g], Xt[k * nx + g + 4], z2p[k * z2s], v[nu * k + 3]};
+        };
+        double w;
+        {
+            // terminal block: lam_t[l] = sum_{t<9} H_N[l][t] x_t(N)[t]
+            const double *hn = tape + (size_t)N * STAGE + 4 * lane;
+            const double2 a = reinterpret_cast<const double2 *>(hn)[0];
+            const double h2 = hn[2];
+            double acc = 0.0;
+            acc = __builtin_fma(a.x, Xt[N * nx + g], acc);
+            acc = __builtin_fma(a.y, Xt[N * nx + g + 4], acc);
+            acc = __builtin_fma(h2, Xt[N * nx + 8], acc); // zero coefficient off row 0
+            w   = rows_sum(acc);
+        }
+        auto stage = [&](int k, const double (&C)[6], const Z &z) {
+            // lanes 0, 4, 8 of row g <- the lam_t' entries of its terms: row 0 w[3], w[7] on lanes 4, 8
+            // (lane 0 takes v_k[3], term 12); row g >= 1: w[g - 1], w[g + 3], w[g + 7] on lanes 0, 4, 8
+            double R = row_ror_masked<1, 0x1>(w, w);
+            R        = row_ror_masked<15, 0x4>(R, w);
+            R        = row_ror_masked<14, 0x8>(R, w);
+            const double X = lane == 0 ? z.z3 : R;
+            double acc = 0.0;
+            acc = __builtin_fma(C[0], z.z0, acc);
+            acc = __builtin_fma(C[1], z.z1, acc);
+            acc = __builtin_fma(C[2], z.z2, acc);
+            fmac_bcast<0, true>(acc, X, C[3]);
+            fmac_bcast<4>(acc, X, C[4]);
+            fmac_bcast<8>(acc, X, C[5]);
+            w = rows_sum(acc);
             if (lane >= nx && lane < nz)
                 Hv[nu * k + (lane - nx)] = w;
-            lt = w;
         };
-        double C[DB][nz], Bc[DB][nx];
+        double Cc[DB][6];
 #pragma unroll
-        for (int j = 0; j < DB; ++j) {
-            load_row(stage_block(N - 1 - j, 2), C[j]);
-            load_row(stage_block(N - 1 - j, 1), Bc[j]);
-        }
-        {
-            double HN[nx];
-            load_row(tape + (size_t)N * STAGE, HN);
-            Dot4 acc;
-            add_all<0, nx>(acc, HN, Xt + N * nx);
-            lt = acc.sum();
-        }
-        double z0[nz], z1[nz];
-        load_z(N - 1, z0);
+        for (int j = 0; j < DB; ++j)
+            load_bwd(N - 1 - j, Cc[j]);
+        Z za = load_z(N - 1), zb;
         auto group = [&](int k0, auto guarded) { // stages k0, k0 - 1, ... k0 - DB + 1
 #pragma unroll
             for (int j = 0; j < DB; ++j) {
                 const int k = k0 - j;
                 if (!decltype(guarded)::value || k >= 0) {
                     if (j % 2 == 0) {
-                        load_z(k - 1, z1);
-                        stage(k, C[j], Bc[j], z0);
+                        zb = load_z(k - 1);
+                        stage(k, Cc[j], za);
                     } else {
-                        load_z(k - 1, z0);
-                        stage(k, C[j], Bc[j], z1);
+                        za = load_z(k - 1);
+                        stage(k, Cc[j], zb);
                     }
                 }
-                load_row(stage_block(k - DB, 2), C[j]);
-                load_row(stage_block(k - DB, 1), Bc[j]);
+                load_bwd(k - DB, Cc[j]);
             }
         };
         int k0 = N - 1;
@@ -760,14 +770,17 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
     pb.Xt = pb.X + (size_t)(a.N + 1) * M::nx;
     pb.TG = reinterpret_cast<double2 *>(pb.Xt + (size_t)(a.N + 1) * M::nx);
     pb.tape = a.ws + (size_t)inst * PB::workspace_doubles(a.N);
-#pragma unroll
-    for (int l = 0; l < M::nx; ++l)
-        pb.x0[l] = a.x0[(size_t)inst * M::nx + l];
     const int n = a.n, m = a.m;
     const size_t total = PB::lds_doubles(a.N, a.npad, a.mpad);
     for (size_t i = lane; i < total; i += WAVE)
         lds[i] = 0.0;
     wave_sync();
+    {
+        double *x0_lds = reinterpret_cast<double *>(pb.TG + 12 * (a.N + 1)); // after the trig store
+        if (lane < M::nx)
+            x0_lds[lane] = a.x0[(size_t)inst * M::nx + lane];
+        pb.x0 = x0_lds;
+    }
     double *x_io = pb.vec(S_XIO), *y = pb.mvec(PB::MV_Y), *Sig = pb.mvec(PB::MV_SIG), *e1 = pb.mvec(PB::MV_E1),
            *e2 = pb.mvec(PB::MV_E2);
     for (int i = lane; i < n; i += WAVE)
@@ -906,13 +919,16 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
     pb.Xt = pb.X + (size_t)(a.N + 1) * M::nx;
     pb.TG = reinterpret_cast<double2 *>(pb.Xt + (size_t)(a.N + 1) * M::nx);
     pb.tape = a.ws + (size_t)inst * PB::workspace_doubles(a.N);
-#pragma unroll
-    for (int l = 0; l < M::nx; ++l)
-        pb.x0[l] = a.x0[(size_t)inst * M::nx + l];
     const size_t total = PB::lds_doubles(a.N, a.npad, a.mpad);
     for (size_t i = lane; i < total; i += WAVE)
         lds[i] = 0.0;
     wave_sync();
+    {
+        double *x0_lds = reinterpret_cast<double *>(pb.TG + 12 * (a.N + 1)); // after the trig store
+        if (lane < M::nx)
+            x0_lds[lane] = a.x0[(size_t)inst * M::nx + lane];
+        pb.x0 = x0_lds;
+    }
     double *u = pb.vec(0), *v = pb.vec(1), *o = pb.vec(2);
     for (int i = lane; i < a.n; i += WAVE) {
         u[i] = a.u[(size_t)inst * a.n + i];

@@ -21,6 +21,7 @@ src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 KERNEL = "pantr_solve_kernel"
+GRID = 600 * 64  # the timed launches: 600 instances, one 64-wide workgroup each
 
 summary = {"tag": tag, "command": "python3 bench.py --steps 3 --warmup 1 --headline-only",
            "kernel": "pantr::pantr_solve_kernel<pantr::ChainModel, 0>",
@@ -34,8 +35,12 @@ for r in csv.DictReader(open(stats)):
                                    "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
                                    "percentage": float(r["Percentage"])}
 trace = newest(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
+durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(trace))
+        if KERNEL in r["Kernel_Name"] and int(r["Grid_Size_X"]) == GRID]
+summary["kernel_trace_timed_launches"] = {"grid_size": GRID, "calls": len(durs), "avg_ms": sum(durs) / max(len(durs), 1),
+                                          "min_ms": min(durs, default=0.0), "max_ms": max(durs, default=0.0)}
 for r in csv.DictReader(open(trace)):
-    if KERNEL in r["Kernel_Name"]:
+    if KERNEL in r["Kernel_Name"] and int(r["Grid_Size_X"]) == GRID:
         summary["dispatch"] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size",
                                                   "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count",
                                                   "SGPR_Count") if k in r}
@@ -47,7 +52,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
         continue
     agg = {}
     for r in csv.DictReader(open(f)):
-        if KERNEL in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"] and int(r.get("Grid_Size", GRID)) == GRID:
             agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for k, v in agg.items():
         pmc[k] = sum(v) / len(v)
