@@ -90,6 +90,22 @@ class TypeErasedProblem {
         pantr_batch_t *h = nullptr;
         check(pantr_batch_create(std::string(name).c_str(), static_cast<int32_t>(horizon), max_instances,
                                  device, &h));
+        adopt(h);
+    }
+    /// load_benchmark_casadi_problem (drivers/casadi-dll-wrapper.cpp:25-67), data half: the problem
+    /// "<dir>/<name>" with the bounds, initial state and initial guess of its sidecar files
+    /// "<dir>/<name>_<formulation>_<N>.csv" / ".guess.csv" in place of the compiled-in values.
+    struct FromFiles {};
+    TypeErasedProblem(FromFiles, const std::string &path, std::string_view formulation, length_t horizon,
+                      int max_instances = 1, int device = 0) {
+        pantr_batch_t *h = nullptr;
+        check(pantr_batch_create_from_files(path.c_str(), std::string(formulation).c_str(),
+                                            static_cast<int32_t>(horizon), max_instances, device, &h));
+        adopt(h);
+    }
+
+  private:
+    void adopt(pantr_batch_t *h) {
         handle.reset(h, pantr_batch_destroy);
         int32_t n_, m_, nx_, nu_, nc_, ncN_;
         check(pantr_batch_dims(h, &n_, &m_, &nx_, &nu_, &nc_, &ncN_));
@@ -98,6 +114,8 @@ class TypeErasedProblem {
         check(pantr_batch_get_initial_state(h, param.data()));
         evaluations = std::make_shared<EvalCounter>();
     }
+
+  public:
     length_t get_n() const { return n; }
     length_t get_m() const { return m; }
     Box get_box_C() const {

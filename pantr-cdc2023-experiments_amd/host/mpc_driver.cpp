@@ -176,11 +176,16 @@ int main(int argc, char *argv[]) try {
     alpaqa::params::set_params(num_sim, "num_sim", extra_opts);
     replay_len = replay ? num_sim : 1;
 
-    // Load the problem (casadi-dll-wrapper.cpp:25-67: "<name>_<formulation>_<N>.so")
-    Problem problem{name, horizon, static_cast<int>(std::max<length_t>(1, replay_len)),
-                    static_cast<int>(device)};
+    // Load the problem (casadi-dll-wrapper.cpp:25-67: "<name>_<formulation>_<N>.so").  The functions are
+    // the library's device code for <name>; the numeric data of the generated problem's sidecar
+    // files (bounds, initial state, initial guess) are used when they lie next to that path.
     fs::path full_path = path.parent_path() / (name + "_" + std::string(formulation) + "_" +
                                                std::to_string(horizon) + ".so");
+    const int instances = static_cast<int>(std::max<length_t>(1, replay_len));
+    Problem problem = fs::exists(fs::path(full_path).replace_extension(".guess.csv"))
+                          ? Problem{Problem::FromFiles{}, path.string(), formulation, horizon, instances,
+                                    static_cast<int>(device)}
+                          : Problem{name, horizon, instances, static_cast<int>(device)};
 
     std::string_view solver_name = "fbetrust"; // mpc-driver.cpp:359
     alpaqa::params::set_params(solver_name, "method", extra_opts);

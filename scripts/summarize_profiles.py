@@ -62,5 +62,18 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         "read_corrected": 2 * pmc["FETCH_SIZE"] * 1024, "write": pmc["WRITE_SIZE"] * 1024,
         "total": (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024,
         "note": "KiB -> bytes; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request)"}
+if "SQ_INSTS_VALU" in pmc and "SQ_WAVE_CYCLES" in pmc and summary.get("kernel_trace_timed_launches", {}).get("avg_ms"):
+    # what actually bounds the kernel: VALU issue of lone wavefronts (MI355X_MICROARCH.md: SQ_WAVE_CYCLES counts
+    # quad-cycles; a 64-wide fp64 / DPP instruction occupies a SIMD for 4 cycles; 256 CUs x 4 SIMDs, 2.4 GHz)
+    ms = summary["kernel_trace_timed_launches"]["avg_ms"]
+    simd_cycles = 1024 * ms * 1e-3 * 2.4e9
+    wave_cycles = 4 * pmc["SQ_WAVE_CYCLES"]
+    summary["valu_issue"] = {
+        "valu_wave_instructions_per_launch": pmc["SQ_INSTS_VALU"],
+        "simd_issue_slots_used_frac": 4 * pmc["SQ_INSTS_VALU"] / simd_cycles,
+        "wave_slot_occupancy_frac": wave_cycles / simd_cycles,
+        "cycles_per_valu_instruction_of_a_wavefront": wave_cycles / pmc["SQ_INSTS_VALU"],
+        "mean_wavefront_ms": wave_cycles / pmc["SQ_WAVES"] / 2.4e9 * 1e3,
+        "note": "one wavefront per instance: the pass lasts as long as its slowest instance, so most SIMD cycles idle"}
 json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))

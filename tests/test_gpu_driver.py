@@ -160,3 +160,28 @@ def test_cpp_facade_eval_functions_match_ctypes_path(tmp_path, problem):
         kkt[1:] = [np.max(np.abs(vv)), np.max(np.abs(y * vv))]
     assert np.allclose(out["kkt"], kkt, rtol=1e-13, atol=0)
     b.close()
+
+
+def test_driver_uses_sidecar_files_next_to_the_problem_path(tmp_path):
+    """benchmark-mpc-driver <dir>/<name> ...: when the generated problem's sidecar files lie in <dir>
+    (generate_problem.py:62-73), their bounds / initial state / initial guess drive the run
+    (casadi-dll-wrapper.cpp:25-67); the closed loop equals the one the Python binding runs from the
+    same files, and the tighter box binds."""
+    N, num_sim = 15, 6
+    d = tmp_path / "problems"
+    d.mkdir()
+    bound = np.tile([0.5, 0.3, 0.6], N)
+    pa.write_problem_files(str(d), "hanging_chain", "ss2p", N, dict(C_lb=-bound, C_ub=bound))
+    name = "run-sidecar"
+    opts = list(pa.DODO_PANTR_OPTS) + list(pa.DODO_HANGING_CHAIN_OPTS)
+    cmd = [DRIVER, str(d / "hanging_chain"), str(N), "ss2p", "method=pantr", f"num_sim={num_sim}",
+           f"results_name={name}", "warm=true"] + opts
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = load_results(str(tmp_path), name)
+    b = pa.PantrBatch(horizon=N, opts=pa.DODO_PANTR_OPTS, files=(str(d / "hanging_chain"), "ss2p"))
+    states, inputs, stats = b.mpc(num_sim, True, np.array([[-1.0, 1.0, 1.0]]), num_dist=5)
+    b.close()
+    assert np.array_equal(res["inputs"].T, inputs[:, 0]) and np.array_equal(res["states"].T, states[:, 0])
+    assert np.all(np.abs(inputs[:, 0]) <= bound) and np.any(np.abs(inputs[:, 0]) == bound)
+    assert np.all(res["runtimes"] > 0)
