@@ -64,11 +64,33 @@ TRACE_COLS = ("eps", "psi", "pnorm", "gamma", "radius", "rho", "q_model", "fbe",
               "cg_its", "accepted")
 
 
+def _host_key():
+    """Identifies the CPU the oracle was built for: it is compiled -march=native, and the
+    built library travels with the repository snapshot to boxes with other CPUs."""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = next((ln for ln in f if ln.startswith("flags")), "")
+    except OSError:
+        flags = ""
+    return hashlib.sha1(flags.encode()).hexdigest()
+
+
 def build(force=False):
     """Compile the oracle with its own Makefile (building the checker is not using it)."""
-    # always through make: a library older than its sources would silently test the wrong arithmetic
+    # always through make: a library older than its sources would silently test the wrong arithmetic;
+    # and rebuilt from scratch when it was built on a host with another instruction set
+    stamp = LIB_PATH + ".host"
+    key = _host_key()
+    try:
+        with open(stamp) as f:
+            force = force or f.read().strip() != key
+    except OSError:
+        force = True
     subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"] + (["-B"] if force else []),
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    with open(stamp, "w") as f:
+        f.write(key)
     return LIB_PATH
 
 
