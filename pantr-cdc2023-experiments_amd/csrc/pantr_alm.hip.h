@@ -874,7 +874,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
         st.inner_convergence_failures = failures;
         st.delta                      = norm_e2;
         st.penalty_norm               = __builtin_sqrt(sq / m);
-        a.stats[inst]                 = st;
+        write_stats(a.stats + inst, st);
     }
 }
 

@@ -78,6 +78,21 @@ struct DeviceStats {
     double phase_s[4];
 };
 enum Phase : int { PH_DIRECTION = 0, PH_PSI_GRAD = 1, PH_PSI_XHAT = 2, PH_GRAD_XHAT = 3 };
+/// Field by field (a struct copy would make the compiler keep the whole record in scratch memory).
+__device__ __forceinline__ void write_stats(DeviceStats *o, const DeviceStats &s) {
+    o->eps = s.eps; o->final_gamma = s.final_gamma; o->final_psi = s.final_psi; o->final_fbe = s.final_fbe;
+    o->final_radius = s.final_radius; o->elapsed_s = s.elapsed_s;
+    o->status = s.status; o->iterations = s.iterations; o->cg_iterations = s.cg_iterations;
+    o->accepted = s.accepted; o->rejected = s.rejected; o->qub_backtracks = s.qub_backtracks;
+    o->n_psi = s.n_psi; o->n_grad_psi = s.n_grad_psi; o->n_psi_grad_psi = s.n_psi_grad_psi;
+    o->n_grad_L = s.n_grad_L; o->n_hess_psi_prod = s.n_hess_psi_prod; o->n_prox_grad_step = s.n_prox_grad_step;
+    o->outer_iterations = s.outer_iterations; o->inner_convergence_failures = s.inner_convergence_failures;
+    o->delta = s.delta; o->penalty_norm = s.penalty_norm;
+    o->linesearch_failures = s.linesearch_failures; o->linesearch_backtracks = s.linesearch_backtracks;
+    o->lbfgs_failures = s.lbfgs_failures; o->lbfgs_rejected = s.lbfgs_rejected;
+    o->tau_1_accepted = s.tau_1_accepted; o->count_tau = s.count_tau; o->sum_tau = s.sum_tau;
+    o->phase_s[0] = s.phase_s[0]; o->phase_s[1] = s.phase_s[1]; o->phase_s[2] = s.phase_s[2]; o->phase_s[3] = s.phase_s[3];
+}
 
 constexpr int TRACE_COLS = 11;
 constexpr int NUM_VEC    = 20; ///< working vectors of the inner solvers (slots S_* inside them)
@@ -864,7 +879,7 @@ __global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // 
         st.elapsed_s    = (double)(wall_clock64() - t_start) * P.tick_s;
         st.outer_iterations = 1;
         st.inner_convergence_failures = r.status == Converged ? 0 : 1;
-        a.stats[inst]   = st;
+        write_stats(a.stats + inst, st);
     }
 }
 
