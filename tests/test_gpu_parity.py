@@ -282,3 +282,22 @@ def inputs_first(batch, x0, guess):
     u, st = batch.solve(x0[None], guess[None])
     assert st["status"][0] == 1
     return u[:, :NU]
+
+
+def test_device_copy_bandwidth_is_plausible():
+    """The measured HBM yardstick bench.py reports next to the 8 TB/s spec peak (16 B/lane device copy)."""
+    gbps = pa.copy_bandwidth(0, nbytes=1 << 30, reps=3)
+    assert 1000.0 < gbps < 8000.0, gbps
+    with pytest.raises(pa.PantrError):
+        pa.copy_bandwidth(0, nbytes=1024, reps=1)
+
+
+def test_solve_device_refuses_pointers_it_cannot_see():
+    """pantr_batch_solve_device checks every buffer with the HIP runtime the library is bound to: host
+    memory (or memory of another runtime, the load-order trap of INTEGRATION.md section 3) is an error,
+    not a fault."""
+    b = pa.PantrBatch("hanging_chain", 5, 1, opts=pa.DODO_PANTR_OPTS)
+    host = np.zeros(64)
+    with pytest.raises(pa.PantrError, match="not device memory"):
+        b.solve_device(1, host.ctypes.data, host.ctypes.data, host.ctypes.data)
+    b.close()

@@ -125,3 +125,20 @@ def test_config3_realistic_quadcopter_horizon_60():
     for k in keys + ("status",):
         assert st[k].tolist() == [s[k] for s in stats_o], k
     assert st["eps"].tolist() == [s["eps"] for s in stats_o] and st["delta"].tolist() == [s["delta"] for s in stats_o]
+
+
+@pytest.mark.parametrize("warm", [True, False])
+def test_closed_loop_records_what_a_replay_needs(warm):
+    """pantr_batch_mpc_record: the guesses every step was solved from and the multipliers it returned equal
+    the oracle's closed loop (mpc-driver.cpp:168-175,192-197), and solving the recorded steps again as
+    one batch reproduces inputs and multipliers (the replay batching bench.py measures)."""
+    problem, N, num_sim = "quadcopter", 12, 8
+    b = pa.PantrBatch(problem, N, num_sim, opts=quad_opts(problem))
+    states, inputs, stats, rec = b.mpc(num_sim, warm, np.zeros((1, 4)), num_dist=0, record=True)
+    o = ob.quad_mpc_full(problem, N, num_sim, warm)
+    assert np.array_equal(rec["guess_u"][:, 0], o["guess_u"]) and np.array_equal(rec["guess_y"][:, 0], o["guess_y"])
+    assert np.array_equal(rec["multipliers"][:, 0], o["multipliers"]) and np.array_equal(inputs[:, 0], o["inputs"])
+    u, y, st = b.solve_al(states[:num_sim, 0], rec["guess_u"][:, 0], rec["guess_y"][:, 0])
+    b.close()
+    assert np.array_equal(u, inputs[:, 0]) and np.array_equal(y, rec["multipliers"][:, 0])
+    assert st["iterations"].tolist() == stats["iterations"][:, 0].tolist()
