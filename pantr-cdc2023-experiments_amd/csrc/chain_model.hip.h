@@ -7,17 +7,21 @@
 //   l, l_N ................ problems/problems/hanging_chain.cpp:127-132
 //   input box ............. problems/problems/hanging_chain.cpp:107-110
 //   initial state ......... problems/problems/hanging_chain.cpp:121-124
-// The reference turns these into straight-line scalar C through CasADi.  Here lane 4p+c
-// (p = 0..9, c = 0..2; lanes 4p+3 and 40..63 idle) owns component c of chain point p: its
-// position and, for the nine free masses p < 9, its velocity.  A lone wavefront pays for every
-// instruction it issues (~5 cycles independent, 8-12 in a dependent fp64 chain, 60 for an LDS
-// crossbar round trip), so the layout minimises instructions:
+// The reference turns these into straight-line scalar C through CasADi.  Here lane 16c+p
+// (c = 0..2: one 16-lane row per component, row 3 idle; p = 0..9, lanes 10..15 of a row idle) owns
+// component c of chain point p: its position and, for the nine free masses p < 9, its velocity.
+// A lone wavefront pays for every instruction it issues (~5 cycles independent, 8-12 in a
+// dependent fp64 chain, 60 for an LDS crossbar round trip), so the layout
+// minimises instructions:
 //   * one instruction handles a component of all ten points,
-//   * the three components of a point sit in one DPP quad: 3-term sums and broadcasts are
-//     quad_perm moves (VALU speed),
-//   * position and velocity of a point share a lane (no shuffle between them),
-//   * the neighbouring point (lane +-4) is four whole-wave DPP shifts by one lane away
-//     (no LDS-crossbar traffic).
+//   * the neighbouring point is the neighbouring lane: one DPP row shift (two v_mov_b32_dpp per
+//     fp64 value; the anchor before point 0 is the zero bound_ctrl supplies),
+//   * the three components of a point sit at one lane position of rows 0..2: a 3-term sum is the
+//     cross-row sum (v_permlane16_swap, v_permlane32_swap), all three components reach every row
+//     with three swaps,
+//   * position and velocity of a point share a lane (no shuffle between them).
+// (Round 1 kept the components in a DPP quad, lane 4p+c, and paid eight moves per neighbour
+// exchange; a substage has two neighbour exchanges and one component gather.)
 // Second-order information (Hessian-vector products): the gradient sweep at the current point
 // records, per RK4 substage and spring, the 3x3 matrices K = dF/dd and M = d(K lF)/dd; a product
 // is then two linear sweeps of a few FMAs per substage over that tape.
@@ -62,9 +66,9 @@ struct ChainModel {
         double xref;       ///< reference position of this component of the end point (1,0,0)
         __device__ explicit Lane(int lane) {
             l      = lane;
-            p      = lane >> 2;
-            c      = lane & 3;
-            active = lane < 4 * NP && c < DIM;
+            p      = lane & 15;
+            c      = lane >> 4;
+            active = p < NP && c < DIM;
             mass   = active && p < NB;
             end    = active && p == NB;
             first  = p == 0;
@@ -86,23 +90,32 @@ struct ChainModel {
     };
 
     // ---- cross-lane ----------------------------------------------------------------------------
-    /// Value of component k of this lane's point (DPP quad_perm broadcast).
-    template <int K>
-    __device__ static __forceinline__ double qb(double v) {
-        constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
-        int lo = __double2loint(v), hi = __double2hiint(v);
-        lo     = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xF, 0xF, true);
-        hi     = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xF, 0xF, true);
-        return __hiloint2double(hi, lo);
+    /// The three components of this lane's point, on every row: v_permlane16_swap pairs rows (0,1)
+    /// and (2,3), v_permlane32_swap pairs (0,2) and (1,3)  (scripts/microbench/dpp_row_rotate_test.hip).
+    struct Comps {
+        double c0, c1, c2;
+    };
+    __device__ static __forceinline__ Comps comps(double v) {
+        double even, odd, c0, c2, c1, c3;
+        row_partner<false>(v, even, odd); // rows 0,1: (row 0, row 1); rows 2,3: (row 2, row 3)
+        row_partner<true>(even, c0, c2);  // row 0's and row 2's value, on all rows
+        row_partner<true>(odd, c1, c3);   // row 1's (and the idle row 3's)
+        return {c0, c1, c2};
     }
-    /// (v0 + v1) + v2 over the three components of this lane's point.
-    __device__ static __forceinline__ double quad_sum(double v) { return (qb<0>(v) + qb<1>(v)) + qb<2>(v); }
-    /// Same component of the previous / next point (0 before point 0; the value after point 9
-    /// is never used).
-    // Four whole-wave DPP shifts by one lane (wave_shr:1 / wave_shl:1, bound_ctrl: lanes shifted
-    // in from outside the wavefront read 0, which is exactly the anchor before point 0).
-    __device__ static __forceinline__ double prev_point(const Lane &, double v) { return wave_shift4<0x138>(v); }
-    __device__ static __forceinline__ double next_point(const Lane &, double v) { return wave_shift4<0x130>(v); }
+    /// (v0 + v1) + v2 over the three components of this lane's point: the cross-row sum
+    /// (row 0 + row 1) + (row 2 + row 3) with the idle row 3 holding 0 (lanes of row 3 contribute
+    /// whatever they hold: the callers keep them at 0).
+    __device__ static __forceinline__ double quad_sum(double v) {
+        double a, b;
+        row_partner<false>(v, a, b);
+        v = a + b;
+        row_partner<true>(v, a, b);
+        return a + b;
+    }
+    /// Same component of the previous / next point: one DPP row shift (0 before point 0; the value
+    /// after point 9 is never used).
+    __device__ static __forceinline__ double prev_point(const Lane &, double v) { return row_from_prev(v); }
+    __device__ static __forceinline__ double next_point(const Lane &, double v) { return row_from_next(v); }
 
     // ---- memory <-> registers ------------------------------------------------------------------
     /// Initial state from the reference's state vector layout [vec(x) (30); vec(v) (27)]
@@ -222,9 +235,8 @@ struct ChainModel {
 
     __device__ static __forceinline__ void tape_store(const Lane &L, double4 *stage, int j, const Springs &sp,
                                                       const AdjAux &ax) {
-        const double d0 = qb<0>(sp.d), d1 = qb<1>(sp.d), d2 = qb<2>(sp.d);
-        const double l0 = qb<0>(ax.lF), l1 = qb<1>(ax.lF), l2 = qb<2>(ax.lF);
-        const double dq[DIM] = {d0, d1, d2}, lq[DIM] = {l0, l1, l2};
+        const Comps dc = comps(sp.d), lc = comps(ax.lF);
+        const double dq[DIM] = {dc.c0, dc.c1, dc.c2}, lq[DIM] = {lc.c0, lc.c1, lc.c2};
         const double e  = 3.0 / sp.n2;
         const double wd = ax.w * sp.d;
         const double g  = e * sp.d;
@@ -284,9 +296,10 @@ struct ChainModel {
                                                    double4 *st_stage, int j) {
         double d_t = s_t.x - prev_point(L, s_t.x);
         reinterpret_cast<double *>(reinterpret_cast<char *>(st_stage) + j * 256)[L.q] = d_t; // idle lanes: slot 31
-        double F  = g.K[0] * qb<0>(d_t);
-        F         = __builtin_fma(g.K[1], qb<1>(d_t), F);
-        F         = __builtin_fma(g.K[2], qb<2>(d_t), F);
+        const Comps dc = comps(d_t);
+        double F  = g.K[0] * dc.c0;
+        F         = __builtin_fma(g.K[1], dc.c1, F);
+        F         = __builtin_fma(g.K[2], dc.c2, F);
         double Fn = next_point(L, F);
         return {s_t.v, L.inv_m_l * (Fn - F)};
     }
@@ -294,9 +307,10 @@ struct ChainModel {
     __device__ static __forceinline__ State fc_adj_tan(const Lane &L, const TapeKM &g, const State &kbar_t) {
         double A   = prev_point(L, kbar_t.v);
         double lF  = inv_m * (A - kbar_t.v); // kbar_t.v stays 0 off the masses (see the return)
-        double ld  = g.K[0] * qb<0>(lF);
-        ld         = __builtin_fma(g.K[1], qb<1>(lF), ld);
-        ld         = __builtin_fma(g.K[2], qb<2>(lF), ld);
+        const Comps lc = comps(lF);
+        double ld  = g.K[0] * lc.c0;
+        ld         = __builtin_fma(g.K[1], lc.c1, ld);
+        ld         = __builtin_fma(g.K[2], lc.c2, ld);
         ld         = __builtin_fma(g.M[0], g.D[0], ld);
         ld         = __builtin_fma(g.M[1], g.D[1], ld);
         ld         = __builtin_fma(g.M[2], g.D[2], ld);
@@ -394,10 +408,13 @@ struct ChainModel {
             acc.x     = L.end ? acc.x + a2 : acc.x;
         }
     }
-    /// Total cost: per point ((((x0 + x1) + x2) + v0) + v1) + v2 on the lane of its component 0,
-    /// then the 64-lane butterfly.
+    /// Total cost: per point ((((x0 + x1) + x2) + v0) + v1) + v2 on the lane of its component 0
+    /// (row 0, lane p), then the 64-lane butterfly: its two cross-row levels add the zeros of rows
+    /// 1..3, its four in-row levels pair p with p^8, p^4, p^2, p^1 - the additions, in the order, of
+    /// the oracle's butterfly with point p at lane 4p.
     __device__ static __forceinline__ double cost_total(const Lane &L, const State &acc) {
-        double p = ((((qb<0>(acc.x) + qb<1>(acc.x)) + qb<2>(acc.x)) + qb<0>(acc.v)) + qb<1>(acc.v)) + qb<2>(acc.v);
+        const Comps x = comps(acc.x), v = comps(acc.v);
+        double p = ((((x.c0 + x.c1) + x.c2) + v.c0) + v.c1) + v.c2;
         return uniform(wave_sum(L.lead ? p : 0.0));
     }
     /// lam + d(l or l_N)/dx.

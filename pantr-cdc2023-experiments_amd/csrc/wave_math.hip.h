@@ -126,20 +126,6 @@ __device__ __forceinline__ double row_from_next(double v) { return dpp_move<0x10
 __device__ __forceinline__ dual row_from_prev(dual v) { return {row_from_prev(v.v), row_from_prev(v.t)}; }
 __device__ __forceinline__ dual row_from_next(dual v) { return {row_from_next(v.v), row_from_next(v.t)}; }
 
-/// Whole-wavefront shift by four lanes as four DPP wave shifts by one (CTRL 0x138 = wave_shr:1:
-/// lane i gets lane i-4; 0x130 = wave_shl:1: lane i gets lane i+4); lanes whose source lies outside
-/// the wavefront get 0.  VALU-speed, no LDS crossbar round trip.  All 64 lanes must be active.
-template <int CTRL>
-__device__ __forceinline__ double wave_shift4(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-        hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    }
-    return __hiloint2double(hi, lo);
-}
-
 /// 64-lane xor-butterfly all-reduce, masks 32, 16, 8, 4, 2, 1 (a + partner at every level, so all
 /// lanes finish with bit-identical sums), without the LDS crossbar: v_permlane32_swap and
 /// v_permlane16_swap (gfx950) across rows, DPP moves inside a 16-lane row.  After a permlane swap
