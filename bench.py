@@ -70,6 +70,9 @@ def measured_traffic(instances):
         if int(d["pmc_per_launch"]["SQ_WAVES"]) != instances:
             src["refused"] = "the PMC passes were taken on another batch size"
             return None, src
+        if "valu_issue" in d:  # what binds instead of HBM: VALU issue of lone wavefronts (same PMC passes)
+            src["valu_issue"] = {k: d["valu_issue"][k] for k in ("simd_issue_slots_used_frac", "wave_slot_occupancy_frac",
+                                                                 "cycles_per_valu_instruction_of_a_wavefront")}
         return float(d["hbm_traffic_bytes_per_launch"]["total"]), src
     except (OSError, KeyError, ValueError) as e:
         src["refused"] = f"no usable summary ({type(e).__name__})"
