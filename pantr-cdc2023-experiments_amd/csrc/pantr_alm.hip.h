@@ -56,6 +56,7 @@ struct ScalarALProblem {
     double *X;   ///< LDS: primal trajectory (N+1) x nx
     double *Xt;  ///< LDS: tangent trajectory (N+1) x nx of a product | adjoints lam_k while the tape is recorded
     double2 *TG; ///< LDS: trig store, 12 (sin, cos) pairs per stage (QuadModelT::trig_load)
+    double *SC;  ///< LDS: 5 doubles per stage, scratch of forward_cascade (models with integrated-input attitude)
     double *tape; ///< HBM: this instance's second-order tape (see workspace_doubles)
     enum { MV_Y = 0, MV_SIG = 1, MV_E1 = 2, MV_E2 = 3, MV_YH = 4, MV_YS = 7, MV_COUNT = 8 };
 
@@ -86,7 +87,8 @@ struct ScalarALProblem {
     __device__ __forceinline__ double *mvec(int slot) const { return mv + slot * mpad; }
     __host__ __device__ static size_t lds_doubles(int N, int npad, int mpad) {
         return (size_t)NUM_VEC * npad + (size_t)MV_COUNT * mpad + (size_t)2 * (N + 1) * nx +
-               (size_t)(N + 1) * M::TRIG_DOUBLES_PER_STAGE + X0_DOUBLES;
+               (size_t)(N + 1) * M::TRIG_DOUBLES_PER_STAGE + X0_DOUBLES +
+               (M::angles_are_integrated_inputs ? (size_t)5 * (N + 1) + 1 : 0);
     }
 
     __device__ __forceinline__ void load_u(const double *u, const double *, int k, double (&uk)[nu]) const {
@@ -279,8 +281,168 @@ struct ScalarALProblem {
             sbar[l] = sbar[l] + a[l];
     }
 
+    /// Forward sweep of a model whose attitude is an integrated input (quadcopter): the states form a
+    /// cascade angles -> velocities -> positions, so nothing but three short scans (one fma per stage
+    /// and component) is sequential; everything else is evaluated for all stages at once, lane = stage
+    /// (or lane = (stage, substage, angle) for the trigonometry).  Every scalar is computed by the
+    /// expression forward() below uses for it (same operands, same order), so the results - psi, the
+    /// trajectory, yhat, the trig store - are the same bits:
+    ///   A  angles:     a_{k+1} = fma(c6, fma(2,w,fma(2,w,w)) + w, a_k), w = u_k[1+j]        (scan)
+    ///   B  sin/cos of the substage angles a_k, fma(Ts/2,w,a_k) (twice), fma(Ts,w,a_k)      (parallel)
+    ///   C  accelerations of the four substages and their Runge-Kutta combination         (parallel)
+    ///   D  velocities: v_{k+1} = fma(c6, C_k, v_k)                                        (scan)
+    ///   E  position slopes v_k, fma(Ts/2,a1,v_k), fma(Ts/2,a2,v_k), fma(Ts,a3,v_k), combined (parallel)
+    ///   F  positions:  p_{k+1} = fma(c6, E_k, p_k)                                        (scan)
+    ///   G  constraints, multiplier estimates, stage costs                                (parallel)
+    ///   H  the two sums psi is made of, in stage order                                   (scan)
+    /// Scratch: rows of the tangent trajectory Xt (accelerations, combinations) and SC (5 doubles per
+    /// stage: the four augmented-Lagrangian products and the stage cost).
+    __device__ __forceinline__ double forward_cascade(const double *u, double *yh) const {
+        wave_sync();
+        const double *yS = mvec(MV_YS), *Sig = mvec(MV_SIG);
+        // the scans run component j3 (of 3) on every lane: lanes with the same j3 hold, and store, the same value
+        const int j3 = (lane & 15) < 3 ? (lane & 15) : 2;
+        // state_{k+1} = fma(c6, slope(k), state_k) for k = 0..N-1, storing state_k to X[k][off + j3] on the way;
+        // the slopes do not depend on the recursion: eight at a time are fetched ahead of the eight dependent fmas
+        auto scan = [&](int off, auto slope) {
+            double acc = x0[off + j3];
+            int k = 0;
+            for (; k + 8 <= N; k += 8) {
+                double c[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    c[i] = slope(k + i);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    X[(k + i) * nx + off + j3] = acc;
+                    acc = madd(M::c6, c[i], acc);
+                }
+            }
+            for (; k < N; ++k) {
+                X[k * nx + off + j3] = acc;
+                acc = madd(M::c6, slope(k), acc);
+            }
+            X[N * nx + off + j3] = acc;
+        };
+        // ---- A: angles ----
+        scan(6, [&](int k) {
+            const double w = u[nu * k + 1 + j3];
+            return madd(2.0, w, madd(2.0, w, w)) + w;
+        });
+        wave_sync();
+        // ---- B: trigonometry of every substage state: task = (stage, {s, s + Ts/2 k, s + Ts k}, angle) ----
+        for (int base = 0; base < 9 * (N + 1); base += WAVE) {
+            const int t = base + lane, k = t / 9, r = t - 9 * k, sub = r / 3, j = r - 3 * sub;
+            if (t < 9 * (N + 1) && (k < N || sub == 0)) {
+                const double a = X[k * nx + 6 + j];
+                const double w = k < N ? u[nu * k + 1 + j] : 0.0;
+                const double val = sub == 0 ? a : sub == 1 ? madd(M::hTs, w, a) : madd(M::Ts, w, a);
+                double sv, cv;
+                sincos_det(val, sv, cv);
+                double2 *tg = TG + 12 * k;
+                if (sub == 0) {
+                    tg[j] = make_double2(sv, cv);
+                } else if (sub == 1) { // the second and third substage states have the same angles
+                    tg[3 + j] = make_double2(sv, cv);
+                    tg[6 + j] = make_double2(sv, cv);
+                } else {
+                    tg[9 + j] = make_double2(sv, cv);
+                }
+            }
+        }
+        wave_sync();
+        // ---- C: accelerations (rows of Xt: a1 | a2 = a3 | combination) ----
+        for (int k = lane; k < N; k += WAVE) {
+            const double2 *tg = TG + 12 * k;
+            const double u0 = u[nu * k];
+            double a1[3], a2[3], a4[3];
+            M::accel(M::trig_load(tg), u0, a1);
+            M::accel(M::trig_load(tg + 3), u0, a2);
+            M::accel(M::trig_load(tg + 9), u0, a4);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                Xt[k * nx + m]     = a1[m];
+                Xt[k * nx + 3 + m] = a2[m];
+                Xt[k * nx + 6 + m] = madd(2.0, a2[m], madd(2.0, a2[m], a1[m])) + a4[m];
+            }
+        }
+        wave_sync();
+        // ---- D: velocities ----
+        scan(3, [&](int k) { return Xt[k * nx + 6 + j3]; });
+        wave_sync();
+        // ---- E: position slopes, combined (over the combination row of Xt) ----
+        for (int k = lane; k < N; k += WAVE) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const double v  = X[k * nx + 3 + m];
+                const double k2 = madd(M::hTs, Xt[k * nx + m], v);
+                const double k3 = madd(M::hTs, Xt[k * nx + 3 + m], v);
+                const double k4 = madd(M::Ts, Xt[k * nx + 3 + m], v);
+                Xt[k * nx + 6 + m] = madd(2.0, k3, madd(2.0, k2, v)) + k4;
+            }
+        }
+        wave_sync();
+        // ---- F: positions ----
+        scan(0, [&](int k) { return Xt[k * nx + 6 + j3]; });
+        wave_sync();
+        // ---- G: constraints, multiplier estimates, costs ----
+        for (int k = lane; k <= N; k += WAVE) {
+            double s[nx], c[nc], uk[nu];
+#pragma unroll
+            for (int l = 0; l < nx; ++l)
+                s[l] = X[k * nx + l];
+            M::constr(M::trig_load(TG + 12 * k), s, c);
+#pragma unroll
+            for (int i = 0; i < nc; ++i) {
+                const int j       = nc * k + i;
+                const double zeta = c[i] + yS[j];
+                const double zhat = tmax(tmin(zeta, box->d_ub[i]), box->d_lb[i]);
+                const double d    = zeta - zhat;
+                const double yhv  = Sig[j] * d;
+                yh[j]             = yhv;
+                SC[5 * k + i]     = yhv * d;
+            }
+            if (k < N) {
+#pragma unroll
+                for (int cc = 0; cc < nu; ++cc)
+                    uk[cc] = u[nu * k + cc];
+                SC[5 * k + 4] = M::stage_cost(s, uk);
+            } else {
+                SC[5 * k + 4] = M::term_cost(s);
+            }
+        }
+        wave_sync();
+        // ---- H: psi = (sum of the costs) + 1/2 (sum of the augmented-Lagrangian products), four stages'
+        //         terms fetched ahead of their (dependent) additions ----
+        double accf = 0.0, accal = 0.0;
+        int k = 0;
+        for (; k + 4 <= N + 1; k += 4) {
+            double e[20];
+#pragma unroll
+            for (int i = 0; i < 20; ++i)
+                e[i] = SC[5 * k + i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int i = 0; i < nc; ++i)
+                    accal = accal + e[5 * q + i];
+                accf = accf + e[5 * q + 4];
+            }
+        }
+        for (; k <= N; ++k) {
+#pragma unroll
+            for (int i = 0; i < nc; ++i)
+                accal = accal + SC[5 * k + i];
+            accf = accf + SC[5 * k + 4];
+        }
+        wave_sync();
+        return accf + (0.5 * accal);
+    }
+
     /// Forward sweep: psi, trajectory, yhat, and the trig store of every substage state.
     __device__ __forceinline__ double forward(const double *u, double *yh) const {
+        if constexpr (M::angles_are_integrated_inputs)
+            return forward_cascade(u, yh);
         wave_sync();
         const double *yS = mvec(MV_YS), *Sig = mvec(MV_SIG);
         double s[nx], xn[nx], c[nc], uk[nu], yhv[nc];
@@ -780,6 +942,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
         if (lane < M::nx)
             x0_lds[lane] = a.x0[(size_t)inst * M::nx + lane];
         pb.x0 = x0_lds;
+        pb.SC = x0_lds + PB::X0_DOUBLES;
     }
     double *x_io = pb.vec(S_XIO), *y = pb.mvec(PB::MV_Y), *Sig = pb.mvec(PB::MV_SIG), *e1 = pb.mvec(PB::MV_E1),
            *e2 = pb.mvec(PB::MV_E2);
@@ -928,6 +1091,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
         if (lane < M::nx)
             x0_lds[lane] = a.x0[(size_t)inst * M::nx + lane];
         pb.x0 = x0_lds;
+        pb.SC = x0_lds + PB::X0_DOUBLES;
     }
     double *u = pb.vec(0), *v = pb.vec(1), *o = pb.vec(2);
     for (int i = lane; i < a.n; i += WAVE) {

@@ -547,7 +547,10 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
     if (b->al()) {
         // trajectories and multipliers live in LDS; the second-order tape streams from HBM
         b->ws_per_instance = ScalarALProblem<QuadModelT<false>>::workspace_doubles(b->N);
-        b->lds_bytes       = ScalarALProblem<QuadModelT<false>>::lds_doubles(b->N, b->npad, b->mpad) * sizeof(double);
+        b->lds_bytes       = (id == ProblemId::RealisticQuadcopter
+                                  ? ScalarALProblem<QuadModelT<true>>::lds_doubles(b->N, b->npad, b->mpad)
+                                  : ScalarALProblem<QuadModelT<false>>::lds_doubles(b->N, b->npad, b->mpad)) *
+                             sizeof(double);
     } else {
         b->ws_per_instance = WaveProblem<ChainModel>::workspace_doubles(b->N);
         b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double); // dynamic part: all vectors (comparators)

@@ -19,6 +19,9 @@ namespace pantr {
 template <bool REALISTIC>
 struct QuadModelT {
     static constexpr int nx = 9, nu = 4, nc = 4;
+    /// The attitude does not feed back into its own dynamics (the angle rates are inputs): the states
+    /// form a cascade angles -> velocities -> positions, which ScalarALProblem::forward_cascade uses.
+    static constexpr bool angles_are_integrated_inputs = !REALISTIC;
     static constexpr double Ts = 0.1, hTs = 0.5 * Ts, g_grav = 9.81, c6 = Ts / 6;
     static constexpr double r2 = 0.1 * 0.1; ///< collision cylinder radius squared (quadcopter.py:70)
     __host__ __device__ static constexpr double pf(int i) { return i == 2 ? 0.5 : 0.25; } // quadcopter.py:90
@@ -91,6 +94,23 @@ struct QuadModelT {
             return trig_uniform(s);
         else
             return trig(s);
+    }
+
+    /// Acceleration of the stage at thrust u0 for the attitude t: the expressions of fc() for ds[3..5].
+    __device__ static __forceinline__ void accel(const Trig<double> &t, double u0, double (&a)[3]) {
+        double r0, r1, r2_;
+        if (!REALISTIC) {
+            r0  = ((t.c2 * t.s1) * t.c0) + (t.s2 * t.s0);
+            r1  = ((t.s2 * t.s1) * t.c0) - (t.c2 * t.s0);
+            r2_ = t.c1 * t.c0;
+        } else {
+            r0  = (t.c2 * t.s1) + ((t.c1 * t.s0) * t.s2);
+            r1  = (t.s2 * t.s1) - ((t.c2 * t.c1) * t.s0);
+            r2_ = t.c0 * t.c1;
+        }
+        a[0] = r0 * u0;
+        a[1] = r1 * u0;
+        a[2] = (r2_ * u0) - g_grav;
     }
 
     /// f_c(state, input) (quadcopter.py:30-46, realistic_quadcopter.py:30-50)
