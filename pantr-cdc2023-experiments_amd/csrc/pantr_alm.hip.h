@@ -56,7 +56,7 @@ struct ScalarALProblem {
     double *X;   ///< LDS: primal trajectory (N+1) x nx
     double *Xt;  ///< LDS: tangent trajectory (N+1) x nx of a product | adjoints lam_k while the tape is recorded
     double2 *TG; ///< LDS: trig store, 12 (sin, cos) pairs per stage (QuadModelT::trig_load)
-    double *SC;  ///< LDS: 5 doubles per stage, scratch of forward_cascade (models with integrated-input attitude)
+    double *scr; ///< LDS: 13 (N + 1) doubles of scratch for the cascade sweeps (models with integrated-input attitude)
     double *tape; ///< HBM: this instance's second-order tape (see workspace_doubles)
     enum { MV_Y = 0, MV_SIG = 1, MV_E1 = 2, MV_E2 = 3, MV_YH = 4, MV_YS = 7, MV_COUNT = 8 };
 
@@ -85,10 +85,12 @@ struct ScalarALProblem {
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
     __device__ __forceinline__ double *ivec(int slot) const { return lds + slot * npad; }
     __device__ __forceinline__ double *mvec(int slot) const { return mv + slot * mpad; }
-    __host__ __device__ static size_t lds_doubles(int N, int npad, int mpad) {
+    /// dedicated_scratch: the cascade sweeps' scratch gets LDS of its own (the comparators, whose direction
+    /// keeps data in the CG block; PANTR and the eval kernel lend them four CG vectors that are dead during sweeps)
+    __host__ __device__ static size_t scratch_doubles(int N) { return M::angles_are_integrated_inputs ? (size_t)13 * (N + 1) + 1 : 0; }
+    __host__ __device__ static size_t lds_doubles(int N, int npad, int mpad, bool dedicated_scratch = false) {
         return (size_t)NUM_VEC * npad + (size_t)MV_COUNT * mpad + (size_t)2 * (N + 1) * nx +
-               (size_t)(N + 1) * M::TRIG_DOUBLES_PER_STAGE + X0_DOUBLES +
-               (M::angles_are_integrated_inputs ? (size_t)5 * (N + 1) + 1 : 0);
+               (size_t)(N + 1) * M::TRIG_DOUBLES_PER_STAGE + X0_DOUBLES + (dedicated_scratch ? scratch_doubles(N) : 0);
     }
 
     __device__ __forceinline__ void load_u(const double *u, const double *, int k, double (&uk)[nu]) const {
@@ -295,7 +297,7 @@ struct ScalarALProblem {
     ///   F  positions:  p_{k+1} = fma(c6, E_k, p_k)                                        (scan)
     ///   G  constraints, multiplier estimates, stage costs                                (parallel)
     ///   H  the two sums psi is made of, in stage order                                   (scan)
-    /// Scratch: rows of the tangent trajectory Xt (accelerations, combinations) and SC (5 doubles per
+    /// Scratch: rows of the tangent trajectory Xt (accelerations, combinations) and scr (5 doubles per
     /// stage: the four augmented-Lagrangian products and the stage cost).
     __device__ __forceinline__ double forward_cascade(const double *u, double *yh) const {
         wave_sync();
@@ -400,15 +402,15 @@ struct ScalarALProblem {
                 const double d    = zeta - zhat;
                 const double yhv  = Sig[j] * d;
                 yh[j]             = yhv;
-                SC[5 * k + i]     = yhv * d;
+                scr[5 * k + i]     = yhv * d;
             }
             if (k < N) {
 #pragma unroll
                 for (int cc = 0; cc < nu; ++cc)
                     uk[cc] = u[nu * k + cc];
-                SC[5 * k + 4] = M::stage_cost(s, uk);
+                scr[5 * k + 4] = M::stage_cost(s, uk);
             } else {
-                SC[5 * k + 4] = M::term_cost(s);
+                scr[5 * k + 4] = M::term_cost(s);
             }
         }
         wave_sync();
@@ -420,7 +422,7 @@ struct ScalarALProblem {
             double e[20];
 #pragma unroll
             for (int i = 0; i < 20; ++i)
-                e[i] = SC[5 * k + i];
+                e[i] = scr[5 * k + i];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -432,8 +434,8 @@ struct ScalarALProblem {
         for (; k <= N; ++k) {
 #pragma unroll
             for (int i = 0; i < nc; ++i)
-                accal = accal + SC[5 * k + i];
-            accf = accf + SC[5 * k + 4];
+                accal = accal + scr[5 * k + i];
+            accf = accf + scr[5 * k + 4];
         }
         wave_sync();
         return accf + (0.5 * accal);
@@ -480,11 +482,183 @@ struct ScalarALProblem {
         wave_sync();
         return accf + (0.5 * accal);
     }
-    /// Adjoint sweep over the stored trajectory and trig store with multipliers yh; OUT(i, value)
-    /// receives grad_i.  STORE_LAM: the adjoints lam_{k+1} every stage receives are kept (rows of LAM,
-    /// which shares the tangent trajectory's LDS) for the second-order recording.
-    template <bool STORE_LAM, class OUT>
-    __device__ __forceinline__ void reverse(const double *u, const double *yh, OUT &&out) const {
+    /// Adjoint sweep of a model whose attitude is an integrated input (quadcopter), as a cascade in the
+    /// opposite direction: position adjoints feed the velocity adjoints feed the angle adjoints, and no
+    /// adjoint feeds back.  Sequential: three scans of a few dependent additions per stage and
+    /// component (operands fetched eight stages ahead).  All the rest - the substage adjoints of f_c
+    /// with their trigonometric coefficients, the input gradients - is evaluated for all stages at once,
+    /// lane = stage, by the very functions reverse() calls (M::fc_adj), on the operands reverse() would
+    /// hand them.  Value for value the arithmetic of reverse() (what it adds of exact zeros - the
+    /// position adjoint of f_c is 0 * u_0 - is skipped: same values, possibly another sign of a zero).
+    ///   1  lam_p(k) = (lam_p(k+1) + dl/dp) - (dc/dp)' yhat                                       (scan)
+    ///   2  lam_v(k) = ((((lam_v + sg) + 2 sg) + 2 sg) + sg) + dl/dv,   sg = c6 lam_p(k+1)         (scan)
+    ///   3  velocity parts of the four substage adjoint seeds, fc_adj on them: A_s (angle parts), u_0 gradient
+    ///   4  lam_a(k) = (((((lam_a + A_4) + A_3) + A_2) + A_1) + dl/da) + (dc/da)' yhat             (scan)
+    ///   5  angle parts of the seeds -> gradients of the three rate inputs; + cost gradient -> grad
+    /// lam_(k+1) of every stage is left in LAM (= rows of Xt) for the second-order recording.
+    __device__ __forceinline__ void reverse_cascade(const double *u, const double *yh, double *grad) const {
+        wave_sync();
+        const int j3 = (lane & 15) < 3 ? (lane & 15) : 2;
+        double *LAM = Xt;
+        // lam(k) = step(k, lam(k+1)) for k = N-1..0, with lam(k+1) stored to LAM[k+1][off + j3] on the way;
+        // prep(k) fetches what step k needs that does not depend on the recursion, eight stages ahead
+        auto scan_down = [&](int off, double lam, auto prep, auto step) {
+            int k = N - 1;
+            for (; k - 7 >= 0; k -= 8) {
+                decltype(prep(0)) o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    o[i] = prep(k - i);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    LAM[(k - i + 1) * nx + off + j3] = lam;
+                    lam = step(o[i], lam);
+                }
+            }
+            for (; k >= 0; --k) {
+                LAM[(k + 1) * nx + off + j3] = lam;
+                lam = step(prep(k), lam);
+            }
+        };
+        const double pf = j3 == 2 ? 0.5 : 0.25; // M::pf(j3)
+        struct Two {
+            double a, b;
+        };
+        // ---- 1: position adjoints ----
+        {
+            const double sN = X[N * nx + j3];
+            double lam = 0.0 + (2.0 * 250.0) * (sN - pf);
+            if (j3 < 2)
+                lam = lam - ((2.0 * sN) * yh[nc * N + 3]);
+            scan_down(
+                0, lam,
+                [&](int k) {
+                    const double sk = X[k * nx + j3];
+                    return Two{(2.0 * 10.0) * (sk - pf), j3 < 2 ? (2.0 * sk) * yh[nc * k + 3] : 0.0};
+                },
+                [&](const Two &o, double mu) { return (mu + o.a) - o.b; });
+        }
+        wave_sync();
+        // ---- 2: velocity adjoints ----
+        {
+            double lam = 0.0 + (2.0 * 25.0) * X[N * nx + 3 + j3];
+            scan_down(
+                3, lam,
+                [&](int k) { return Two{M::c6 * LAM[(k + 1) * nx + j3], (2.0 * 1.0) * X[k * nx + 3 + j3]}; },
+                [&](const Two &o, double mu) {
+                    const double t2 = 2.0 * o.a;
+                    return ((((mu + o.a) + t2) + t2) + o.a) + o.b;
+                });
+        }
+        wave_sync();
+        // ---- 3: substage adjoints of f_c on the velocity parts of their seeds (lane = stage) ----
+        for (int k = lane; k < N; k += WAVE) {
+            const double2 *tg = TG + 12 * k;
+            double uk[nu], kb[nx], sb[nx], ub[nu], ub0[4];
+#pragma unroll
+            for (int c = 0; c < nu; ++c)
+                uk[c] = u[nu * k + c];
+#pragma unroll
+            for (int l = 0; l < nx; ++l)
+                kb[l] = 0.0;
+            double sgp[3], sgv[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                sgp[i] = M::c6 * LAM[(k + 1) * nx + i];
+                sgv[i] = M::c6 * LAM[(k + 1) * nx + 3 + i];
+            }
+            double *A = scr + 13 * k;
+            // substage 4: seed c6 lam
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                kb[3 + i] = sgv[i];
+            M::fc_adj(M::trig_load(tg + 9), uk, kb, sb, ub);
+            ub0[0] = ub[0];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                A[j] = sb[6 + j];
+            // substage 3: seed 2 c6 lam + Ts a_4, a_4[v] = the position part of seed 4
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                kb[3 + i] = madd(M::Ts, sgp[i], 2.0 * sgv[i]);
+            M::fc_adj(M::trig_load(tg + 6), uk, kb, sb, ub);
+            ub0[1] = ub[0];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                A[3 + j] = sb[6 + j];
+            // substage 2: seed 2 c6 lam + Ts/2 a_3
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                kb[3 + i] = madd(M::hTs, 2.0 * sgp[i], 2.0 * sgv[i]);
+            M::fc_adj(M::trig_load(tg + 3), uk, kb, sb, ub);
+            ub0[2] = ub[0];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                A[6 + j] = sb[6 + j];
+            // substage 1: seed c6 lam + Ts/2 a_2
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                kb[3 + i] = madd(M::hTs, 2.0 * sgp[i], sgv[i]);
+            M::fc_adj(M::trig_load(tg), uk, kb, sb, ub);
+            ub0[3] = ub[0];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                A[9 + j] = sb[6 + j];
+            A[12] = ((ub0[0] + ub0[1]) + ub0[2]) + ub0[3];
+        }
+        wave_sync();
+        // ---- 4: angle adjoints ----
+        {
+            // (dc/da)' yhat of stage k on this lane's angle: c_0 = phi, c_1 = theta, c_2 = cos phi cos theta
+            auto constr_term = [&](int k) {
+                const auto t      = M::trig_load(TG + 12 * k);
+                const double *yb  = yh + nc * k;
+                return j3 == 0 ? yb[0] - ((t.s0 * t.c1) * yb[2]) : j3 == 1 ? yb[1] - ((t.c0 * t.s1) * yb[2]) : 0.0;
+            };
+            double lam = 0.0 + (2.0 * 10.0) * X[N * nx + 6 + j3];
+            if (j3 < 2)
+                lam = lam + constr_term(N);
+            struct Six {
+                double a4, a3, a2, a1, g, c;
+            };
+            scan_down(
+                6, lam,
+                [&](int k) {
+                    const double *A = scr + 13 * k;
+                    return Six{A[j3], A[3 + j3], A[6 + j3], A[9 + j3], (2.0 * 1.0) * X[k * nx + 6 + j3], constr_term(k)};
+                },
+                [&](const Six &o, double mu) {
+                    const double l = ((((mu + o.a4) + o.a3) + o.a2) + o.a1) + o.g;
+                    return j3 < 2 ? l + o.c : l;
+                });
+        }
+        wave_sync();
+        // ---- 5: gradients (lane = stage) ----
+        for (int k = lane; k < N; k += WAVE) {
+            const double *A = scr + 13 * k;
+            const double u0 = u[nu * k];
+            grad[nu * k] = A[12] + (2e-4 * u0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double sga = M::c6 * LAM[(k + 1) * nx + 6 + j];
+                const double kb4 = sga;
+                const double kb3 = madd(M::Ts, A[j], 2.0 * sga);
+                const double kb2 = madd(M::hTs, A[3 + j], 2.0 * sga);
+                const double kb1 = madd(M::hTs, A[6 + j], sga);
+                const double uj  = u[nu * k + 1 + j];
+                grad[nu * k + 1 + j] = (((kb4 + kb3) + kb2) + kb1) + ((2e-4 * uj) + (20.0 * uj));
+            }
+        }
+        wave_sync();
+    }
+
+    /// Adjoint sweep over the stored trajectory and trig store with multipliers yh: grad_i.  STORE_LAM:
+    /// the adjoints lam_{k+1} every stage receives are kept (rows of LAM, which shares the tangent
+    /// trajectory's LDS) for the second-order recording.
+    template <bool STORE_LAM>
+    __device__ __forceinline__ void reverse(const double *u, const double *yh, double *grad) const {
+        if constexpr (M::angles_are_integrated_inputs)
+            return reverse_cascade(u, yh, grad);
         wave_sync();
         double lam[nx], sbar[nx], ubar[nu], gu[nu], s[nx], uk[nu], yk[nc];
 #pragma unroll
@@ -507,9 +681,10 @@ struct ScalarALProblem {
             for (int l = 0; l < nx; ++l)
                 lam[l] = sbar[l];
             M::cost_grad(s, uk, lam, gu);
+            if (lane == 0)
 #pragma unroll
-            for (int c = 0; c < nu; ++c)
-                out(nu * k + c, ubar[c] + gu[c]);
+                for (int c = 0; c < nu; ++c)
+                    grad[nu * k + c] = ubar[c] + gu[c];
             load_yh(yh, k, yk);
             M::constr_adj(M::trig_load(tg), s, yk, lam);
         }
@@ -520,10 +695,7 @@ struct ScalarALProblem {
     __device__ __forceinline__ double eval_psi_grad(const double *u, double *grad) const {
         double *yh = mvec(MV_E2); // scratch (e2 is rewritten at the end of the inner solve)
         double psi = forward(u, yh);
-        reverse<false>(u, yh, [&](int i, double g) {
-            if (lane == 0)
-                grad[i] = g;
-        });
+        reverse<false>(u, yh, grad);
         return psi;
     }
     __device__ __forceinline__ double eval_psi_xhat(const double *u, int yh_slot) const {
@@ -555,10 +727,7 @@ struct ScalarALProblem {
     ///      64 at a time, instead of one sweep of N dependent ones.
     /// The arithmetic of every entry is the one of the sweep it replaces (value parts = step 1).
     __device__ __forceinline__ void eval_grad_xhat(const double *u, double *grad, int yh_slot) const {
-        reverse<true>(u, mvec(MV_YH + yh_slot), [&](int i, double g) {
-            if (lane == 0)
-                grad[i] = g;
-        });
+        reverse<true>(u, mvec(MV_YH + yh_slot), grad);
         // terminal block: lane d < nx seeds direction e_d of x_N
         if (lane < nx) {
             const int d = lane;
@@ -933,7 +1102,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
     pb.TG = reinterpret_cast<double2 *>(pb.Xt + (size_t)(a.N + 1) * M::nx);
     pb.tape = a.ws + (size_t)inst * PB::workspace_doubles(a.N);
     const int n = a.n, m = a.m;
-    const size_t total = PB::lds_doubles(a.N, a.npad, a.mpad);
+    const size_t total = PB::lds_doubles(a.N, a.npad, a.mpad, METHOD != 0);
     for (size_t i = lane; i < total; i += WAVE)
         lds[i] = 0.0;
     wave_sync();
@@ -942,7 +1111,9 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
         if (lane < M::nx)
             x0_lds[lane] = a.x0[(size_t)inst * M::nx + lane];
         pb.x0 = x0_lds;
-        pb.SC = x0_lds + PB::X0_DOUBLES;
+        // scratch of the cascade sweeps: PANTR lends the CG vectors z, r, d, Bd (dead outside the direction
+        // computation); the comparators keep L-BFGS scalars in the CG block and get LDS of their own
+        pb.scr = METHOD == 0 ? pb.vec(PB::CG_BASE + 3) : x0_lds + PB::X0_DOUBLES;
     }
     double *x_io = pb.vec(S_XIO), *y = pb.mvec(PB::MV_Y), *Sig = pb.mvec(PB::MV_SIG), *e1 = pb.mvec(PB::MV_E1),
            *e2 = pb.mvec(PB::MV_E2);
@@ -1091,7 +1262,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
         if (lane < M::nx)
             x0_lds[lane] = a.x0[(size_t)inst * M::nx + lane];
         pb.x0 = x0_lds;
-        pb.SC = x0_lds + PB::X0_DOUBLES;
+        pb.scr = pb.vec(PB::CG_BASE + 3); // four vector slots this kernel does not use
     }
     double *u = pb.vec(0), *v = pb.vec(1), *o = pb.vec(2);
     for (int i = lane; i < a.n; i += WAVE) {
@@ -1128,10 +1299,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
         // grad_x L(x, y) = grad f + grad g' y (formulation.hpp:98,170-174): the trajectory at u, then
         // the adjoint sweep with the caller's y as the multipliers (Sigma plays no role)
         pb.eval_psi_xhat(u, 0);
-        pb.template reverse<false>(u, pb.mvec(PB::MV_Y), [&](int i, double g) {
-            if (lane == 0)
-                o[i] = g;
-        });
+        pb.template reverse<false>(u, pb.mvec(PB::MV_Y), o);
     } else {
         pb.eval_psi_xhat(u, 0);
         pb.eval_grad_xhat(u, pb.vec(3), 0); // records the tape at u

@@ -57,6 +57,7 @@ struct pantr_batch {
     size_t ws_per_instance = 0; ///< doubles
     size_t lds_bytes       = 0; ///< dynamic LDS with all vectors in LDS (scalar models; the comparators on the chain)
     size_t lds_bytes_pantr = 0; ///< hanging chain, method=pantr: CG block + staging slot only (iterates in HBM)
+    size_t lds_bytes_cmp   = 0; ///< scalar models, method=panoc|strucpanoc
     SolverOptions opts = SolverOptions::driver_defaults();
     // device memory
     double *d_x0 = nullptr, *d_u = nullptr, *d_v = nullptr, *d_o1 = nullptr, *d_o2 = nullptr,
@@ -282,6 +283,8 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
         if (b->opts.alm.initial_penalty <= 0)
             return fail(PANTR_ERR_INVALID_ARGUMENT,
                         "alm.initial_penalty must be > 0 (automatic penalty initialisation is not supported)");
+        if (method != 0 && b->lds_bytes_cmp > 160 * 1024)
+            return fail(PANTR_ERR_OUT_OF_RANGE, "horizon too long for method=panoc|strucpanoc: their vectors do not fit the 160 KiB LDS");
         AlmSolveArgs a{};
         a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj; a.m = b->m; a.mpad = b->mpad; a.mj = b->mj;
         a.trace_cap = b->trace_cap; a.trace_instances = b->trace_instances;
@@ -296,9 +299,9 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
             if (method == 0)
                 hipLaunchKernelGGL((pantr_alm_kernel<M, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
             else if (method == 1)
-                hipLaunchKernelGGL((pantr_alm_kernel<M, 1>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+                hipLaunchKernelGGL((pantr_alm_kernel<M, 1>), dim3(B), dim3(WAVE), b->lds_bytes_cmp, stream, a);
             else
-                hipLaunchKernelGGL((pantr_alm_kernel<M, 2>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+                hipLaunchKernelGGL((pantr_alm_kernel<M, 2>), dim3(B), dim3(WAVE), b->lds_bytes_cmp, stream, a);
             return 0;
         });
         HIP_TRY(hipGetLastError());
@@ -547,10 +550,14 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
     if (b->al()) {
         // trajectories and multipliers live in LDS; the second-order tape streams from HBM
         b->ws_per_instance = ScalarALProblem<QuadModelT<false>>::workspace_doubles(b->N);
-        b->lds_bytes       = (id == ProblemId::RealisticQuadcopter
-                                  ? ScalarALProblem<QuadModelT<true>>::lds_doubles(b->N, b->npad, b->mpad)
-                                  : ScalarALProblem<QuadModelT<false>>::lds_doubles(b->N, b->npad, b->mpad)) *
-                             sizeof(double);
+        auto lds_of = [&](bool dedicated_scratch) {
+            return (id == ProblemId::RealisticQuadcopter
+                        ? ScalarALProblem<QuadModelT<true>>::lds_doubles(b->N, b->npad, b->mpad, dedicated_scratch)
+                        : ScalarALProblem<QuadModelT<false>>::lds_doubles(b->N, b->npad, b->mpad, dedicated_scratch)) *
+                   sizeof(double);
+        };
+        b->lds_bytes     = lds_of(false); // method=pantr and the evaluation kernel
+        b->lds_bytes_cmp = lds_of(true);  // the comparators: the cascade sweeps' scratch gets LDS of its own
     } else {
         b->ws_per_instance = WaveProblem<ChainModel>::workspace_doubles(b->N);
         b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double); // dynamic part: all vectors (comparators)
@@ -561,15 +568,18 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
         return fail(PANTR_ERR_OUT_OF_RANGE, "decision vectors do not fit the 160 KiB LDS");
     if (b->al()) {
         for (const void *k : {(const void *)&pantr_alm_kernel<QuadModelT<false>, 0>,
-                              (const void *)&pantr_alm_kernel<QuadModelT<false>, 1>,
-                              (const void *)&pantr_alm_kernel<QuadModelT<false>, 2>,
                               (const void *)&pantr_alm_kernel<QuadModelT<true>, 0>,
-                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 1>,
-                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 2>,
                               (const void *)&pantr_alm_eval_kernel<QuadModelT<false>>,
                               (const void *)&pantr_alm_eval_kernel<QuadModelT<true>>})
             if (int rc = raise_dynamic_lds(k, b->lds_bytes))
                 return rc;
+        if (b->lds_bytes_cmp <= 160 * 1024) // else the comparators are refused at launch
+            for (const void *k : {(const void *)&pantr_alm_kernel<QuadModelT<false>, 1>,
+                                  (const void *)&pantr_alm_kernel<QuadModelT<false>, 2>,
+                                  (const void *)&pantr_alm_kernel<QuadModelT<true>, 1>,
+                                  (const void *)&pantr_alm_kernel<QuadModelT<true>, 2>})
+                if (int rc = raise_dynamic_lds(k, b->lds_bytes_cmp))
+                    return rc;
     } else {
         if (int rc = raise_dynamic_lds((const void *)&pantr_solve_kernel<ChainModel, 0>, b->lds_bytes_pantr))
             return rc;
@@ -827,7 +837,8 @@ int pantr_batch_footprint(const pantr_batch_t *b, int64_t *lds_bytes, int64_t *w
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
     if (lds_bytes) { // of the solve kernel the handle's current method selects
         const bool pantr_chain = !b->al() && b->opts.method == host::Method::PANTR;
-        *lds_bytes = (int64_t)((pantr_chain ? b->lds_bytes_pantr : b->lds_bytes) +
+        const bool cmp_scalar = b->al() && b->opts.method != host::Method::PANTR;
+        *lds_bytes = (int64_t)((pantr_chain ? b->lds_bytes_pantr : cmp_scalar ? b->lds_bytes_cmp : b->lds_bytes) +
                                (b->al() ? 0 : WaveProblem<ChainModel>::tape_lds_bytes()));
     }
     if (ws_bytes_per_instance) *ws_bytes_per_instance = (int64_t)(b->ws_per_instance * sizeof(double));
