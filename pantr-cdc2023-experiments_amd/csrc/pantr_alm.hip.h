@@ -7,13 +7,16 @@
 //   constraints on x_0..x_{N-1} and x_N                          python/.../formulations/ss.py:39-40
 //   alpaqa::ALMSolver::operator() (m > 0)                        drivers/mpc-driver.cpp:104-115,217
 //   ALM options                                                  new-benchmarks-paper/dodo.py:12-22,101-105
-// One wavefront per MPC instance as for the chain.  The nine-state stage is small, so the first-order
-// sweeps evaluate it identically on every lane (no cross-lane traffic; trajectories and multipliers
-// live in LDS).  The second-order work is spread over lanes: the adjoint sweep of grad_L runs on dual
-// numbers with lane d seeding direction e_d of z = (x_k, u_k), which yields the stage Jacobian J_k
-// and the stage Hessian H_k of the Lagrangian-like recursion column by column in ONE sweep; each
-// Hessian-vector product of the CG iterations is then 13x13 / 13x9 matrix-vector work per stage,
-// lane l owning component l, streamed from the HBM tape one stage ahead of the arithmetic.
+// One wavefront per MPC instance as for the chain.  The nine-state stage is small and its states are a
+// cascade (attitude -> velocities -> positions), so the first-order sweeps keep only what truly is a
+// recursion sequential - three short scans, and for realistic_quadcopter the attitude itself - and
+// evaluate everything else for all stages at once, lane = stage (forward_cascade, reverse_cascade;
+// trajectories, multipliers and the sin/cos values of every substage state live in LDS).  The
+// second-order work is spread over lanes as well: grad_L is followed by one task per (stage, direction)
+// on dual numbers, which yields the stage Jacobian J_k and the stage Hessian H_k of the Lagrangian-like
+// recursion column by column; each Hessian-vector product of the CG iterations is then 13x13 / 13x9
+// matrix-vector work per stage, split over the four 16-lane rows, streamed from the HBM tape ahead of
+// the arithmetic.
 #pragma once
 #include "pantr_kernel.hip.h"
 #include <type_traits>
@@ -56,7 +59,8 @@ struct ScalarALProblem {
     double *X;   ///< LDS: primal trajectory (N+1) x nx
     double *Xt;  ///< LDS: tangent trajectory (N+1) x nx of a product | adjoints lam_k while the tape is recorded
     double2 *TG; ///< LDS: trig store, 12 (sin, cos) pairs per stage (QuadModelT::trig_load)
-    double *scr; ///< LDS: 13 (N + 1) doubles of scratch for the cascade sweeps (models with integrated-input attitude)
+    double *scr;  ///< LDS: 13 (N + 1) + 1 doubles of scratch for the cascade sweeps
+    double *coef; ///< LDS: coef_doubles(N), see there
     double *tape; ///< HBM: this instance's second-order tape (see workspace_doubles)
     enum { MV_Y = 0, MV_SIG = 1, MV_E1 = 2, MV_E2 = 3, MV_YH = 4, MV_YS = 7, MV_COUNT = 8 };
 
@@ -87,115 +91,39 @@ struct ScalarALProblem {
     __device__ __forceinline__ double *mvec(int slot) const { return mv + slot * mpad; }
     /// dedicated_scratch: the cascade sweeps' scratch gets LDS of its own (the comparators, whose direction
     /// keeps data in the CG block; PANTR and the eval kernel lend them four CG vectors that are dead during sweeps)
-    __host__ __device__ static size_t scratch_doubles(int N) { return M::angles_are_integrated_inputs ? (size_t)13 * (N + 1) + 1 : 0; }
+    __host__ __device__ static size_t scratch_doubles(int N) { return (size_t)13 * (N + 1) + 1; }
+    /// realistic_quadcopter: the coefficients of the angle-rate adjoints (5 per substage), evaluated for
+    /// all stages at once ahead of the sequential angle-adjoint recursion
+    static constexpr int COEF = 20;
+    __host__ __device__ static size_t coef_doubles(int N) { return M::angles_are_integrated_inputs ? 0 : (size_t)COEF * N; }
     __host__ __device__ static size_t lds_doubles(int N, int npad, int mpad, bool dedicated_scratch = false) {
         return (size_t)NUM_VEC * npad + (size_t)MV_COUNT * mpad + (size_t)2 * (N + 1) * nx +
-               (size_t)(N + 1) * M::TRIG_DOUBLES_PER_STAGE + X0_DOUBLES + (dedicated_scratch ? scratch_doubles(N) : 0);
+               (size_t)(N + 1) * M::TRIG_DOUBLES_PER_STAGE + X0_DOUBLES + coef_doubles(N) +
+               (dedicated_scratch ? scratch_doubles(N) : 0);
     }
 
-    __device__ __forceinline__ void load_u(const double *u, const double *, int k, double (&uk)[nu]) const {
-#pragma unroll
-        for (int c = 0; c < nu; ++c)
-            uk[c] = u[nu * k + c];
-    }
-    __device__ __forceinline__ void store_x(int k, const double (&s)[nx]) const {
-        if (lane == 0)
-#pragma unroll
-            for (int l = 0; l < nx; ++l)
-                X[k * nx + l] = s[l];
-    }
-    __device__ __forceinline__ void load_x(int k, double (&s)[nx]) const {
-#pragma unroll
-        for (int l = 0; l < nx; ++l)
-            s[l] = X[k * nx + l];
-    }
-    __device__ __forceinline__ void store_yh(double *yh, int j, double v) const {
-        if (lane == 0)
-            yh[j] = v;
-    }
-    __device__ __forceinline__ void load_yh(const double *yh, int k, double (&o)[nc]) const {
-#pragma unroll
-        for (int i = 0; i < nc; ++i)
-            o[i] = yh[nc * k + i];
-    }
-
-    /// One RK4 step.  UNIFORM: the state's values are the same on every lane (Trig by trig_uniform);
-    /// t1 = Trig of s, which the caller usually needs as well.  tg (UNIFORM only, may be null): the
-    /// stage's trig store; the values of substages 1..3 are written to tg[3], tg[6], tg[9] ...
-    template <bool UNIFORM, class T>
+    /// One RK4 step of the full state, every lane on its own state (the simulate kernel); t1 = Trig of s.
+    /// The sweeps of the solver never take this path: they integrate the cascade (forward_cascade).
+    template <class T>
     __device__ __forceinline__ void rk4(const typename M::template Trig<T> &t1, const T (&s)[nx], const T (&u)[nu],
-                                        T (&xn)[nx], double2 *tg = nullptr) const {
+                                        T (&xn)[nx]) const {
         T k1[nx], k2[nx], k3[nx], k4[nx], w[nx];
-        auto trig_sub = [&](int j) {
-            if constexpr (UNIFORM)
-                return M::trig_uniform(w, tg ? tg + 3 * j : nullptr);
-            else
-                return M::trig(w);
-        };
         M::fc(t1, s, u, k1);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             w[l] = madd(M::hTs, k1[l], s[l]);
-        M::fc(trig_sub(1), w, u, k2);
+        M::fc(M::trig(w), w, u, k2);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             w[l] = madd(M::hTs, k2[l], s[l]);
-        M::fc(trig_sub(2), w, u, k3);
+        M::fc(M::trig(w), w, u, k3);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             w[l] = madd(M::Ts, k3[l], s[l]);
-        M::fc(trig_sub(3), w, u, k4);
+        M::fc(M::trig(w), w, u, k4);
 #pragma unroll
         for (int l = 0; l < nx; ++l)
             xn[l] = madd(M::c6, madd(2.0, k3[l], madd(2.0, k2[l], k1[l])) + k4[l], s[l]);
-    }
-    /// Adjoint of one RK4 step over the stored trigonometric values of its four substage states
-    /// (tg: the stage's entries of the trig store, written by the forward sweep at the same point):
-    /// fc_adj needs only those, the input and the incoming adjoints, so nothing of the forward pass
-    /// is evaluated again.  Values are the same on every lane.
-    __device__ __forceinline__ void rk4_adj_stored(const double2 *tg, const double (&u)[nu], const double (&mu)[nx],
-                                                   double (&sbar)[nx], double (&ubar)[nu]) const {
-        double kb1[nx], kb2[nx], kb3[nx], kb4[nx], a[nx], ua[nu];
-#pragma unroll
-        for (int l = 0; l < nx; ++l) {
-            double sg = M::c6 * mu[l];
-            kb1[l]    = sg;
-            kb2[l]    = 2.0 * sg;
-            kb3[l]    = 2.0 * sg;
-            kb4[l]    = sg;
-            sbar[l]   = mu[l];
-        }
-        M::fc_adj(M::trig_load(tg + 9), u, kb4, a, ubar);
-#pragma unroll
-        for (int l = 0; l < nx; ++l) {
-            sbar[l] = sbar[l] + a[l];
-            kb3[l]  = madd(M::Ts, a[l], kb3[l]);
-        }
-        M::fc_adj(M::trig_load(tg + 6), u, kb3, a, ua);
-#pragma unroll
-        for (int c = 0; c < nu; ++c)
-            ubar[c] = ubar[c] + ua[c];
-#pragma unroll
-        for (int l = 0; l < nx; ++l) {
-            sbar[l] = sbar[l] + a[l];
-            kb2[l]  = madd(M::hTs, a[l], kb2[l]);
-        }
-        M::fc_adj(M::trig_load(tg + 3), u, kb2, a, ua);
-#pragma unroll
-        for (int c = 0; c < nu; ++c)
-            ubar[c] = ubar[c] + ua[c];
-#pragma unroll
-        for (int l = 0; l < nx; ++l) {
-            sbar[l] = sbar[l] + a[l];
-            kb1[l]  = madd(M::hTs, a[l], kb1[l]);
-        }
-        M::fc_adj(M::trig_load(tg), u, kb1, a, ua);
-#pragma unroll
-        for (int c = 0; c < nu; ++c)
-            ubar[c] = ubar[c] + ua[c];
-#pragma unroll
-        for (int l = 0; l < nx; ++l)
-            sbar[l] = sbar[l] + a[l];
     }
     /// The same step and its adjoint on dual numbers whose values and tangents differ per lane (one
     /// (stage, direction) pair per lane): the substage states are rebuilt for their tangents, the
@@ -283,11 +211,13 @@ struct ScalarALProblem {
             sbar[l] = sbar[l] + a[l];
     }
 
-    /// Forward sweep of a model whose attitude is an integrated input (quadcopter): the states form a
-    /// cascade angles -> velocities -> positions, so nothing but three short scans (one fma per stage
-    /// and component) is sequential; everything else is evaluated for all stages at once, lane = stage
-    /// (or lane = (stage, substage, angle) for the trigonometry).  Every scalar is computed by the
-    /// expression forward() below uses for it (same operands, same order), so the results - psi, the
+    /// Forward sweep.  The states form a cascade angles -> velocities -> positions, so little is
+    /// sequential: three short scans (one fma per stage and component) and, for realistic_quadcopter,
+    /// the attitude (A+B below as one stage-by-stage integration of the three angles; for quadcopter,
+    /// whose angle rates are inputs, A is a scan as well and B parallel).  Everything else is evaluated
+    /// for all stages at once, lane = stage (or lane = (stage, substage, angle) for the trigonometry).
+    /// Every scalar is computed by the expression a stage-by-stage RK4 sweep over the full state uses
+    /// for it (oracle: SingleShootingAL::forward; same operands, same order), so the results - psi, the
     /// trajectory, yhat, the trig store - are the same bits:
     ///   A  angles:     a_{k+1} = fma(c6, fma(2,w,fma(2,w,w)) + w, a_k), w = u_k[1+j]        (scan)
     ///   B  sin/cos of the substage angles a_k, fma(Ts/2,w,a_k) (twice), fma(Ts,w,a_k)      (parallel)
@@ -297,8 +227,8 @@ struct ScalarALProblem {
     ///   F  positions:  p_{k+1} = fma(c6, E_k, p_k)                                        (scan)
     ///   G  constraints, multiplier estimates, stage costs                                (parallel)
     ///   H  the two sums psi is made of, in stage order                                   (scan)
-    /// Scratch: rows of the tangent trajectory Xt (accelerations, combinations) and scr (5 doubles per
-    /// stage: the four augmented-Lagrangian products and the stage cost).
+    /// Scratch: rows of the tangent trajectory Xt (accelerations) and scr (5 doubles per stage: the four
+    /// augmented-Lagrangian products and the stage cost; then 3 per stage: the combined slopes).
     __device__ __forceinline__ double forward_cascade(const double *u, double *yh) const {
         wave_sync();
         const double *yS = mvec(MV_YS), *Sig = mvec(MV_SIG);
@@ -326,66 +256,102 @@ struct ScalarALProblem {
             }
             X[N * nx + off + j3] = acc;
         };
-        // ---- A: angles ----
-        scan(6, [&](int k) {
-            const double w = u[nu * k + 1 + j3];
-            return madd(2.0, w, madd(2.0, w, w)) + w;
-        });
-        wave_sync();
-        // ---- B: trigonometry of every substage state: task = (stage, {s, s + Ts/2 k, s + Ts k}, angle) ----
-        for (int base = 0; base < 9 * (N + 1); base += WAVE) {
-            const int t = base + lane, k = t / 9, r = t - 9 * k, sub = r / 3, j = r - 3 * sub;
-            if (t < 9 * (N + 1) && (k < N || sub == 0)) {
-                const double a = X[k * nx + 6 + j];
-                const double w = k < N ? u[nu * k + 1 + j] : 0.0;
-                const double val = sub == 0 ? a : sub == 1 ? madd(M::hTs, w, a) : madd(M::Ts, w, a);
-                double sv, cv;
-                sincos_det(val, sv, cv);
-                double2 *tg = TG + 12 * k;
-                if (sub == 0) {
-                    tg[j] = make_double2(sv, cv);
-                } else if (sub == 1) { // the second and third substage states have the same angles
-                    tg[3 + j] = make_double2(sv, cv);
-                    tg[6 + j] = make_double2(sv, cv);
-                } else {
-                    tg[9 + j] = make_double2(sv, cv);
+        if constexpr (M::angles_are_integrated_inputs) {
+            // ---- A: angles ----
+            scan(6, [&](int k) {
+                const double w = u[nu * k + 1 + j3];
+                return madd(2.0, w, madd(2.0, w, w)) + w;
+            });
+            wave_sync();
+            // ---- B: trigonometry of every substage state: task = (stage, {s, s + Ts/2 k, s + Ts k}, angle) ----
+            for (int base = 0; base < 9 * (N + 1); base += WAVE) {
+                const int t = base + lane, k = t / 9, r = t - 9 * k, sub = r / 3, j = r - 3 * sub;
+                if (t < 9 * (N + 1) && (k < N || sub == 0)) {
+                    const double a = X[k * nx + 6 + j];
+                    const double w = k < N ? u[nu * k + 1 + j] : 0.0;
+                    const double val = sub == 0 ? a : sub == 1 ? madd(M::hTs, w, a) : madd(M::Ts, w, a);
+                    double sv, cv;
+                    sincos_det(val, sv, cv);
+                    double2 *tg = TG + 12 * k;
+                    if (sub == 0) {
+                        tg[j] = make_double2(sv, cv);
+                    } else if (sub == 1) { // the second and third substage states have the same angles
+                        tg[3 + j] = make_double2(sv, cv);
+                        tg[6 + j] = make_double2(sv, cv);
+                    } else {
+                        tg[9 + j] = make_double2(sv, cv);
+                    }
                 }
             }
+        } else {
+            // ---- A+B: the attitude, stage by stage (values the same on every lane; sin/cos: one angle per
+            //      lane and a broadcast), leaving the angle rows of X and the trig store ----
+            double a[3] = {x0[6], x0[7], x0[8]}, uk[nu], un[nu];
+#pragma unroll
+            for (int c = 0; c < nu; ++c)
+                un[c] = u[c];
+            for (int k = 0; k < N; ++k) {
+#pragma unroll
+                for (int c = 0; c < nu; ++c)
+                    uk[c] = un[c];
+                if (k + 1 < N)
+#pragma unroll
+                    for (int c = 1; c < nu; ++c)
+                        un[c] = u[nu * (k + 1) + c];
+                X[k * nx + 6 + j3] = j3 == 0 ? a[0] : j3 == 1 ? a[1] : a[2];
+                double2 *tg = TG + 12 * k;
+                double k1[3], k2[3], k3[3], k4[3];
+                M::angle_rates(M::trig_uniform(a[0], a[1], a[2], tg), uk, k1);
+                M::angle_rates(M::trig_uniform(madd(M::hTs, k1[0], a[0]), madd(M::hTs, k1[1], a[1]),
+                                               madd(M::hTs, k1[2], a[2]), tg + 3), uk, k2);
+                M::angle_rates(M::trig_uniform(madd(M::hTs, k2[0], a[0]), madd(M::hTs, k2[1], a[1]),
+                                               madd(M::hTs, k2[2], a[2]), tg + 6), uk, k3);
+                M::angle_rates(M::trig_uniform(madd(M::Ts, k3[0], a[0]), madd(M::Ts, k3[1], a[1]),
+                                               madd(M::Ts, k3[2], a[2]), tg + 9), uk, k4);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    a[j] = madd(M::c6, madd(2.0, k3[j], madd(2.0, k2[j], k1[j])) + k4[j], a[j]);
+            }
+            X[N * nx + 6 + j3] = j3 == 0 ? a[0] : j3 == 1 ? a[1] : a[2];
+            M::trig_uniform(a[0], a[1], a[2], TG + 12 * N);
         }
         wave_sync();
-        // ---- C: accelerations (rows of Xt: a1 | a2 = a3 | combination) ----
+        // ---- C: accelerations of the four substages (rows of Xt: a1 | a2 | a3) and their combination (cmb) ----
+        double *cmb = scr + 5 * (N + 1);
         for (int k = lane; k < N; k += WAVE) {
             const double2 *tg = TG + 12 * k;
             const double u0 = u[nu * k];
-            double a1[3], a2[3], a4[3];
+            double a1[3], a2[3], a3[3], a4[3];
             M::accel(M::trig_load(tg), u0, a1);
             M::accel(M::trig_load(tg + 3), u0, a2);
+            M::accel(M::trig_load(tg + 6), u0, a3);
             M::accel(M::trig_load(tg + 9), u0, a4);
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 Xt[k * nx + m]     = a1[m];
                 Xt[k * nx + 3 + m] = a2[m];
-                Xt[k * nx + 6 + m] = madd(2.0, a2[m], madd(2.0, a2[m], a1[m])) + a4[m];
+                Xt[k * nx + 6 + m] = a3[m];
+                cmb[3 * k + m]     = madd(2.0, a3[m], madd(2.0, a2[m], a1[m])) + a4[m];
             }
         }
         wave_sync();
         // ---- D: velocities ----
-        scan(3, [&](int k) { return Xt[k * nx + 6 + j3]; });
+        scan(3, [&](int k) { return cmb[3 * k + j3]; });
         wave_sync();
-        // ---- E: position slopes, combined (over the combination row of Xt) ----
+        // ---- E: position slopes, combined ----
         for (int k = lane; k < N; k += WAVE) {
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const double v  = X[k * nx + 3 + m];
                 const double k2 = madd(M::hTs, Xt[k * nx + m], v);
                 const double k3 = madd(M::hTs, Xt[k * nx + 3 + m], v);
-                const double k4 = madd(M::Ts, Xt[k * nx + 3 + m], v);
-                Xt[k * nx + 6 + m] = madd(2.0, k3, madd(2.0, k2, v)) + k4;
+                const double k4 = madd(M::Ts, Xt[k * nx + 6 + m], v);
+                cmb[3 * k + m]  = madd(2.0, k3, madd(2.0, k2, v)) + k4;
             }
         }
         wave_sync();
         // ---- F: positions ----
-        scan(0, [&](int k) { return Xt[k * nx + 6 + j3]; });
+        scan(0, [&](int k) { return cmb[3 * k + j3]; });
         wave_sync();
         // ---- G: constraints, multiplier estimates, costs ----
         for (int k = lane; k <= N; k += WAVE) {
@@ -442,54 +408,18 @@ struct ScalarALProblem {
     }
 
     /// Forward sweep: psi, trajectory, yhat, and the trig store of every substage state.
-    __device__ __forceinline__ double forward(const double *u, double *yh) const {
-        if constexpr (M::angles_are_integrated_inputs)
-            return forward_cascade(u, yh);
-        wave_sync();
-        const double *yS = mvec(MV_YS), *Sig = mvec(MV_SIG);
-        double s[nx], xn[nx], c[nc], uk[nu], yhv[nc];
-#pragma unroll
-        for (int l = 0; l < nx; ++l)
-            s[l] = x0[l];
-        double accf = 0.0, accal = 0.0;
-        for (int k = 0; k <= N; ++k) {
-            double2 *tg  = TG + 12 * k;
-            const auto t1 = M::trig_uniform(s, tg);
-            M::constr(t1, s, c);
-#pragma unroll
-            for (int i = 0; i < nc; ++i) {
-                int j       = nc * k + i;
-                double zeta = c[i] + yS[j]; // y / Sigma: set_al()
-                double zhat = tmax(tmin(zeta, box->d_ub[i]), box->d_lb[i]);
-                double d    = zeta - zhat;
-                yhv[i]      = Sig[j] * d;
-                accal       = accal + (yhv[i] * d);
-            }
-            store_x(k, s); // one lane-0 block per stage: state row and multiplier estimates
-#pragma unroll
-            for (int i = 0; i < nc; ++i)
-                store_yh(yh, nc * k + i, yhv[i]);
-            if (k == N)
-                break;
-            load_u(u, nullptr, k, uk);
-            accf = accf + M::stage_cost(s, uk);
-            rk4<true>(t1, s, uk, xn, tg);
-#pragma unroll
-            for (int l = 0; l < nx; ++l)
-                s[l] = xn[l];
-        }
-        accf = accf + M::term_cost(s);
-        wave_sync();
-        return accf + (0.5 * accal);
-    }
-    /// Adjoint sweep of a model whose attitude is an integrated input (quadcopter), as a cascade in the
-    /// opposite direction: position adjoints feed the velocity adjoints feed the angle adjoints, and no
-    /// adjoint feeds back.  Sequential: three scans of a few dependent additions per stage and
-    /// component (operands fetched eight stages ahead).  All the rest - the substage adjoints of f_c
-    /// with their trigonometric coefficients, the input gradients - is evaluated for all stages at once,
-    /// lane = stage, by the very functions reverse() calls (M::fc_adj), on the operands reverse() would
-    /// hand them.  Value for value the arithmetic of reverse() (what it adds of exact zeros - the
-    /// position adjoint of f_c is 0 * u_0 - is skipped: same values, possibly another sign of a zero).
+    __device__ __forceinline__ double forward(const double *u, double *yh) const { return forward_cascade(u, yh); }
+    /// Adjoint sweep, as a cascade in the opposite direction: position adjoints feed the velocity
+    /// adjoints feed the angle adjoints, and no adjoint feeds back.  Sequential: scans of a few
+    /// dependent additions per stage and component (operands fetched eight stages ahead); for
+    /// realistic_quadcopter the angle adjoints chain through the four substage adjoints of the angle
+    /// rates instead (phase 4 as a stage-by-stage recursion over coefficients phase 3 has prepared).
+    /// All the rest - the substage adjoints of f_c with their trigonometric coefficients, the input
+    /// gradients - is evaluated for all stages at once, lane = stage, by the pieces M::fc_adj is made
+    /// of, on the operands a stage-by-stage adjoint sweep would hand them (oracle:
+    /// SingleShootingAL::reverse).  Value for value the same arithmetic (what that sweep adds of exact
+    /// zeros - the position adjoint of f_c is 0 * u_0 - is skipped: same values, possibly another sign
+    /// of a zero).
     ///   1  lam_p(k) = (lam_p(k+1) + dl/dp) - (dc/dp)' yhat                                       (scan)
     ///   2  lam_v(k) = ((((lam_v + sg) + 2 sg) + 2 sg) + sg) + dl/dv,   sg = c6 lam_p(k+1)         (scan)
     ///   3  velocity parts of the four substage adjoint seeds, fc_adj on them: A_s (angle parts), u_0 gradient
@@ -572,7 +502,7 @@ struct ScalarALProblem {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 kb[3 + i] = sgv[i];
-            M::fc_adj(M::trig_load(tg + 9), uk, kb, sb, ub);
+            M::fc_adj_translation(M::trig_load(tg + 9), uk, kb, sb, ub);
             ub0[0] = ub[0];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -581,7 +511,7 @@ struct ScalarALProblem {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 kb[3 + i] = madd(M::Ts, sgp[i], 2.0 * sgv[i]);
-            M::fc_adj(M::trig_load(tg + 6), uk, kb, sb, ub);
+            M::fc_adj_translation(M::trig_load(tg + 6), uk, kb, sb, ub);
             ub0[1] = ub[0];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -590,7 +520,7 @@ struct ScalarALProblem {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 kb[3 + i] = madd(M::hTs, 2.0 * sgp[i], 2.0 * sgv[i]);
-            M::fc_adj(M::trig_load(tg + 3), uk, kb, sb, ub);
+            M::fc_adj_translation(M::trig_load(tg + 3), uk, kb, sb, ub);
             ub0[2] = ub[0];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -599,16 +529,28 @@ struct ScalarALProblem {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 kb[3 + i] = madd(M::hTs, 2.0 * sgp[i], sgv[i]);
-            M::fc_adj(M::trig_load(tg), uk, kb, sb, ub);
+            M::fc_adj_translation(M::trig_load(tg), uk, kb, sb, ub);
             ub0[3] = ub[0];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
                 A[9 + j] = sb[6 + j];
             A[12] = ((ub0[0] + ub0[1]) + ub0[2]) + ub0[3];
+            if constexpr (!M::angles_are_integrated_inputs) {
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) { // in the order the recursion visits them: substage 4 first
+                    const auto c = M::angle_rates_adj_coef(M::trig_load(tg + 9 - 3 * sub), uk);
+                    double *o    = coef + COEF * k + 5 * sub;
+                    o[0] = c.ic;
+                    o[1] = c.x;
+                    o[2] = c.y;
+                    o[3] = c.num;
+                    o[4] = c.z;
+                }
+            }
         }
         wave_sync();
         // ---- 4: angle adjoints ----
-        {
+        if constexpr (M::angles_are_integrated_inputs) {
             // (dc/da)' yhat of stage k on this lane's angle: c_0 = phi, c_1 = theta, c_2 = cos phi cos theta
             auto constr_term = [&](int k) {
                 const auto t      = M::trig_load(TG + 12 * k);
@@ -631,6 +573,81 @@ struct ScalarALProblem {
                     const double l = ((((mu + o.a4) + o.a3) + o.a2) + o.a1) + o.g;
                     return j3 < 2 ? l + o.c : l;
                 });
+        } else {
+            // the angle rates depend on the angles: the four substage adjoints of a stage chain through
+            // angle_rates_adj (values the same on every lane), on top of the A_s of phase 3; this is also
+            // where the gradients of the three rate inputs come from
+            auto sel3 = [&](const double (&v)[3]) { return j3 == 0 ? v[0] : j3 == 1 ? v[1] : v[2]; };
+            auto constr_adj_angles = [&](int k, double (&l)[3]) {
+                const auto t     = M::trig_load(TG + 12 * k);
+                const double *yb = yh + nc * k;
+                l[0] = l[0] + (yb[0] - ((t.s0 * t.c1) * yb[2]));
+                l[1] = l[1] + (yb[1] - ((t.c0 * t.s1) * yb[2]));
+            };
+            double mu[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                mu[j] = 0.0 + (2.0 * 10.0) * X[N * nx + 6 + j];
+            constr_adj_angles(N, mu);
+            for (int k = N - 1; k >= 0; --k) {
+                LAM[(k + 1) * nx + 6 + j3] = sel3(mu);
+                const double *A   = scr + 13 * k;
+                const double2 *tg = TG + 12 * k;
+                auto rates_adj    = [&](int sub, const double (&kba)[3], double (&sba)[3], double (&uba)[3]) {
+                    const double *o  = coef + COEF * k + 5 * sub;
+                    const double2 e0 = tg[9 - 3 * sub], e1 = tg[10 - 3 * sub]; // (sin, cos) of phi, theta
+                    M::angle_rates_adj_apply(e0.x, e1.x, e1.y, typename M::template RateAdjCoef<double>{o[0], o[1], o[2], o[3], o[4]},
+                                             kba, sba, uba);
+                };
+                double uk[nu], kb1[3], kb2[3], kb3[3], kb4[3], sbar[3], a[3], ubar[3], ua[3];
+#pragma unroll
+                for (int c = 0; c < nu; ++c)
+                    uk[c] = u[nu * k + c];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double sg = M::c6 * mu[j];
+                    kb1[j]  = sg;
+                    kb2[j]  = 2.0 * sg;
+                    kb3[j]  = 2.0 * sg;
+                    kb4[j]  = sg;
+                    sbar[j] = mu[j];
+                    a[j]    = A[j];
+                }
+                rates_adj(0, kb4, a, ubar);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    sbar[j] = sbar[j] + a[j];
+                    kb3[j]  = madd(M::Ts, a[j], kb3[j]);
+                    a[j]    = A[3 + j];
+                }
+                rates_adj(1, kb3, a, ua);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    ubar[j] = ubar[j] + ua[j];
+                    sbar[j] = sbar[j] + a[j];
+                    kb2[j]  = madd(M::hTs, a[j], kb2[j]);
+                    a[j]    = A[6 + j];
+                }
+                rates_adj(2, kb2, a, ua);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    ubar[j] = ubar[j] + ua[j];
+                    sbar[j] = sbar[j] + a[j];
+                    kb1[j]  = madd(M::hTs, a[j], kb1[j]);
+                    a[j]    = A[9 + j];
+                }
+                rates_adj(3, kb1, a, ua);
+                double g[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    ubar[j] = ubar[j] + ua[j];
+                    sbar[j] = sbar[j] + a[j];
+                    mu[j]   = sbar[j] + (2.0 * 1.0) * X[k * nx + 6 + j];
+                    g[j]    = ubar[j] + ((2e-4 * uk[1 + j]) + (20.0 * uk[1 + j]));
+                }
+                grad[nu * k + 1 + j3] = sel3(g);
+                constr_adj_angles(k, mu);
+            }
         }
         wave_sync();
         // ---- 5: gradients (lane = stage) ----
@@ -638,57 +655,28 @@ struct ScalarALProblem {
             const double *A = scr + 13 * k;
             const double u0 = u[nu * k];
             grad[nu * k] = A[12] + (2e-4 * u0);
+            if constexpr (M::angles_are_integrated_inputs) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const double sga = M::c6 * LAM[(k + 1) * nx + 6 + j];
-                const double kb4 = sga;
-                const double kb3 = madd(M::Ts, A[j], 2.0 * sga);
-                const double kb2 = madd(M::hTs, A[3 + j], 2.0 * sga);
-                const double kb1 = madd(M::hTs, A[6 + j], sga);
-                const double uj  = u[nu * k + 1 + j];
-                grad[nu * k + 1 + j] = (((kb4 + kb3) + kb2) + kb1) + ((2e-4 * uj) + (20.0 * uj));
+                for (int j = 0; j < 3; ++j) {
+                    const double sga = M::c6 * LAM[(k + 1) * nx + 6 + j];
+                    const double kb4 = sga;
+                    const double kb3 = madd(M::Ts, A[j], 2.0 * sga);
+                    const double kb2 = madd(M::hTs, A[3 + j], 2.0 * sga);
+                    const double kb1 = madd(M::hTs, A[6 + j], sga);
+                    const double uj  = u[nu * k + 1 + j];
+                    grad[nu * k + 1 + j] = (((kb4 + kb3) + kb2) + kb1) + ((2e-4 * uj) + (20.0 * uj));
+                }
             }
         }
         wave_sync();
     }
 
-    /// Adjoint sweep over the stored trajectory and trig store with multipliers yh: grad_i.  STORE_LAM:
-    /// the adjoints lam_{k+1} every stage receives are kept (rows of LAM, which shares the tangent
-    /// trajectory's LDS) for the second-order recording.
+    /// Adjoint sweep over the stored trajectory and trig store with multipliers yh: grad_i; the adjoints
+    /// lam_{k+1} every stage receives are left in LAM (which shares the tangent trajectory's LDS) for the
+    /// second-order recording.
     template <bool STORE_LAM>
     __device__ __forceinline__ void reverse(const double *u, const double *yh, double *grad) const {
-        if constexpr (M::angles_are_integrated_inputs)
-            return reverse_cascade(u, yh, grad);
-        wave_sync();
-        double lam[nx], sbar[nx], ubar[nu], gu[nu], s[nx], uk[nu], yk[nc];
-#pragma unroll
-        for (int l = 0; l < nx; ++l)
-            lam[l] = 0.0;
-        load_x(N, s);
-        M::cost_grad(s, static_cast<const double *>(nullptr), lam, gu);
-        load_yh(yh, N, yk);
-        M::constr_adj(M::trig_load(TG + 12 * N), s, yk, lam);
-        for (int k = N - 1; k >= 0; --k) {
-            if (STORE_LAM && lane == 0)
-#pragma unroll
-                for (int l = 0; l < nx; ++l)
-                    Xt[(k + 1) * nx + l] = lam[l];
-            load_x(k, s);
-            load_u(u, nullptr, k, uk);
-            const double2 *tg = TG + 12 * k;
-            rk4_adj_stored(tg, uk, lam, sbar, ubar);
-#pragma unroll
-            for (int l = 0; l < nx; ++l)
-                lam[l] = sbar[l];
-            M::cost_grad(s, uk, lam, gu);
-            if (lane == 0)
-#pragma unroll
-                for (int c = 0; c < nu; ++c)
-                    grad[nu * k + c] = ubar[c] + gu[c];
-            load_yh(yh, k, yk);
-            M::constr_adj(M::trig_load(tg), s, yk, lam);
-        }
-        wave_sync();
+        reverse_cascade(u, yh, grad);
     }
 
     // ---- the interface pantr_inner() drives ----------------------------------------------------
@@ -1113,7 +1101,8 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
         pb.x0 = x0_lds;
         // scratch of the cascade sweeps: PANTR lends the CG vectors z, r, d, Bd (dead outside the direction
         // computation); the comparators keep L-BFGS scalars in the CG block and get LDS of their own
-        pb.scr = METHOD == 0 ? pb.vec(PB::CG_BASE + 3) : x0_lds + PB::X0_DOUBLES;
+        pb.coef = x0_lds + PB::X0_DOUBLES;
+        pb.scr  = METHOD == 0 ? pb.vec(PB::CG_BASE + 3) : pb.coef + PB::coef_doubles(a.N);
     }
     double *x_io = pb.vec(S_XIO), *y = pb.mvec(PB::MV_Y), *Sig = pb.mvec(PB::MV_SIG), *e1 = pb.mvec(PB::MV_E1),
            *e2 = pb.mvec(PB::MV_E2);
@@ -1262,7 +1251,8 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
         if (lane < M::nx)
             x0_lds[lane] = a.x0[(size_t)inst * M::nx + lane];
         pb.x0 = x0_lds;
-        pb.scr = pb.vec(PB::CG_BASE + 3); // four vector slots this kernel does not use
+        pb.coef = x0_lds + PB::X0_DOUBLES;
+        pb.scr  = pb.vec(PB::CG_BASE + 3); // four vector slots this kernel does not use
     }
     double *u = pb.vec(0), *v = pb.vec(1), *o = pb.vec(2);
     for (int i = lane; i < a.n; i += WAVE) {
@@ -1325,7 +1315,7 @@ __global__ void pantr_scalar_simulate_kernel(int B, const double *x, const doubl
         s[l] = x[(size_t)inst * M::nx + l];
     for (int c = 0; c < M::nu; ++c)
         uk[c] = u[(size_t)inst * u_stride + c];
-    pb.template rk4<false>(M::trig(s), s, uk, r); // one instance per lane: no wave-uniform shortcuts
+    pb.rk4(M::trig(s), s, uk, r); // one instance per lane: no wave-uniform shortcuts
     for (int l = 0; l < M::nx; ++l)
         xn[(size_t)inst * M::nx + l] = r[l];
 }

@@ -19,8 +19,10 @@ namespace pantr {
 template <bool REALISTIC>
 struct QuadModelT {
     static constexpr int nx = 9, nu = 4, nc = 4;
-    /// The attitude does not feed back into its own dynamics (the angle rates are inputs): the states
-    /// form a cascade angles -> velocities -> positions, which ScalarALProblem::forward_cascade uses.
+    /// Both models are a cascade angles -> velocities -> positions (the attitude does not depend on the
+    /// translation), which ScalarALProblem's sweeps use.  In quadcopter the angle rates are inputs, so
+    /// the attitude is a plain sum over the stages; in realistic_quadcopter they depend on the angles
+    /// and the attitude is integrated stage by stage.
     static constexpr bool angles_are_integrated_inputs = !REALISTIC;
     static constexpr double Ts = 0.1, hTs = 0.5 * Ts, g_grav = 9.81, c6 = Ts / 6;
     static constexpr double r2 = 0.1 * 0.1; ///< collision cylinder radius squared (quadcopter.py:70)
@@ -88,14 +90,6 @@ struct QuadModelT {
         return {{v.s0, v.c0 * t0}, {v.c0, -(v.s0 * t0)}, {v.s1, v.c1 * t1},
                 {v.c1, -(v.s1 * t1)}, {v.s2, v.c2 * t2}, {v.c2, -(v.s2 * t2)}};
     }
-    template <bool UNIFORM, class T>
-    __device__ static __forceinline__ Trig<T> trig_of(const T *s) {
-        if constexpr (UNIFORM)
-            return trig_uniform(s);
-        else
-            return trig(s);
-    }
-
     /// Acceleration of the stage at thrust u0 for the attitude t: the expressions of fc() for ds[3..5].
     __device__ static __forceinline__ void accel(const Trig<double> &t, double u0, double (&a)[3]) {
         double r0, r1, r2_;
@@ -132,23 +126,38 @@ struct QuadModelT {
         ds[3] = r0 * u[0];
         ds[4] = r1 * u[0];
         ds[5] = (r2_ * u[0]) - g_grav;
+        angle_rates(t, u, ds + 6);
+    }
+    /// Rates of the three angles, ds[6..8] of f_c: the body rates themselves (quadcopter) or mapped
+    /// through the inverse Euler-rate matrix (realistic_quadcopter).  They depend on the angles and the
+    /// inputs only, which is what lets the sweeps integrate the attitude ahead of everything else.
+    template <class T>
+    __device__ static __forceinline__ void angle_rates(const Trig<T> &t, const T *u, T *da) {
         if (!REALISTIC) {
-            ds[6] = u[1];
-            ds[7] = u[2];
-            ds[8] = u[3];
+            da[0] = u[1];
+            da[1] = u[2];
+            da[2] = u[3];
         } else { // Omega [a b c]' = omega, Omega = [[c1,0,-c0 s1],[0,1,s0],[s1,0,c0 c1]], det = c0
             T a   = (t.c1 * u[1]) + (t.s1 * u[3]);
             T cc  = ((t.c1 * u[3]) - (t.s1 * u[1])) / t.c0;
             T b   = u[2] - (t.s0 * cc);
-            ds[6] = a;
-            ds[7] = b;
-            ds[8] = cc;
+            da[0] = a;
+            da[1] = b;
+            da[2] = cc;
         }
     }
 
     /// Adjoint of f_c: sb = (df/ds)' kb, ub = (df/du)' kb.
     template <class T>
     __device__ static __forceinline__ void fc_adj(const Trig<T> &t, const T *u, const T *kb, T *sb, T *ub) {
+        fc_adj_translation(t, u, kb, sb, ub);
+        angle_rates_adj(t, u, kb + 6, sb + 6, ub + 1);
+    }
+    /// The part of fc_adj that the position and velocity rows of f_c contribute: all of sb, and ub[0]
+    /// (the thrust); it reads kb[0..5] only.
+    template <class T>
+    __device__ static __forceinline__ void fc_adj_translation(const Trig<T> &t, const T *u, const T *kb, T *sb,
+                                                              T *ub) {
         const T at = u[0];
         T r0, r1, r2_, dr0[3], dr1[3], dr2[3]; // d r_i / d s[6+j]
         if (!REALISTIC) {
@@ -189,25 +198,49 @@ struct QuadModelT {
         const T w0 = at * a0, w1 = at * a1, w2 = at * a2;
         for (int j = 0; j < 3; ++j)
             sb[6 + j] = ((dr0[j] * w0) + (dr1[j] * w1)) + (dr2[j] * w2);
+    }
+    /// Adjoint of angle_rates: with kba = kb[6..8], adds (d rates / d angles)' kba to sba = sb[6..8]
+    /// and returns uba = ub[1..3] = (d rates / d u[1..3])' kba.  In two steps: what depends on the
+    /// substage state and the inputs only (RateAdjCoef: the adjoint sweep evaluates it for all stages
+    /// at once), and the products with the incoming adjoint.
+    template <class T>
+    struct RateAdjCoef {
+        T ic, x, y, num, z;
+    };
+    template <class T>
+    __device__ static __forceinline__ RateAdjCoef<T> angle_rates_adj_coef(const Trig<T> &t, const T *u) {
+        // a = c1 u1 + s1 u3 ; cc = (c1 u3 - s1 u1)/c0 ; b = u2 - s0 cc
+        RateAdjCoef<T> k;
+        k.num      = (t.c1 * u[3]) - (t.s1 * u[1]);
+        k.ic       = 1.0 / t.c0; // one reciprocal serves the three quotients by cos(phi)
+        const T cc = k.num * k.ic;
+        k.x        = (cc * t.s0) * k.ic; // d cc / d phi = num s0 / c0^2
+        k.y        = t.c0 * cc;          // -d b / d phi at fixed cc
+        k.z        = (t.s1 * u[3]) + (t.c1 * u[1]); // -d num / d theta
+        return k;
+    }
+    template <class T>
+    __device__ static __forceinline__ void angle_rates_adj_apply(const T &s0, const T &s1, const T &c1,
+                                                                 const RateAdjCoef<T> &k, const T *kba, T *sba,
+                                                                 T *uba) {
+        const T ka = kba[0], kb_ = kba[1], kc = kba[2];
+        const T kcc = kc - (s0 * kb_); // total adjoint of cc
+        const T q   = kcc * k.ic;      // adjoint of num
+        uba[0] = (c1 * ka) - (s1 * q);
+        uba[1] = kb_;
+        uba[2] = (s1 * ka) + (c1 * q);
+        sba[0] = sba[0] + ((k.x * kcc) - (k.y * kb_));
+        sba[1] = sba[1] + ((k.num * ka) - (k.z * q)); // a -> num ka ; num -> -z q
+    }
+    template <class T>
+    __device__ static __forceinline__ void angle_rates_adj(const Trig<T> &t, const T *u, const T *kba, T *sba,
+                                                           T *uba) {
         if (!REALISTIC) {
-            ub[1] = kb[6];
-            ub[2] = kb[7];
-            ub[3] = kb[8];
+            uba[0] = kba[0];
+            uba[1] = kba[1];
+            uba[2] = kba[2];
         } else {
-            // a = c1 u1 + s1 u3 ; cc = (c1 u3 - s1 u1)/c0 ; b = u2 - s0 cc
-            const T ka = kb[6], kb_ = kb[7], kc = kb[8];
-            const T num = (t.c1 * u[3]) - (t.s1 * u[1]);
-            const T ic  = 1.0 / t.c0;          // one reciprocal serves the three quotients by cos(phi)
-            const T cc  = num * ic;
-            const T kcc = kc - (t.s0 * kb_);   // total adjoint of cc
-            const T q   = kcc * ic;            // adjoint of num
-            ub[1] = (t.c1 * ka) - (t.s1 * q);
-            ub[2] = kb_;
-            ub[3] = (t.s1 * ka) + (t.c1 * q);
-            // d/dphi (s[6]): b -> -c0 cc kb_ ; cc = num/c0 -> num s0/c0^2 = cc s0/c0
-            sb[6] = sb[6] + ((((cc * t.s0) * ic) * kcc) - ((t.c0 * cc) * kb_));
-            // d/dtheta (s[7]): a -> (-s1 u1 + c1 u3) ka = num ka ; num -> (-s1 u3 - c1 u1) q
-            sb[7] = sb[7] + ((num * ka) - (((t.s1 * u[3]) + (t.c1 * u[1])) * q));
+            angle_rates_adj_apply(t.s0, t.s1, t.c1, angle_rates_adj_coef(t, u), kba, sba, uba);
         }
     }
 
