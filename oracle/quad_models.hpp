@@ -68,6 +68,7 @@ inline Dual tmax(Dual a, double b) { return a.v > b ? a : Dual{b, 0.0}; }
 template <bool REALISTIC>
 struct QuadcopterT {
     static constexpr int nx = 9, nu = 4, nc = 4;
+    static constexpr bool realistic = REALISTIC;
     static constexpr double Ts = 0.1, hTs = 0.5 * Ts, g_grav = 9.81, c6 = Ts / 6;
     static constexpr double r2 = 0.1 * 0.1; ///< collision cylinder radius squared (quadcopter.py:70)
     static constexpr double pf[3] = {0.25, 0.25, 0.5}; // quadcopter.py:90
@@ -401,20 +402,32 @@ struct SingleShootingAL {
     }
 
     // ---- the second-order tape ------------------------------------------------------------------
-    // Recorded by grad_L (the point PANTR's Hessian-vector products follow).  With z = (x_k, u_k)
-    // (nz = nx + nu directions) and the multiplier estimate yhat_k(x_k) of the stage:
-    //   J_k[d][i] = d x_{k+1,i} / d z_d                            (dual RK4 step seeded with e_d)
-    //   H_k[d][l] = d/d z_d of the stage's adjoint outputs [lam_k ; grad_k] at fixed lam_{k+1}
-    //             = column d of  sum_i lam_{k+1,i} hess F_i + hess l + d(dc' yhat)/dz
-    // One dual evaluation of the stage per direction (the kernels run the nz directions on nz lanes
-    // of one sweep); the value parts of that evaluation are the ordinary adjoint sweep.
-    static constexpr int nz = nx + nu;
+    // Recorded by grad_L (the point PANTR's Hessian-vector products follow).  With z = (x_k, u_k),
+    // x = (p, v, a) (position, velocity, attitude), u = (thrust, w) and the multiplier estimate
+    // yhat_k(x_k) of the stage, a product needs
+    //   J_k = d x_{k+1} / d z                and
+    //   H_k = d/dz of the stage's adjoint outputs [lam_k ; grad_k] at fixed lam_{k+1}
+    //       = sum_i lam_{k+1,i} hess F_i + hess l + d(dc' yhat)/dz.
+    // Both have the block structure of the cascade attitude -> velocity -> position:
+    //   p+ = p + cpv v + Jp (a, u)     v+ = v + Jv (a, u)     a+ = Ja (a, w)  (quadcopter: a + cw w)
+    //   H  = blockdiag(Hpp, hvv I, Hau),  Hau over (a, u): 7 x 7
+    // (f_c is linear in p and v and the cost separates; the constraints touch p and a apart).  Only
+    // the nonzero blocks are recorded - one dual evaluation of the stage per direction of (a, u), a
+    // dual evaluation of the position terms of cost and constraints per direction of p; cpv = c6 * 6
+    // and hvv = 2 q_v are constants - and the product runs over these blocks, in the order written
+    // in hess_prod_tape() (which is the specification the kernels follow).
+    static constexpr int nz = nx + nu, nau = 3 + nu; ///< nau: directions (a_0..2, u_0..3)
+    static constexpr bool angle_rates_are_inputs = !Model::realistic;
     struct StageTape {
-        double J[nz][nx];
-        double H[nz][nz];
+        double Jp[3][nau], Jv[3][nau]; ///< d p+_i / d (a,u)_e, d v+_i / d (a,u)_e
+        double Ja[3][6];               ///< d a+_i / d (a_0..2, w_0..2)
+        double Hau[nau][nau];          ///< [l][e]: derivative along (a,u)_l of adjoint output (a,u)_e
+        double Hpp[3][3];              ///< [l][e]: derivative along p_l of adjoint output p_e
     };
     mutable std::vector<StageTape> tape_;
-    mutable double HN_[nx][nx];
+    mutable double HNpp_[3][3], HNaa_[3][3];
+    static constexpr double cpv = Model::c6 * 6.0; ///< d p+ / d v
+    static constexpr double hvv = 2.0 * 1.0, hvvN = 2.0 * 25.0; ///< d2 l / d v2, stage and terminal cost
     mutable std::vector<double> tape_u_;
     mutable bool tape_valid_ = false;
 
@@ -430,108 +443,234 @@ struct SingleShootingAL {
             yk[i]  = Sig[j] * d;
         }
     }
+    /// Derivative along state direction d of the state-only adjoint terms of stage k (cost gradient
+    /// and constraint adjoint with the multiplier estimate of the stage): row d of hess l + d(dc' yhat)/dx.
+    void state_terms_dual(const double *s_, const double *uk, int k, int d, Dual *lt) const {
+        Dual s[nx], yk[nc], gu[nu], ud[nu];
+        for (int l = 0; l < nx; ++l) {
+            s[l]  = {s_[l], l == d ? 1.0 : 0.0};
+            lt[l] = Dual{};
+        }
+        stage_multipliers(s, k, yk);
+        if (uk) {
+            for (int c = 0; c < nu; ++c)
+                ud[c] = {uk[c], 0.0};
+            Model::cost_grad(s, ud, lt, gu);
+        } else {
+            Model::cost_grad(s, static_cast<const Dual *>(nullptr), lt, gu);
+        }
+        Model::constr_adj(s, yk, lt);
+    }
     /// The adjoint sweep of reverse<double>() (same gradient, bit for bit) that also records the tape.
     void reverse_record(const double *u, const double *X, double *grad) const {
         tape_.resize(N);
         tape_u_.assign(u, u + n());
         tape_valid_ = true;
         double lam[nx];
-        for (int d = 0; d < nx; ++d) {
-            Dual s[nx], yk[nc], lt[nx], gu[nu];
-            for (int l = 0; l < nx; ++l) {
-                s[l]  = {X[N * nx + l], l == d ? 1.0 : 0.0};
-                lt[l] = Dual{};
-            }
-            stage_multipliers(s, N, yk);
-            Model::cost_grad(s, static_cast<const Dual *>(nullptr), lt, gu);
-            Model::constr_adj(s, yk, lt);
-            for (int l = 0; l < nx; ++l) {
-                HN_[d][l] = lt[l].t;
-                lam[l]    = lt[l].v;
+        {
+            double gu[nu];
+            for (int l = 0; l < nx; ++l)
+                lam[l] = 0.0;
+            Model::cost_grad(X + N * nx, static_cast<const double *>(nullptr), lam, gu);
+            std::vector<double> yN(nc);
+            stage_multipliers(X + N * nx, N, yN.data());
+            Model::constr_adj(X + N * nx, yN.data(), lam);
+            Dual lt[nx];
+            for (int d = 0; d < 3; ++d) {
+                state_terms_dual(X + N * nx, nullptr, N, d, lt);
+                for (int e = 0; e < 3; ++e)
+                    HNpp_[d][e] = lt[e].t;
+                state_terms_dual(X + N * nx, nullptr, N, 6 + d, lt);
+                for (int e = 0; e < 3; ++e)
+                    HNaa_[d][e] = lt[6 + e].t;
             }
         }
         for (int k = N - 1; k >= 0; --k) {
+            StageTape &tp = tape_[k];
             double lam_k[nx];
-            for (int d = 0; d < nz; ++d) {
+            for (int l = 0; l < nau; ++l) { // direction (a,u)_l = z_{6 + l}
+                const int d = 6 + l;
                 Dual s[nx], ud[nu], xn[nx], yk[nc], mu[nx], sbar[nx], ubar[nu], gu[nu];
-                for (int l = 0; l < nx; ++l) {
-                    s[l]  = {X[k * nx + l], l == d ? 1.0 : 0.0};
-                    mu[l] = {lam[l], 0.0};
+                for (int i = 0; i < nx; ++i) {
+                    s[i]  = {X[k * nx + i], i == d ? 1.0 : 0.0};
+                    mu[i] = {lam[i], 0.0};
                 }
                 for (int c = 0; c < nu; ++c)
                     ud[c] = {u[nu * k + c], nx + c == d ? 1.0 : 0.0};
                 rk4(s, ud, xn);
-                for (int i = 0; i < nx; ++i)
-                    tape_[k].J[d][i] = xn[i].t;
+                for (int i = 0; i < 3; ++i) {
+                    tp.Jp[i][l] = xn[i].t;
+                    tp.Jv[i][l] = xn[3 + i].t;
+                    if (l != 3) // the attitude does not depend on the thrust
+                        tp.Ja[i][l < 3 ? l : l - 1] = xn[6 + i].t;
+                }
                 stage_multipliers(s, k, yk);
                 rk4_adj(s, ud, mu, sbar, ubar);
                 Model::cost_grad(s, ud, sbar, gu);
                 for (int c = 0; c < nu; ++c) {
-                    Dual g               = ubar[c] + gu[c];
-                    tape_[k].H[d][nx + c] = g.t;
-                    grad[nu * k + c]      = g.v;
+                    Dual g           = ubar[c] + gu[c];
+                    tp.Hau[l][3 + c] = g.t;
+                    grad[nu * k + c] = g.v;
                 }
                 Model::constr_adj(s, yk, sbar);
-                for (int l = 0; l < nx; ++l) {
-                    tape_[k].H[d][l] = sbar[l].t;
-                    lam_k[l]         = sbar[l].v;
-                }
+                for (int e = 0; e < 3; ++e)
+                    tp.Hau[l][e] = sbar[6 + e].t;
+                for (int i = 0; i < nx; ++i)
+                    lam_k[i] = sbar[i].v;
+            }
+            Dual lt[nx];
+            for (int d = 0; d < 3; ++d) {
+                state_terms_dual(X + k * nx, u + nu * k, k, d, lt);
+                for (int e = 0; e < 3; ++e)
+                    tp.Hpp[d][e] = lt[e].t;
             }
             std::copy(lam_k, lam_k + nx, lam);
         }
     }
-    /// Sum of products the way the kernels accumulate it: four partial sums (term t goes to partial
-    /// t mod 4, each an fma chain starting from 0), combined as (p0 + p1) + (p2 + p3).
-    struct Dot4 {
-        double p[4] = {0.0, 0.0, 0.0, 0.0};
-        int t       = 0;
-        void add(double a, double b) {
-            p[t & 3] = std::fma(a, b, p[t & 3]);
-            ++t;
+    /// c[0] z[0] + c[1] z[1] + ... as one fma chain in index order, on top of `acc` (CONT) or from the
+    /// first product.
+    template <int LEN, bool CONT = false>
+    static double dot_seq(const double *c, const double *z, double acc = 0.0) {
+        int e = 0;
+        if (!CONT) {
+            acc = c[0] * z[0];
+            e   = 1;
         }
-        double sum() const { return (p[0] + p[1]) + (p[2] + p[3]); }
-    };
-    /// Hv over the tape: x_t' = J z_t forward, then [lam_t ; Hv_k] = H z_t + J' lam_t' backward, every
-    /// component one Dot4 over its terms in index order.  Component l of H z_t uses direction l's
-    /// column of H as the row (H is symmetric up to rounding).
+        for (; e < LEN; ++e)
+            acc = std::fma(c[e], z[e], acc);
+        return acc;
+    }
+    /// Running sums in the order the kernels' wavefront scan forms them.  excl[k] = init + r[0] + ... +
+    /// r[k-1] for k = 0..n, with the additions grouped as follows: blocks of 64 consecutive entries (a
+    /// short block is padded with +0.0); inside a block a Kogge-Stone scan at distances 1, 2, 4, 8 within
+    /// groups of 16 (an entry without a partner adds +0.0), then the odd groups add the total of the
+    /// group before them, then the upper half adds the total of the lower half; an entry's sum is
+    /// (sum of the blocks before) + (sum of its predecessors in its block).
+    static void prefix_scan(const double *r, int n, double init, double *excl /* n + 1 */) {
+        double carry = init;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            double x[64], t[64];
+            for (int i = 0; i < 64; ++i)
+                x[i] = k0 + i < n ? r[k0 + i] : 0.0;
+            for (int d = 1; d <= 8; d *= 2) {
+                for (int i = 0; i < 64; ++i)
+                    t[i] = x[i] + ((i & 15) >= d ? x[i - d] : 0.0);
+                std::copy(t, t + 64, x);
+            }
+            for (int i = 0; i < 64; ++i)
+                t[i] = x[i] + ((i & 16) ? x[(i & ~15) - 1] : 0.0);
+            std::copy(t, t + 64, x);
+            for (int i = 0; i < 64; ++i)
+                t[i] = x[i] + ((i & 32) ? x[31] : 0.0);
+            std::copy(t, t + 64, x);
+            const int cnt = std::min(64, n - k0);
+            for (int i = 0; i < cnt; ++i)
+                excl[k0 + i] = carry + (i ? x[i - 1] : 0.0);
+            carry = carry + x[cnt - 1];
+        }
+        excl[n] = carry;
+    }
+    /// Hv over the tape.  Forward: the tangent trajectory x' = (p', v', a'); each state is its initial
+    /// value plus the running sum of increments that do not involve it, so the increments are formed
+    /// for all stages first and summed by prefix_scan (attitude of realistic_quadcopter: a 3 x 3
+    /// recursion, stage by stage).  Backward: lam' = (lp, lv, la) and the products, the same way over
+    /// the stages in reverse order.  Output l takes the row recorded along direction l as its
+    /// coefficients (H is symmetric up to rounding).
     void hess_prod_tape(const double *v, double *Hv) const {
-        std::vector<double> Xt((N + 1) * nx, 0.0);
-        double z[nz], w[nz];
+        std::vector<double> Xt((N + 1) * nx, 0.0), inc(N), run(N + 1);
+        auto xt = [&](int k, int i) -> double & { return Xt[k * nx + i]; };
+        // attitude
+        for (int i = 0; i < 3; ++i) {
+            if (angle_rates_are_inputs) {
+                for (int k = 0; k < N; ++k)
+                    inc[k] = tape_[k].Ja[i][3 + i] * v[nu * k + 1 + i];
+                prefix_scan(inc.data(), N, 0.0, run.data());
+                for (int k = 0; k <= N; ++k)
+                    xt(k, 6 + i) = run[k];
+            }
+        }
+        if (!angle_rates_are_inputs) {
+            for (int k = 0; k < N; ++k)
+                for (int i = 0; i < 3; ++i) {
+                    const double Sw = dot_seq<3>(tape_[k].Ja[i] + 3, v + nu * k + 1);
+                    xt(k + 1, 6 + i) = dot_seq<3, true>(tape_[k].Ja[i], &xt(k, 6), Sw);
+                }
+        }
+        // velocity, position
+        std::vector<double> Rp(3 * N);
+        for (int i = 0; i < 3; ++i) {
+            for (int k = 0; k < N; ++k) {
+                const double *vk    = v + nu * k;
+                const double z[nau] = {xt(k, 6), xt(k, 7), xt(k, 8), vk[0], vk[1], vk[2], vk[3]};
+                inc[k]              = dot_seq<nau>(tape_[k].Jv[i], z);
+                Rp[3 * k + i]       = dot_seq<nau>(tape_[k].Jp[i], z);
+            }
+            prefix_scan(inc.data(), N, 0.0, run.data());
+            for (int k = 0; k <= N; ++k)
+                xt(k, 3 + i) = run[k];
+            for (int k = 0; k < N; ++k)
+                inc[k] = std::fma(cpv, xt(k, 3 + i), Rp[3 * k + i]);
+            prefix_scan(inc.data(), N, 0.0, run.data());
+            for (int k = 0; k <= N; ++k)
+                xt(k, i) = run[k];
+        }
+        // backward, over j = N - 1 - k; LM[k] = lam'_k
+        std::vector<double> LM((N + 1) * nx, 0.0);
+        auto lm = [&](int k, int i) -> double & { return LM[k * nx + i]; };
+        auto suffix = [&](int comp) { // lm(k, comp) = lm(N, comp) + inc[N-1-k] + ... (inc in reversed order)
+            prefix_scan(inc.data(), N, lm(N, comp), run.data());
+            for (int j = 0; j <= N; ++j)
+                lm(N - j, comp) = run[j];
+        };
+        for (int i = 0; i < 3; ++i) {
+            lm(N, i)     = dot_seq<3>(HNpp_[i], &xt(N, 0));
+            lm(N, 3 + i) = hvvN * xt(N, 3 + i);
+            lm(N, 6 + i) = dot_seq<3>(HNaa_[i], &xt(N, 6));
+        }
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < N; ++j)
+                inc[j] = dot_seq<3>(tape_[N - 1 - j].Hpp[i], &xt(N - 1 - j, 0));
+            suffix(i);
+            for (int j = 0; j < N; ++j)
+                inc[j] = std::fma(cpv, lm(N - j, i), hvv * xt(N - 1 - j, 3 + i));
+            suffix(3 + i);
+        }
+        std::vector<double> T(nau * N);
         for (int k = 0; k < N; ++k) {
-            for (int d = 0; d < nx; ++d)
-                z[d] = Xt[k * nx + d];
-            for (int c = 0; c < nu; ++c)
-                z[nx + c] = v[nu * k + c];
-            for (int i = 0; i < nx; ++i) {
-                Dot4 acc;
-                for (int d = 0; d < nz; ++d)
-                    acc.add(tape_[k].J[d][i], z[d]);
-                Xt[(k + 1) * nx + i] = acc.sum();
+            const StageTape &tp = tape_[k];
+            const double *vk    = v + nu * k;
+            const double z[nau] = {xt(k, 6), xt(k, 7), xt(k, 8), vk[0], vk[1], vk[2], vk[3]};
+            for (int l = 0; l < nau; ++l) {
+                double acc = dot_seq<nau>(tp.Hau[l], z);
+                for (int i = 0; i < 3; ++i)
+                    acc = std::fma(tp.Jp[i][l], lm(k + 1, i), acc);
+                for (int i = 0; i < 3; ++i)
+                    acc = std::fma(tp.Jv[i][l], lm(k + 1, 3 + i), acc);
+                T[nau * k + l] = acc;
             }
+            Hv[nu * k] = T[nau * k + 3];
         }
-        double lt[nx];
-        for (int l = 0; l < nx; ++l) {
-            Dot4 acc;
-            for (int d = 0; d < nx; ++d)
-                acc.add(HN_[l][d], Xt[N * nx + d]);
-            lt[l] = acc.sum();
-        }
-        for (int k = N - 1; k >= 0; --k) {
-            for (int d = 0; d < nx; ++d)
-                z[d] = Xt[k * nx + d];
-            for (int c = 0; c < nu; ++c)
-                z[nx + c] = v[nu * k + c];
-            for (int l = 0; l < nz; ++l) {
-                Dot4 acc;
-                for (int d = 0; d < nz; ++d)
-                    acc.add(tape_[k].H[l][d], z[d]);
-                for (int i = 0; i < nx; ++i)
-                    acc.add(tape_[k].J[l][i], lt[i]);
-                w[l] = acc.sum();
+        if (angle_rates_are_inputs) {
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < N; ++j)
+                    inc[j] = T[nau * (N - 1 - j) + i];
+                suffix(6 + i);
+                for (int k = 0; k < N; ++k)
+                    Hv[nu * k + 1 + i] = std::fma(tape_[k].Ja[i][3 + i], lm(k + 1, 6 + i), T[nau * k + 4 + i]);
             }
-            for (int c = 0; c < nu; ++c)
-                Hv[nu * k + c] = w[nx + c];
-            std::copy(w, w + nx, lt);
+        } else {
+            for (int k = N - 1; k >= 0; --k) {
+                const StageTape &tp = tape_[k];
+                for (int j = 0; j < 3; ++j) {
+                    double acc = T[nau * k + 4 + j], acl = T[nau * k + j];
+                    for (int i = 0; i < 3; ++i) {
+                        acc = std::fma(tp.Ja[i][3 + j], lm(k + 1, 6 + i), acc);
+                        acl = std::fma(tp.Ja[i][j], lm(k + 1, 6 + i), acl);
+                    }
+                    Hv[nu * k + 1 + j] = acc;
+                    lm(k, 6 + j)       = acl;
+                }
+            }
         }
     }
 

@@ -64,25 +64,25 @@ struct ScalarALProblem {
     double *tape; ///< HBM: this instance's second-order tape (see workspace_doubles)
     enum { MV_Y = 0, MV_SIG = 1, MV_E1 = 2, MV_E2 = 3, MV_YH = 4, MV_YS = 7, MV_COUNT = 8 };
 
-    // Second-order tape.  With z = (x_k, u_k) (nz = 13 directions), J[d][i] = d x_{k+1,i} / d z_d and
-    // H[l][d] the stage Hessian (oracle: SingleShootingAL::StageTape), a product needs per stage
-    //   forward : x_t'[i] = sum_{d<13} J[d][i] z_d                               (13 terms per component)
-    //   backward: w[l]    = sum_{t<13} H[l][t] z_t + sum_{i<9} J[l][i] lam_t'[i]  (22 terms, t = 13 + i)
-    // each a Dot4: term t goes to partial t mod 4, result (p0 + p1) + (p2 + p3).  The four partial sums
-    // are the four 16-lane rows of the wavefront: lane (g, c) = 16 g + c owns partial g of component c,
-    // so a stage is 4 (forward) or 6 (backward) fused multiply-adds per lane and one cross-row sum
-    // instead of 13 or 22 multiply-adds on 16 of the 64 lanes.  The tape stores, per stage, what each
-    // lane multiplies by, in lane order:
-    //   FWD block (256 doubles): lane (g, i), j = 0..3: J[g + 4j][i]               (0 beyond the 13 terms)
-    //   BWD block (384 doubles): lane (g, l), j = 0..5: term t = g + 4j: H[l][t] | J[l][t - 13]
-    // and after the N stages the terminal block (256 doubles): lane (g, l), j = 0..2: H_N[l][g + 4j].
-    // Padding entries are zero (the workspace is zero-filled when the handle is created and never
-    // written there): a lane with nothing to add multiplies by 0.
-    static constexpr int nz = nx + nu, ROW = 16, FWD = 4 * WAVE, BWD = 6 * WAVE, STAGE = FWD + BWD, HNB = 4 * WAVE;
-    __host__ __device__ static size_t workspace_doubles(int N) { return (size_t)N * STAGE + HNB; }
-    __device__ static __forceinline__ int fwd_index(int i, int d) { return ((d & 3) * ROW + i) * 4 + (d >> 2); }
-    __device__ static __forceinline__ int bwd_index(int l, int t) { return FWD + ((t & 3) * ROW + l) * 6 + (t >> 2); }
-    __device__ static __forceinline__ int hn_index(int l, int t) { return ((t & 3) * ROW + l) * 4 + (t >> 2); }
+    // Second-order tape (oracle: SingleShootingAL::StageTape).  With z = (x_k, u_k), x = (p, v, a),
+    // u = (thrust, w): J = d x_{k+1} / d z and H = d/dz of the stage's adjoint outputs at fixed
+    // lam_{k+1} have the block structure of the cascade attitude -> velocity -> position,
+    //   p+ = p + cpv v + Jp (a,u)     v+ = v + Jv (a,u)     a+ = Ja (a,w)      H = blockdiag(Hpp, hvv I, Hau)
+    // with (a,u) the NAU = 7 directions that need a dual evaluation of the stage.  The tape holds the
+    // blocks coefficient-major - entry c of stage k at tape[c * pitch + k] - so that the products,
+    // which work on all stages at once (lane = stage), read contiguous rows:
+    //   C_JP + 7 i + e : d p+_i / d (a,u)_e        C_JV + 7 i + e : d v+_i / d (a,u)_e
+    //   C_JA + 6 i + e : d a+_i / d (a_0..2, w_0..2)_e
+    //   C_HAU + 7 l + e: derivative along (a,u)_l of adjoint output (a,u)_e
+    //   C_HPP + 3 l + e: derivative along p_l of adjoint output p_e
+    // and after them the terminal block: HNpp[3][3], HNaa[3][3].  cpv = c6 * 6 (d p+ / d v) and
+    // hvv = 2 q_v are constants.
+    static constexpr int nz = nx + nu, NAU = 3 + nu;
+    static constexpr int C_JP = 0, C_JV = C_JP + 3 * NAU, C_JA = C_JV + 3 * NAU, C_HAU = C_JA + 18,
+                         C_HPP = C_HAU + NAU * NAU, NCOEF = C_HPP + 9, HNB = 18;
+    static constexpr double cpv = M::c6 * 6.0, hvv = 2.0 * 1.0, hvvN = 2.0 * 25.0;
+    __host__ __device__ static int tape_pitch(int N) { return (N + 15) & ~15; }
+    __host__ __device__ static size_t workspace_doubles(int N) { return (size_t)NCOEF * tape_pitch(N) + HNB; }
 
     static constexpr int CG_BASE = NUM_ITER_VEC; ///< all 20 vectors in LDS: iterates first, then the CG block
     static constexpr int X0_DOUBLES = 16;        ///< the initial state, at the end of the dynamic LDS
@@ -716,9 +716,11 @@ struct ScalarALProblem {
     /// The arithmetic of every entry is the one of the sweep it replaces (value parts = step 1).
     __device__ __forceinline__ void eval_grad_xhat(const double *u, double *grad, int yh_slot) const {
         reverse<true>(u, mvec(MV_YH + yh_slot), grad);
-        // terminal block: lane d < nx seeds direction e_d of x_N
-        if (lane < nx) {
-            const int d = lane;
+        int pitch = tape_pitch(N);
+        asm volatile("" : "+s"(pitch)); // see hess_prod()
+        // terminal block: lanes 0..2 seed the position directions of x_N, lanes 3..5 the attitude's
+        if (lane < 6) {
+            const int blk = lane < 3 ? 0 : 6, d = lane < 3 ? lane : lane + 3;
             dual s[nx], yk[nc], lt[nx], gu[nu];
 #pragma unroll
             for (int l = 0; l < nx; ++l) {
@@ -729,36 +731,62 @@ struct ScalarALProblem {
             stage_multipliers(tN, s, N, yk);
             M::cost_grad(s, static_cast<const dual *>(nullptr), lt, gu);
             M::constr_adj(tN, s, yk, lt);
-            double *HN = tape + (size_t)N * STAGE; // row d of H_N (direction d's column, H_N is symmetric)
+            double *HN = tape + (size_t)NCOEF * pitch + 3 * lane; // HNpp rows, then HNaa rows
 #pragma unroll
-            for (int l = 0; l < nx; ++l)
-                HN[hn_index(d, l)] = lt[l].t;
+            for (int e = 0; e < 3; ++e)
+                HN[e] = (blk == 0 ? lt[e] : lt[6 + e]).t;
         }
-        const int tasks = N * nz;
+        // position block of every stage: one (stage, position direction) per lane
+        for (int base = 0; base < 3 * N; base += WAVE) {
+            const int task = base + lane;
+            if (task < 3 * N) {
+                const int k = task / 3, d = task - 3 * k;
+                dual s[nx], uk[nu], yk[nc], lt[nx], gu[nu];
+#pragma unroll
+                for (int l = 0; l < nx; ++l) {
+                    s[l]  = {X[k * nx + l], d == l ? 1.0 : 0.0};
+                    lt[l] = dual{};
+                }
+#pragma unroll
+                for (int c = 0; c < nu; ++c)
+                    uk[c] = {u[nu * k + c], 0.0};
+                const auto t1 = M::trig_load(TG + 12 * k, s[6].t, s[7].t, s[8].t);
+                stage_multipliers(t1, s, k, yk);
+                M::cost_grad(s, uk, lt, gu);
+                M::constr_adj(t1, s, yk, lt);
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                    tape[(size_t)(C_HPP + 3 * d + e) * pitch + k] = lt[e].t;
+            }
+        }
+        // the (a, u) directions: one (stage, direction) per lane
+        const int tasks = N * NAU;
         for (int base = 0; base < tasks; base += WAVE) {
             const int task  = base + lane;
             const bool live = task < tasks;
             const int tt    = live ? task : tasks - 1; // idle lanes of the last round repeat a task, unstored
-            const int k = tt / nz, d = tt - k * nz;
+            const int k = tt / NAU, l = tt - k * NAU, d = 6 + l;
             dual s[nx], uk[nu], xn[nx], yk[nc], mu[nx], sbar[nx], ubar[nu], gu[nu];
 #pragma unroll
-            for (int l = 0; l < nx; ++l) {
-                s[l]  = {X[k * nx + l], d == l ? 1.0 : 0.0};
-                mu[l] = {Xt[(k + 1) * nx + l], 0.0}; // lam_{k+1} (reverse<true>)
+            for (int i = 0; i < nx; ++i) {
+                s[i]  = {X[k * nx + i], d == i ? 1.0 : 0.0};
+                mu[i] = {Xt[(k + 1) * nx + i], 0.0}; // lam_{k+1} (reverse_cascade)
             }
 #pragma unroll
             for (int c = 0; c < nu; ++c)
                 uk[c] = {u[nu * k + c], d == nx + c ? 1.0 : 0.0};
             const double2 *tg = TG + 12 * k;
-            double *stage     = tape + (size_t)k * STAGE;
+            double *col       = tape + k;
             const auto t1     = M::trig_load(tg, s[6].t, s[7].t, s[8].t);
             stage_multipliers(t1, s, k, yk);
             rk4_adj_dual(tg, t1, s, uk, mu, sbar, ubar, xn);
             if (live) {
 #pragma unroll
-                for (int i = 0; i < nx; ++i) {
-                    stage[fwd_index(i, d)]      = xn[i].t; // J[d][i]: term d of forward component i
-                    stage[bwd_index(d, nz + i)] = xn[i].t; //          term 13 + i of backward component d
+                for (int i = 0; i < 3; ++i) {
+                    col[(size_t)(C_JP + NAU * i + l) * pitch] = xn[i].t;
+                    col[(size_t)(C_JV + NAU * i + l) * pitch] = xn[3 + i].t;
+                    if (l != 3) // the attitude does not depend on the thrust
+                        col[(size_t)(C_JA + 6 * i + (l < 3 ? l : l - 1)) * pitch] = xn[6 + i].t;
                 }
             }
             M::cost_grad(s, uk, sbar, gu);
@@ -766,13 +794,13 @@ struct ScalarALProblem {
             for (int c = 0; c < nu; ++c) {
                 dual g = ubar[c] + gu[c];
                 if (live)
-                    stage[bwd_index(d, nx + c)] = g.t; // H[d][9 + c] (row d = direction d's column)
+                    col[(size_t)(C_HAU + NAU * l + 3 + c) * pitch] = g.t;
             }
             M::constr_adj(t1, s, yk, sbar);
             if (live)
 #pragma unroll
-                for (int l = 0; l < nx; ++l)
-                    stage[bwd_index(d, l)] = sbar[l].t;
+                for (int e = 0; e < 3; ++e)
+                    col[(size_t)(C_HAU + NAU * l + e) * pitch] = sbar[6 + e].t;
         }
         wave_sync();
         wait_vmem(); // the products read the tape back through global loads
@@ -793,179 +821,272 @@ struct ScalarALProblem {
                          : "+v"(acc)
                          : "v"(own), "v"(coef), "n"(SRC));
     }
-    /// `src` rotated inside the 16-lane rows selected by ROWMASK (lane m <- lane m - N mod 16, i.e.
-    /// row_ror:N); the other rows keep `old`  (scripts/microbench/dpp_row_rotate_test.hip).
-    template <int N, int ROWMASK>
-    __device__ static __forceinline__ double row_ror_masked(double old, double src) {
-        int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), 0x120 + N, ROWMASK, 0xF, false);
-        int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), 0x120 + N, ROWMASK, 0xF, false);
-        return __hiloint2double(hi, lo);
-    }
-    /// (row 0 + row 1) + (row 2 + row 3) of the same lane position, the same bits on all four rows:
-    /// the Dot4 sum (p0 + p1) + (p2 + p3) of partials held one per row.
-    __device__ static __forceinline__ double rows_sum(double v) {
-        double a, b;
-        row_partner<false>(v, a, b); // v_permlane16_swap: a = the even row's value, b = the odd row's
-        v = a + b;
-        row_partner<true>(v, a, b);  // v_permlane32_swap: a = rows 0/1, b = rows 2/3
-        return a + b;
-    }
 
-    /// Hessian-vector product over the tape recorded by eval_grad_xhat() (layout above).  Lane (g, c)
-    /// accumulates partial g of component c; what a stage hands to the next (x_t forward, lam_t
-    /// backward: component c on lane c of every row after the cross-row sum) reaches the multiply-adds
-    /// as DPP row broadcasts: row g needs components g, g + 4, g + 8 of x_t (terms g, g + 4, g + 8) -
-    /// one row-masked rotation per row puts them on lanes 0, 4, 8 of that row, and the lanes in
-    /// between take the v_k entries of the remaining terms from LDS.  Everything else a stage needs
-    /// does not depend on the previous stage and is loaded ahead: LDS operands one stage ahead, the
-    /// tape rows DF / DB stages ahead (32 and 48 bytes per lane and stage, 5 KiB per stage in all:
-    /// the whole wavefront reads contiguous rows).
-    static constexpr int DF = 8, DB = 8;
-    __device__ __forceinline__ const double *stage_rows(int k) const {
-        k = k < 0 ? 0 : (k >= N ? N - 1 : k); // clamped: the prefetch runs past the ends
-        return tape + (size_t)k * STAGE;
-    }
-    __device__ __forceinline__ void load_fwd(int k, double (&e)[4]) const {
-        const double2 *p = reinterpret_cast<const double2 *>(stage_rows(k)) + 2 * lane;
-        const double2 a = p[0], b = p[1];
-        e[0] = a.x; e[1] = a.y; e[2] = b.x; e[3] = b.y;
-    }
-    __device__ __forceinline__ void load_bwd(int k, double (&c)[6]) const {
-        const double2 *p = reinterpret_cast<const double2 *>(stage_rows(k) + FWD) + 3 * lane;
-        const double2 a = p[0], b = p[1], d = p[2];
-        c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = d.x; c[5] = d.y;
-    }
+    /// Hessian-vector product over the tape recorded by eval_grad_xhat(), in the order of the oracle's
+    /// SingleShootingAL::hess_prod_tape.  The tangent states and the second-order adjoints are each
+    /// "initial value + running sum of increments that do not involve them", so with lane = stage
+    /// (blocks of 64 stages, the running totals carried from block to block) a product is: tape rows
+    /// into registers (contiguous rows: entry c of stage k at tape[c * pitch + k]), a few dozen
+    /// multiply-adds per lane, and wavefront scans (wave_running_sum: 6 DPP levels) - no recursion over
+    /// the stages at all for quadcopter.  The backward half runs on the mirrored assignment lane = N - 1 -
+    /// stage, so that its sums over the stages ABOVE a stage are running sums over the lanes below again.
+    ///   forward   a' = scan(cw w)            | realistic_quadcopter: 3 x 3 recursion, stage by stage (LDS)
+    ///             Rv = Jv (a', v_k), Rp = Jp (a', v_k);  v' = scan(Rv);  p' = scan(fma(cpv, v', Rp))
+    ///   backward  lp = lp_N + scan(Hpp p');  lv = lv_N + scan(fma(cpv, lp+, hvv v'))
+    ///             T = Hau (a', v_k) + Jp' lp+ + Jv' lv+;   Hv[thrust] = T
+    ///             la = la_N + scan(T_a), Hv[rates] = fma(cw, la+, T_w)   | realistic: recursion, then T_w + Ja_w' la+
+    /// (x+ : the value of stage k + 1.)  LDS: x' in the tangent trajectory rows Xt (forward -> backward
+    /// hand-over), for realistic_quadcopter lam_a' in the trajectory rows X and per-stage scratch in the
+    /// trig store (W): all rebuilt by the next forward sweep before anything reads them (a product only
+    /// ever follows the recording at the same point).
     __device__ __forceinline__ void hess_prod(const double *, const double *v, double *Hv) const {
         wave_sync();
-        static_assert(DF % 2 == 0 && DB % 2 == 0, "the LDS register sets alternate inside a group");
-        const int g = lane >> 4, c = lane & (ROW - 1);
-        // ---- forward: x_t' = J z, z = (x_t, v_k); lane (g, i) adds terms g, g + 4, g + 8, (12) ----
-        {
-            // the lane whose row_newbcast slot carries a v term: rows 1..3 lane 8 (terms 9..11 = v[0..2]),
-            // row 0 lane 12 (term 12 = v[3])
-            const bool isv = g == 0 ? c == 12 : c == 8;
-            const int vidx = g == 0 ? 3 : g - 1;
-            double y = 0.0; // x_t: component i on lane i of every row
-            auto load_v = [&](int k) {
-                k = k >= N ? N - 1 : k;
-                return v[nu * k + vidx];
-            };
-            auto stage = [&](int k, const double (&e)[4], double vv) {
-                if (lane < nx)
-                    Xt[k * nx + lane] = y; // for the backward sweep
-                double R = row_ror_masked<15, 0x2>(y, y);
-                R        = row_ror_masked<14, 0x4>(R, y);
-                R        = row_ror_masked<13, 0x8>(R, y);
-                const double X = isv ? vv : R;
-                double acc = 0.0;
-                fmac_bcast<0, true>(acc, X, e[0]);
-                fmac_bcast<4>(acc, X, e[1]);
-                fmac_bcast<8>(acc, X, e[2]);
-                fmac_bcast<12>(acc, X, e[3]);
-                y = rows_sum(acc);
-            };
-            double E[DF][4], va, vb;
+        int pitch = tape_pitch(N);
+        // the row addresses are loop invariants of the whole solve: computed ahead they would occupy
+        // (and spill) a few hundred registers for the lifetime of the kernel; they are scalar work of a
+        // few dozen cycles per product instead
+        asm volatile("" : "+s"(pitch));
+        constexpr bool RATES_ARE_INPUTS = M::angles_are_integrated_inputs;
+        constexpr int NJA = RATES_ARE_INPUTS ? 3 : 18, NJ = 6 * NAU, NH = NAU * NAU + 9;
+        const int KS = N + 1;
+        double *LM = X, *W = reinterpret_cast<double *>(TG);
+        enum { W_SW = 0, W_TA = 0, W_TW = 3, W_JA = 6 }; // rows of W (realistic_quadcopter)
+        auto load_ja = [&](int k, double (&ja)[NJA]) {
 #pragma unroll
-            for (int j = 0; j < DF; ++j)
-                load_fwd(j, E[j]);
-            va = load_v(0);
-            auto group = [&](int k0, auto guarded) { // full groups run branch-free, the last one guarded
+            for (int q = 0; q < NJA; ++q)
+                ja[q] = tape[(size_t)(RATES_ARE_INPUTS ? C_JA + 6 * q + 3 + q : C_JA + q) * pitch + k];
+        };
+        auto load_j = [&](int k, double (&cj)[NJ]) { // Jp rows, then Jv rows
 #pragma unroll
-                for (int j = 0; j < DF; ++j) {
-                    const int k = k0 + j;
-                    if (!decltype(guarded)::value || k < N) {
-                        if (j % 2 == 0) {
-                            vb = load_v(k + 1);
-                            stage(k, E[j], va);
-                        } else {
-                            va = load_v(k + 1);
-                            stage(k, E[j], vb);
-                        }
+            for (int q = 0; q < NJ; ++q)
+                cj[q] = tape[(size_t)(C_JP + q) * pitch + k];
+        };
+        auto load_h = [&](int k, double (&ch)[NH]) { // Hau rows, then Hpp rows
+#pragma unroll
+            for (int q = 0; q < NH; ++q)
+                ch[q] = tape[(size_t)(C_HAU + q) * pitch + k];
+        };
+        // running sum over the stages of a block: returns what the stages before this lane's add up to
+        // (carry included) and moves the carry on to the next block; `cnt` stages in the block
+        auto scan = [&](double inc, double &carry, int cnt) {
+            const double s   = wave_running_sum(inc);
+            const double out = carry + lane_below(s);
+            carry            = carry + lane_value(s, cnt - 1);
+            return out;
+        };
+
+        if constexpr (!RATES_ARE_INPUTS) {
+            // ---- attitude tangent: coefficients and Sw = Ja_w w to LDS, then the recursion ----
+            for (int k = lane; k < N; k += WAVE) {
+                double ja[NJA];
+                load_ja(k, ja);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    double acc = ja[6 * i + 3] * v[nu * k + 1];
+                    acc        = __builtin_fma(ja[6 * i + 4], v[nu * k + 2], acc);
+                    acc        = __builtin_fma(ja[6 * i + 5], v[nu * k + 3], acc);
+                    W[(W_SW + i) * KS + k] = acc;
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        W[(W_JA + 3 * i + e) * KS + k]     = ja[6 * i + e]; // for a': lane i needs row i
+                        W[(W_JA + 9 + 3 * e + i) * KS + k] = ja[6 * i + e]; // for la: lane j needs column j
                     }
-                    load_fwd(k + DF, E[j]);
                 }
-            };
-            int k0 = 0;
-            for (; k0 + DF <= N; k0 += DF)
-                group(k0, std::false_type{});
-            if (k0 < N)
-                group(k0, std::true_type{});
-            if (lane < nx)
-                Xt[N * nx + lane] = y;
-            wait_vmem(); // the clamped prefetches past the last stage
+            }
+            wave_sync();
+            attitude_recursion<true>(W + W_SW * KS, W + W_JA * KS, KS, Xt + 6, 0.0);
             wave_sync();
         }
-        // ---- backward: w = H z + J' lam_t'; lane (g, l) adds terms g + 4 j, j = 0..5 ----
-        // terms t < 13 multiply z_t = (x_t of the stage, v_k)_t: lane-dependent LDS operands, read one
-        // stage ahead; terms t >= 13 multiply lam_t'[t - 13] = the previous stage's w: row broadcasts.
-        // Row 0: terms 0, 4, 8, 12 | 16, 20; rows 1..3: g, g + 4, g + 8 | g + 12, g + 16, (21 for g = 1).
-        const double *z2p = g == 0 ? Xt + 8 : v + (g - 1); // term g + 8: x_t[8] (row 0) or v[g - 1]
-        const int z2s     = g == 0 ? nx : nu;
-        struct Z {
-            double z0, z1, z2, z3;
-        };
-        auto load_z = [&](int k) {
-            k = k < 0 ? 0 : k;
-            return Z{Xt[k * nx + g], Xt[k * nx + g + 4], z2p[k * z2s], v[nu * k + 3]};
-        };
-        double w;
-        {
-            // terminal block: lam_t[l] = sum_{t<9} H_N[l][t] x_t(N)[t]
-            const double *hn = tape + (size_t)N * STAGE + 4 * lane;
-            const double2 a = reinterpret_cast<const double2 *>(hn)[0];
-            const double h2 = hn[2];
-            double acc = 0.0;
-            acc = __builtin_fma(a.x, Xt[N * nx + g], acc);
-            acc = __builtin_fma(a.y, Xt[N * nx + g + 4], acc);
-            acc = __builtin_fma(h2, Xt[N * nx + 8], acc); // zero coefficient off row 0
-            w   = rows_sum(acc);
-        }
-        auto stage = [&](int k, const double (&C)[6], const Z &z) {
-            // lanes 0, 4, 8 of row g <- the lam_t' entries of its terms: row 0 w[3], w[7] on lanes 4, 8
-            // (lane 0 takes v_k[3], term 12); row g >= 1: w[g - 1], w[g + 3], w[g + 7] on lanes 0, 4, 8
-            double R = row_ror_masked<1, 0x1>(w, w);
-            R        = row_ror_masked<15, 0x4>(R, w);
-            R        = row_ror_masked<14, 0x8>(R, w);
-            const double X = lane == 0 ? z.z3 : R;
-            double acc = 0.0;
-            acc = __builtin_fma(C[0], z.z0, acc);
-            acc = __builtin_fma(C[1], z.z1, acc);
-            acc = __builtin_fma(C[2], z.z2, acc);
-            fmac_bcast<0, true>(acc, X, C[3]);
-            fmac_bcast<4>(acc, X, C[4]);
-            fmac_bcast<8>(acc, X, C[5]);
-            w = rows_sum(acc);
-            if (lane >= nx && lane < nz)
-                Hv[nu * k + (lane - nx)] = w;
-        };
-        double Cc[DB][6];
+        // ---- forward: lane = stage ----
+        double ca[3] = {0.0, 0.0, 0.0}, cv[3] = {0.0, 0.0, 0.0}, cp[3] = {0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < N; k0 += WAVE) {
+            const int cnt = N - k0 < WAVE ? N - k0 : WAVE;
+            const bool on = lane < cnt;
+            const int k   = on ? k0 + lane : N - 1; // idle lanes shadow the last stage; they add 0 and store nothing
+            double cj[NJ], z[NAU];
+            load_j(k, cj);
+            z[3] = v[nu * k]; z[4] = v[nu * k + 1]; z[5] = v[nu * k + 2]; z[6] = v[nu * k + 3];
+            if constexpr (RATES_ARE_INPUTS) {
+                double cw[NJA];
+                load_ja(k, cw);
 #pragma unroll
-        for (int j = 0; j < DB; ++j)
-            load_bwd(N - 1 - j, Cc[j]);
-        Z za = load_z(N - 1), zb;
-        auto group = [&](int k0, auto guarded) { // stages k0, k0 - 1, ... k0 - DB + 1
+                for (int i = 0; i < 3; ++i)
+                    z[i] = scan(on ? cw[i] * z[4 + i] : 0.0, ca[i], cnt);
+            } else {
 #pragma unroll
-            for (int j = 0; j < DB; ++j) {
-                const int k = k0 - j;
-                if (!decltype(guarded)::value || k >= 0) {
-                    if (j % 2 == 0) {
-                        zb = load_z(k - 1);
-                        stage(k, Cc[j], za);
-                    } else {
-                        za = load_z(k - 1);
-                        stage(k, Cc[j], zb);
-                    }
-                }
-                load_bwd(k - DB, Cc[j]);
+                for (int i = 0; i < 3; ++i)
+                    z[i] = Xt[k * nx + 6 + i];
             }
-        };
-        int k0 = N - 1;
-        for (; k0 - DB + 1 >= 0; k0 -= DB)
-            group(k0, std::false_type{});
-        if (k0 >= 0)
-            group(k0, std::true_type{});
-        wait_vmem(); // the clamped prefetches past the first stage
+            double pt[3], vt[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double rp = cj[NAU * i] * z[0], rv = cj[3 * NAU + NAU * i] * z[0];
+#pragma unroll
+                for (int e = 1; e < NAU; ++e) {
+                    rp = __builtin_fma(cj[NAU * i + e], z[e], rp);
+                    rv = __builtin_fma(cj[3 * NAU + NAU * i + e], z[e], rv);
+                }
+                vt[i] = scan(on ? rv : 0.0, cv[i], cnt);
+                pt[i] = scan(on ? __builtin_fma(cpv, vt[i], rp) : 0.0, cp[i], cnt);
+            }
+            if (on) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    Xt[k * nx + i]     = pt[i];
+                    Xt[k * nx + 3 + i] = vt[i];
+                    if constexpr (RATES_ARE_INPUTS)
+                        Xt[k * nx + 6 + i] = z[i];
+                }
+            }
+        }
+        if (lane < 3) { // x'_N: the totals
+            Xt[N * nx + lane]     = lane == 0 ? cp[0] : lane == 1 ? cp[1] : cp[2];
+            Xt[N * nx + 3 + lane] = lane == 0 ? cv[0] : lane == 1 ? cv[1] : cv[2];
+            if constexpr (RATES_ARE_INPUTS)
+                Xt[N * nx + 6 + lane] = lane == 0 ? ca[0] : lane == 1 ? ca[1] : ca[2];
+        }
         wave_sync();
+        // ---- lam'_N (same values on every lane) ----
+        double lp[3], lv[3], la[3];
+        {
+            const double *HN = tape + (size_t)NCOEF * pitch;
+            const double *xN = Xt + N * nx;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                lp[i] = HN[3 * i] * xN[0];
+                lp[i] = __builtin_fma(HN[3 * i + 1], xN[1], lp[i]);
+                lp[i] = __builtin_fma(HN[3 * i + 2], xN[2], lp[i]);
+                lv[i] = hvvN * xN[3 + i];
+                la[i] = HN[9 + 3 * i] * xN[6];
+                la[i] = __builtin_fma(HN[9 + 3 * i + 1], xN[7], la[i]);
+                la[i] = __builtin_fma(HN[9 + 3 * i + 2], xN[8], la[i]);
+            }
+        }
+        // ---- backward: lane = N - 1 - stage ----
+        for (int j0 = 0; j0 < N; j0 += WAVE) {
+            const int cnt = N - j0 < WAVE ? N - j0 : WAVE;
+            const bool on = lane < cnt;
+            const int k   = on ? N - 1 - (j0 + lane) : 0;
+            double ch[NH], cj[NJ], z[NAU], xp[3], xv[3], lpn[3], lvn[3];
+            load_h(k, ch);
+            load_j(k, cj);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                xp[i] = Xt[k * nx + i];
+                xv[i] = Xt[k * nx + 3 + i];
+                z[i]  = Xt[k * nx + 6 + i];
+            }
+            z[3] = v[nu * k]; z[4] = v[nu * k + 1]; z[5] = v[nu * k + 2]; z[6] = v[nu * k + 3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double q = ch[NAU * NAU + 3 * i] * xp[0];
+                q        = __builtin_fma(ch[NAU * NAU + 3 * i + 1], xp[1], q);
+                q        = __builtin_fma(ch[NAU * NAU + 3 * i + 2], xp[2], q);
+                lpn[i]   = scan(on ? q : 0.0, lp[i], cnt); // lp of stage k + 1
+                lvn[i]   = scan(on ? __builtin_fma(cpv, lpn[i], hvv * xv[i]) : 0.0, lv[i], cnt);
+            }
+            double T[NAU];
+#pragma unroll
+            for (int l = 0; l < NAU; ++l) {
+                double t = ch[NAU * l] * z[0];
+#pragma unroll
+                for (int e = 1; e < NAU; ++e)
+                    t = __builtin_fma(ch[NAU * l + e], z[e], t);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    t = __builtin_fma(cj[NAU * i + l], lpn[i], t);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    t = __builtin_fma(cj[3 * NAU + NAU * i + l], lvn[i], t);
+                T[l] = t;
+            }
+            if (on)
+                Hv[nu * k] = T[3];
+            if constexpr (RATES_ARE_INPUTS) {
+                double cw[NJA];
+                load_ja(k, cw);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const double lan = scan(on ? T[i] : 0.0, la[i], cnt);
+                    if (on)
+                        Hv[nu * k + 1 + i] = __builtin_fma(cw[i], lan, T[4 + i]);
+                }
+            } else if (on) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    W[(W_TA + i) * KS + k] = T[i];
+                    W[(W_TW + i) * KS + k] = T[4 + i];
+                }
+            }
+        }
+        if constexpr (!RATES_ARE_INPUTS) {
+            wave_sync();
+            const int j3 = (lane & 15) < 3 ? (lane & 15) : 2;
+            attitude_recursion<false>(W + W_TA * KS, W + (W_JA + 9) * KS, KS, LM + 6, j3 == 0 ? la[0] : j3 == 1 ? la[1] : la[2]);
+            wave_sync();
+            for (int k = lane; k < N; k += WAVE) {
+                double ja[NJA];
+                load_ja(k, ja);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double t = W[(W_TW + j) * KS + k];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        t = __builtin_fma(ja[6 * i + 3 + j], LM[(k + 1) * nx + 6 + i], t);
+                    Hv[nu * k + 1 + j] = t;
+                }
+            }
+        }
+        wave_sync();
+    }
+    /// The 3 x 3 recursions of realistic_quadcopter's attitude: y <- start[j] + sum_e coef[j][e] y[e], lane j
+    /// of every row holding component j (lanes 3..15: shadows of lane 2), the three components reaching the
+    /// multiply-adds as row-broadcast DPP operands.  UP: stages 0..N-1, y(k) stored to out[k] and the
+    /// final value to out[N] (a'); otherwise stages N-1..0 with y(k+1) stored to out[k+1] (la).  start
+    /// and coef rows are LDS arrays over the stages (row r of stage k at [r * KS + k]; coef rows 3 j + e).
+    template <bool UP>
+    __device__ __forceinline__ void attitude_recursion(const double *start, const double *coef, int KS, double *out,
+                                                       double y0) const {
+        const int j3      = (lane & 15) < 3 ? (lane & 15) : 2;
+        const bool writer = lane < 3;
+        double y          = y0;
+        auto step = [&](double s, double c0, double c1, double c2) {
+            double nxt = s;
+            fmac_bcast<0, true>(nxt, y, c0);
+            fmac_bcast<1>(nxt, y, c1);
+            fmac_bcast<2>(nxt, y, c2);
+            y = nxt;
+        };
+        auto at = [&](int i) { return UP ? i : N - 1 - i; }; // i-th stage visited
+        int i = 0;
+        for (; i + 8 <= N; i += 8) {
+            double s[8], c[8][3], kept[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = at(i + q);
+                s[q]        = start[j3 * KS + k];
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                    c[q][e] = coef[(3 * j3 + e) * KS + k];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                kept[q] = y;
+                step(s[q], c[q][0], c[q][1], c[q][2]);
+            }
+            if (writer)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    out[(UP ? at(i + q) : at(i + q) + 1) * nx + j3] = kept[q];
+        }
+        for (; i < N; ++i) {
+            const int k = at(i);
+            if (writer)
+                out[(UP ? k : k + 1) * nx + j3] = y;
+            step(start[j3 * KS + k], coef[3 * j3 * KS + k], coef[(3 * j3 + 1) * KS + k], coef[(3 * j3 + 2) * KS + k]);
+        }
+        if (UP && writer)
+            out[N * nx + j3] = y;
     }
     /// y / Sigma for the sweeps; call whenever y or Sigma changed (they are fixed during an inner solve).
     __device__ __forceinline__ void set_al() const {

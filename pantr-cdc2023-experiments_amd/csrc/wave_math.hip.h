@@ -121,6 +121,36 @@ __device__ __forceinline__ double dpp_move(double v) {
     hi     = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+/// The same with a row mask: lanes of the 16-lane rows outside ROW_MASK (bit r = row r) read 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_rows(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo     = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true);
+    hi     = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+/// Inclusive running sum over the 64 lanes, lane i <- x_0 + ... + x_i, the additions grouped as the
+/// oracle's prefix_scan() groups them: Kogge-Stone at distances 1, 2, 4, 8 inside the 16-lane rows
+/// (row_shr DPP moves; a lane without a source adds +0.0), then rows 1 and 3 add the total of the row
+/// before them (row_bcast:15), then rows 2 and 3 add the total of the lower half (row_bcast:31).  All
+/// lanes must be active.
+__device__ __forceinline__ double wave_running_sum(double x) {
+    x = x + dpp_move<0x111>(x);
+    x = x + dpp_move<0x112>(x);
+    x = x + dpp_move<0x114>(x);
+    x = x + dpp_move<0x118>(x);
+    x = x + dpp_move_rows<0x142, 0xA>(x);
+    x = x + dpp_move_rows<0x143, 0xC>(x);
+    return x;
+}
+/// The value of the lane below (lane 0: +0.0): wave_shr:1.
+__device__ __forceinline__ double lane_below(double v) { return dpp_move<0x138>(v); }
+/// The value lane `src` (wave-uniform) holds, on every lane.
+__device__ __forceinline__ double lane_value(double v, int src) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double row_from_prev(double v) { return dpp_move<0x111>(v); } // row_shr:1
 __device__ __forceinline__ double row_from_next(double v) { return dpp_move<0x101>(v); } // row_shl:1
 __device__ __forceinline__ dual row_from_prev(dual v) { return {row_from_prev(v.v), row_from_prev(v.t)}; }

@@ -327,7 +327,7 @@ def test_alm_reaches_kkt_point(problem, N):
     ub = np.tile([np.pi / 2, np.pi / 2, np.inf, 0.0], N + 1)
     viol = g - np.clip(g, lb, ub)
     assert np.abs(viol).max() <= 1e-7                                    # constraint violation
-    assert np.abs(y * viol).max() <= 1e-6                                 # complementarity
+    assert np.abs(y * viol).max() <= 1e-8 * max(1.0, np.abs(y).max())      # complementarity: |y| x the ALM tolerance on the violation
     # gradient of the Lagrangian via psi with huge-penalty-free trick: Sigma=1, y' = y - g + clip(g + y)
     Sig = np.ones_like(y)
     zeta_target = y  # want yhat = Sigma (zeta - clip(zeta)) = y  with zeta = g + y'/Sigma
