@@ -806,22 +806,6 @@ struct ScalarALProblem {
         wait_vmem(); // the products read the tape back through global loads
     }
 
-    /// acc += (the value lane SRC of this lane's 16-lane row holds in `own`) * coef, the broadcast fused
-    /// into the fma (v_fmac_f64 with a row_newbcast DPP source; the only DPP form the fp64 ALU has).
-    /// FIRST: `own` was written by the instruction just before (DPP reads need two wait states after a
-    /// VALU write; inline asm is outside the compiler's hazard pass).
-    template <int SRC, bool FIRST = false>
-    __device__ static __forceinline__ void fmac_bcast(double &acc, double own, double coef) {
-        if (FIRST)
-            asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                         : "+v"(acc)
-                         : "v"(own), "v"(coef), "n"(SRC));
-        else
-            asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                         : "+v"(acc)
-                         : "v"(own), "v"(coef), "n"(SRC));
-    }
-
     /// Hessian-vector product over the tape recorded by eval_grad_xhat(), in the order of the oracle's
     /// SingleShootingAL::hess_prod_tape.  The tangent states and the second-order adjoints are each
     /// "initial value + running sum of increments that do not involve them", so with lane = stage
@@ -848,9 +832,7 @@ struct ScalarALProblem {
         asm volatile("" : "+s"(pitch));
         constexpr bool RATES_ARE_INPUTS = M::angles_are_integrated_inputs;
         constexpr int NJA = RATES_ARE_INPUTS ? 3 : 18, NJ = 6 * NAU, NH = NAU * NAU + 9;
-        const int KS = N + 1;
         double *LM = X, *W = reinterpret_cast<double *>(TG);
-        enum { W_SW = 0, W_TA = 0, W_TW = 3, W_JA = 6 }; // rows of W (realistic_quadcopter)
         auto load_ja = [&](int k, double (&ja)[NJA]) {
 #pragma unroll
             for (int q = 0; q < NJA; ++q)
@@ -876,7 +858,8 @@ struct ScalarALProblem {
         };
 
         if constexpr (!RATES_ARE_INPUTS) {
-            // ---- attitude tangent: coefficients and Sw = Ja_w w to LDS, then the recursion ----
+            // ---- attitude tangent: operands of the two recursions to LDS (W: 24 doubles per stage; see
+            //      attitude_recursion), then the recursion of a' ----
             for (int k = lane; k < N; k += WAVE) {
                 double ja[NJA];
                 load_ja(k, ja);
@@ -885,16 +868,16 @@ struct ScalarALProblem {
                     double acc = ja[6 * i + 3] * v[nu * k + 1];
                     acc        = __builtin_fma(ja[6 * i + 4], v[nu * k + 2], acc);
                     acc        = __builtin_fma(ja[6 * i + 5], v[nu * k + 3], acc);
-                    W[(W_SW + i) * KS + k] = acc;
+                    W[24 * k + 4 * i] = acc; // Sw_i
 #pragma unroll
                     for (int e = 0; e < 3; ++e) {
-                        W[(W_JA + 3 * i + e) * KS + k]     = ja[6 * i + e]; // for a': lane i needs row i
-                        W[(W_JA + 9 + 3 * e + i) * KS + k] = ja[6 * i + e]; // for la: lane j needs column j
+                        W[24 * k + 4 * i + 1 + e]      = ja[6 * i + e]; // a'_i: row i of Ja
+                        W[24 * k + 12 + 4 * e + 1 + i] = ja[6 * i + e]; // la_e: column e of Ja
                     }
                 }
             }
             wave_sync();
-            attitude_recursion<true>(W + W_SW * KS, W + W_JA * KS, KS, Xt + 6, 0.0);
+            attitude_recursion<true>(W, Xt + 6, 0.0);
             wave_sync();
         }
         // ---- forward: lane = stage ----
@@ -1014,22 +997,22 @@ struct ScalarALProblem {
             } else if (on) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    W[(W_TA + i) * KS + k] = T[i];
-                    W[(W_TW + i) * KS + k] = T[4 + i];
+                    W[24 * k + 12 + 4 * i] = T[i];     // start value of la_i's step
+                    LM[(k + 1) * nx + i]   = T[4 + i]; // T_w: free columns of the rows la is stored to
                 }
             }
         }
         if constexpr (!RATES_ARE_INPUTS) {
             wave_sync();
             const int j3 = (lane & 15) < 3 ? (lane & 15) : 2;
-            attitude_recursion<false>(W + W_TA * KS, W + (W_JA + 9) * KS, KS, LM + 6, j3 == 0 ? la[0] : j3 == 1 ? la[1] : la[2]);
+            attitude_recursion<false>(W + 12, LM + 6, j3 == 0 ? la[0] : j3 == 1 ? la[1] : la[2]);
             wave_sync();
             for (int k = lane; k < N; k += WAVE) {
                 double ja[NJA];
                 load_ja(k, ja);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    double t = W[(W_TW + j) * KS + k];
+                    double t = LM[(k + 1) * nx + j];
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
                         t = __builtin_fma(ja[6 * i + 3 + j], LM[(k + 1) * nx + 6 + i], t);
@@ -1039,51 +1022,70 @@ struct ScalarALProblem {
         }
         wave_sync();
     }
-    /// The 3 x 3 recursions of realistic_quadcopter's attitude: y <- start[j] + sum_e coef[j][e] y[e], lane j
-    /// of every row holding component j (lanes 3..15: shadows of lane 2), the three components reaching the
+    /// The 3 x 3 recursions of realistic_quadcopter's attitude: y <- s_j + sum_e c_je y_e, lane j of every
+    /// row holding component j (lanes 3..15: shadows of lane 2), the three components reaching the
     /// multiply-adds as row-broadcast DPP operands.  UP: stages 0..N-1, y(k) stored to out[k] and the
-    /// final value to out[N] (a'); otherwise stages N-1..0 with y(k+1) stored to out[k+1] (la).  start
-    /// and coef rows are LDS arrays over the stages (row r of stage k at [r * KS + k]; coef rows 3 j + e).
+    /// final value to out[N] (a'); otherwise stages N-1..0 with y(k+1) stored to out[k+1] (la).
+    /// Operands: 4 doubles (s_j, c_j0, c_j1, c_j2) per component at rec[24 k + 4 j] (two 16-byte LDS
+    /// reads per stage), fetched one group of four stages ahead.
     template <bool UP>
-    __device__ __forceinline__ void attitude_recursion(const double *start, const double *coef, int KS, double *out,
-                                                       double y0) const {
+    __device__ __forceinline__ void attitude_recursion(const double *rec, double *out, double y0) const {
         const int j3      = (lane & 15) < 3 ? (lane & 15) : 2;
         const bool writer = lane < 3;
         double y          = y0;
-        auto step = [&](double s, double c0, double c1, double c2) {
-            double nxt = s;
-            fmac_bcast<0, true>(nxt, y, c0);
-            fmac_bcast<1>(nxt, y, c1);
-            fmac_bcast<2>(nxt, y, c2);
+        // the three broadcasts are independent moves; a DPP operand fused into each multiply-add would
+        // put the (long) DPP latency of v_fmac_f64 on the dependent chain three times per stage
+        auto step = [&](const double2 &a, const double2 &b) { // a = (s, c0), b = (c1, c2)
+            const double y0_ = row_bcast<0>(y), y1_ = row_bcast<1>(y), y2_ = row_bcast<2>(y);
+            double nxt = __builtin_fma(a.y, y0_, a.x);
+            nxt        = __builtin_fma(b.x, y1_, nxt);
+            nxt        = __builtin_fma(b.y, y2_, nxt);
             y = nxt;
         };
-        auto at = [&](int i) { return UP ? i : N - 1 - i; }; // i-th stage visited
-        int i = 0;
-        for (; i + 8 <= N; i += 8) {
-            double s[8], c[8][3], kept[8];
+        auto at = [&](int i) { // i-th stage visited (clamped: the operand fetch runs one group ahead)
+            i = i < N ? i : N - 1;
+            return UP ? i : N - 1 - i;
+        };
+        constexpr int G = 4;
+        auto fetch = [&](int i0, double2 (&a)[G], double2 (&b)[G]) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int k = at(i + q);
-                s[q]        = start[j3 * KS + k];
-#pragma unroll
-                for (int e = 0; e < 3; ++e)
-                    c[q][e] = coef[(3 * j3 + e) * KS + k];
+            for (int q = 0; q < G; ++q) {
+                const double2 *p = reinterpret_cast<const double2 *>(rec + 24 * at(i0 + q) + 4 * j3);
+                a[q] = p[0];
+                b[q] = p[1];
             }
+        };
+        auto run = [&](int i0, const double2 (&a)[G], const double2 (&b)[G]) {
+            if (i0 + G <= N) {
+                double kept[G];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                kept[q] = y;
-                step(s[q], c[q][0], c[q][1], c[q][2]);
+                for (int q = 0; q < G; ++q) {
+                    kept[q] = y;
+                    step(a[q], b[q]);
+                }
+                if (writer)
+#pragma unroll
+                    for (int q = 0; q < G; ++q)
+                        out[(UP ? at(i0 + q) : at(i0 + q) + 1) * nx + j3] = kept[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+                    if (i0 + q < N) {
+                        if (writer)
+                            out[(UP ? at(i0 + q) : at(i0 + q) + 1) * nx + j3] = y;
+                        step(a[q], b[q]);
+                    }
             }
-            if (writer)
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    out[(UP ? at(i + q) : at(i + q) + 1) * nx + j3] = kept[q];
-        }
-        for (; i < N; ++i) {
-            const int k = at(i);
-            if (writer)
-                out[(UP ? k : k + 1) * nx + j3] = y;
-            step(start[j3 * KS + k], coef[3 * j3 * KS + k], coef[(3 * j3 + 1) * KS + k], coef[(3 * j3 + 2) * KS + k]);
+        };
+        double2 aA[G], bA[G], aB[G], bB[G];
+        fetch(0, aA, bA);
+        for (int i = 0; i < N; i += 2 * G) {
+            fetch(i + G, aB, bB);
+            run(i, aA, bA);
+            if (i + G >= N)
+                break;
+            fetch(i + 2 * G, aA, bA);
+            run(i + G, aB, bB);
         }
         if (UP && writer)
             out[N * nx + j3] = y;

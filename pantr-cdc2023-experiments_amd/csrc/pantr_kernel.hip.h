@@ -596,7 +596,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
         int nJ = 0, cg_its = 0;
         if (!P.disable_acceleration) {
             double *q = pb.vec(S_Q), *work = pb.vec(S_WORK), *rJ = pb.vec(S_RJ), *z = pb.vec(S_Z),
-                   *r = pb.vec(S_R), *d = pb.vec(S_D), *Bd = pb.vec(S_BD), *step = pb.vec(S_STEP);
+                   *r = pb.vec(S_R), *d = pb.vec(S_D), *step = pb.vec(S_STEP);
             const uint32_t mask = pb.inactive_mask(prox.gamma, X_(prox), G_(prox), nJ);
             const double inv_gamma = -1.0 / prox.gamma;
             for (int j = 0; j < nj; ++j) {
@@ -616,14 +616,14 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
             const int cg_max = (int)lround((double)nJ * P.max_iter_factor);
             while (true) {
                 if (state == CGSTART) {
+                    // all 64 nj slots: the CG passes below run without bounds checks, the padding of
+                    // every vector they touch is zero and stays zero (rJ's and work's are never written)
                     for (int j = 0; j < nj; ++j) {
-                        int i = j * WAVE + lane;
-                        if (i < n) {
-                            double g = rJ[i];
-                            z[i]     = 0.0;
-                            r[i]     = g;
-                            d[i]     = -g;
-                        }
+                        int i    = j * WAVE + lane;
+                        double g = rJ[i];
+                        z[i]     = 0.0;
+                        r[i]     = g;
+                        d[i]     = -g;
                     }
                     r_sq            = pb.dot(r, r);
                     double grad_mag = __builtin_sqrt(r_sq);
@@ -655,23 +655,39 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                     continue;
                 }
                 if (state == CG) {
-                    for (int j = 0; j < nj; ++j) {
-                        int i = j * WAVE + lane;
-                        if (i < n)
-                            Bd[i] = (mask >> j) & 1u ? work[i] : 0.0;
-                    }
+                    // One CG iteration = three passes over the vectors (each lane its nj elements) and
+                    // three reductions, two of them side by side.  Bd = (H d) restricted to J is formed
+                    // on the fly from `work`; the arithmetic is that of
+                    //   Bd = mask(work); dBd = d'Bd; step = z + alpha d; |step|^2; r += alpha Bd; |r|^2;
+                    //   d = -r + beta d; z = step
+                    // element by element and sum by sum.
                     ++cg_its;
-                    double dBd = pb.dot(d, Bd);
+                    double acc = 0.0;
+                    for (int j = 0; j < nj; ++j) {
+                        int i    = j * WAVE + lane;
+                        double b = (mask >> j) & 1u ? work[i] : 0.0;
+                        acc      = acc + d[i] * b;
+                    }
+                    double dBd = uniform(wave_sum(acc));
                     bool to_boundary = false, neg_curv = dBd <= 0.0;
-                    double alpha = 0;
+                    double alpha = 0, r_next_sq = 0;
                     if (!neg_curv) {
                         alpha = r_sq / dBd;
+                        double a2 = 0.0, a3 = 0.0;
                         for (int j = 0; j < nj; ++j) {
-                            int i = j * WAVE + lane;
-                            if (i < n)
-                                step[i] = z[i] + alpha * d[i];
+                            int i     = j * WAVE + lane;
+                            double si = z[i] + alpha * d[i];
+                            step[i]   = si;
+                            a2        = a2 + si * si;
+                            double b  = (mask >> j) & 1u ? work[i] : 0.0;
+                            double ri = r[i] + alpha * b; // unused if the step reaches the boundary
+                            r[i]      = ri;
+                            a3        = a3 + ri * ri;
                         }
-                        to_boundary = __builtin_sqrt(pb.dot(step, step)) >= radius;
+                        a2          = wave_sum(a2);
+                        a3          = wave_sum(a3);
+                        to_boundary = __builtin_sqrt(uniform(a2)) >= radius;
+                        r_next_sq   = uniform(a3);
                     }
                     if (neg_curv || to_boundary) {
                         // ||z + t d|| = radius
@@ -703,12 +719,6 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                         }
                         continue;
                     }
-                    for (int j = 0; j < nj; ++j) {
-                        int i = j * WAVE + lane;
-                        if (i < n)
-                            r[i] = r[i] + alpha * Bd[i];
-                    }
-                    double r_next_sq = pb.dot(r, r);
                     if (__builtin_sqrt(r_next_sq) < tolerance || cg_i > cg_max) {
                         state = EVAL_STEP;
                         vin   = step;
@@ -718,10 +728,8 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                     r_sq        = r_next_sq;
                     for (int j = 0; j < nj; ++j) {
                         int i = j * WAVE + lane;
-                        if (i < n) {
-                            d[i] = (-r[i]) + beta * d[i];
-                            z[i] = step[i];
-                        }
+                        d[i]  = (-r[i]) + beta * d[i];
+                        z[i]  = step[i];
                     }
                     ++cg_i;
                     vin = d;

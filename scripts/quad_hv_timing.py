@@ -7,9 +7,10 @@ sys.path.insert(0, os.path.join(ROOT, "pantr-cdc2023-experiments_amd"))
 import pantr_amd as pa
 L = pa.lib()
 rng = np.random.default_rng(0)
+PROBLEM = sys.argv[1] if len(sys.argv) > 1 else "quadcopter"
 for N in (20, 60):
     for B in (1, 60):
-        b = pa.PantrBatch("quadcopter", N, B)
+        b = pa.PantrBatch(PROBLEM, N, B)
         n, m = 4 * N, 4 * N + 4
         x0 = np.tile(b.initial_state(), (B, 1)); u = np.tile(b.initial_guess(), (B, 1)) + 0.1 * rng.standard_normal((B, n))
         y, Sig, v = np.zeros((B, m)), np.full((B, m), 1e4), rng.standard_normal((B, n))
