@@ -59,7 +59,7 @@ struct ScalarALProblem {
     double *X;   ///< LDS: primal trajectory (N+1) x nx
     double *Xt;  ///< LDS: tangent trajectory (N+1) x nx of a product | adjoints lam_k while the tape is recorded
     double2 *TG; ///< LDS: trig store, 12 (sin, cos) pairs per stage (QuadModelT::trig_load)
-    double *scr;  ///< LDS: 13 (N + 1) + 1 doubles of scratch for the cascade sweeps
+    double *scr;  ///< LDS: scratch_doubles(N) of scratch for the cascade sweeps (16-byte aligned)
     double *coef; ///< LDS: coef_doubles(N), see there
     double *tape; ///< HBM: this instance's second-order tape (see workspace_doubles)
     enum { MV_Y = 0, MV_SIG = 1, MV_E1 = 2, MV_E2 = 3, MV_YH = 4, MV_YS = 7, MV_COUNT = 8 };
@@ -90,8 +90,9 @@ struct ScalarALProblem {
     __device__ __forceinline__ double *ivec(int slot) const { return lds + slot * npad; }
     __device__ __forceinline__ double *mvec(int slot) const { return mv + slot * mpad; }
     /// dedicated_scratch: the cascade sweeps' scratch gets LDS of its own (the comparators, whose direction
-    /// keeps data in the CG block; PANTR and the eval kernel lend them four CG vectors that are dead during sweeps)
-    __host__ __device__ static size_t scratch_doubles(int N) { return (size_t)13 * (N + 1) + 1; }
+    /// keeps data in the CG block; PANTR and the eval kernel lend them the five vector slots z, r, d, (Bd), step,
+    /// which are dead during sweeps: 5 npad >= 20 N covers 18 (N + 1) + 2 for every N, checked at handle creation)
+    __host__ __device__ static size_t scratch_doubles(int N) { return (size_t)18 * (N + 1) + 2; }
     /// realistic_quadcopter: the coefficients of the angle-rate adjoints (5 per substage), evaluated for
     /// all stages at once ahead of the sequential angle-adjoint recursion
     static constexpr int COEF = 20;
@@ -211,6 +212,61 @@ struct ScalarALProblem {
             sbar[l] = sbar[l] + a[l];
     }
 
+    /// The sequential part of the sweeps: y <- step(operands of the stage, y) over the stages, component j3
+    /// of a 3-vector on every lane (lane j < 3 of every 16-lane row: component j; the other lanes shadow
+    /// component 2 - every lane stores, lanes of equal j3 the same value to the same address).  UP: stages
+    /// 0..N-1, y(k) stored to out[k nx] and the final value to out[N nx]; otherwise stages N-1..0 with
+    /// y(k+1) stored to out[(k+1) nx]  (`out` points at the component's column).  prep(k) READS the
+    /// operands of stage k (no arithmetic: the wavefront would wait for the reads right there); those of the
+    /// next group of G stages are requested before the current group runs, and `step` derives what it needs
+    /// from them ahead of its dependent chain.  G x (LDS reads of prep) <= 12: the hardware counts 15
+    /// outstanding reads.
+    template <bool UP, int G, class Prep, class Step>
+    __device__ __forceinline__ double stage_recursion(double y, double *out, Prep prep, Step step) const {
+        using Ops = decltype(prep(0));
+        auto at   = [&](int i) { return UP ? i : N - 1 - i; }; // i-th stage visited
+        auto fetch = [&](int i0, Ops (&o)[G]) {
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+                o[q] = prep(at(i0 + q));
+        };
+        auto run = [&](int i0, const Ops (&o)[G]) {
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                out[(UP ? at(i0 + q) : at(i0 + q) + 1) * nx] = y;
+                y = step(o[q], y);
+            }
+        };
+        int i = 0;
+        if (G <= N) {
+            Ops oA[G], oB[G];
+            fetch(0, oA);
+            while (true) {
+                const bool more = i + 2 * G <= N;
+                if (more)
+                    fetch(i + G, oB);
+                run(i, oA);
+                i += G;
+                if (!more)
+                    break;
+                const bool more2 = i + 2 * G <= N;
+                if (more2)
+                    fetch(i + G, oA);
+                run(i, oB);
+                i += G;
+                if (!more2)
+                    break;
+            }
+        }
+        for (; i < N; ++i) { // fewer than G stages left
+            out[(UP ? at(i) : at(i) + 1) * nx] = y;
+            y = step(prep(at(i)), y);
+        }
+        if (UP)
+            out[N * nx] = y;
+        return y;
+    }
+
     /// Forward sweep.  The states form a cascade angles -> velocities -> positions, so little is
     /// sequential: three short scans (one fma per stage and component) and, for realistic_quadcopter,
     /// the attitude (A+B below as one stage-by-stage integration of the three angles; for quadcopter,
@@ -234,34 +290,16 @@ struct ScalarALProblem {
         const double *yS = mvec(MV_YS), *Sig = mvec(MV_SIG);
         // the scans run component j3 (of 3) on every lane: lanes with the same j3 hold, and store, the same value
         const int j3 = (lane & 15) < 3 ? (lane & 15) : 2;
-        // state_{k+1} = fma(c6, slope(k), state_k) for k = 0..N-1, storing state_k to X[k][off + j3] on the way;
-        // the slopes do not depend on the recursion: eight at a time are fetched ahead of the eight dependent fmas
-        auto scan = [&](int off, auto slope) {
-            double acc = x0[off + j3];
-            int k = 0;
-            for (; k + 8 <= N; k += 8) {
-                double c[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    c[i] = slope(k + i);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    X[(k + i) * nx + off + j3] = acc;
-                    acc = madd(M::c6, c[i], acc);
-                }
-            }
-            for (; k < N; ++k) {
-                X[k * nx + off + j3] = acc;
-                acc = madd(M::c6, slope(k), acc);
-            }
-            X[N * nx + off + j3] = acc;
+        // state_{k+1} = fma(c6, slope(k), state_k) for k = 0..N-1, state_k stored to X[k][off + j3] on the way
+        auto scan = [&](int off, auto read, auto slope) {
+            stage_recursion<true, 8>(x0[off + j3], X + off + j3, read,
+                                     [&](double raw, double acc) { return madd(M::c6, slope(raw), acc); });
         };
+        auto as_is = [](double c) { return c; };
         if constexpr (M::angles_are_integrated_inputs) {
             // ---- A: angles ----
-            scan(6, [&](int k) {
-                const double w = u[nu * k + 1 + j3];
-                return madd(2.0, w, madd(2.0, w, w)) + w;
-            });
+            scan(6, [&](int k) { return u[nu * k + 1 + j3]; },
+                 [](double w) { return madd(2.0, w, madd(2.0, w, w)) + w; });
             wave_sync();
             // ---- B: trigonometry of every substage state: task = (stage, {s, s + Ts/2 k, s + Ts k}, angle) ----
             for (int base = 0; base < 9 * (N + 1); base += WAVE) {
@@ -336,7 +374,7 @@ struct ScalarALProblem {
         }
         wave_sync();
         // ---- D: velocities ----
-        scan(3, [&](int k) { return cmb[3 * k + j3]; });
+        scan(3, [&](int k) { return cmb[3 * k + j3]; }, as_is);
         wave_sync();
         // ---- E: position slopes, combined ----
         for (int k = lane; k < N; k += WAVE) {
@@ -351,7 +389,7 @@ struct ScalarALProblem {
         }
         wave_sync();
         // ---- F: positions ----
-        scan(0, [&](int k) { return cmb[3 * k + j3]; });
+        scan(0, [&](int k) { return cmb[3 * k + j3]; }, as_is);
         wave_sync();
         // ---- G: constraints, multiplier estimates, costs ----
         for (int k = lane; k <= N; k += WAVE) {
@@ -430,58 +468,54 @@ struct ScalarALProblem {
         wave_sync();
         const int j3 = (lane & 15) < 3 ? (lane & 15) : 2;
         double *LAM = Xt;
-        // lam(k) = step(k, lam(k+1)) for k = N-1..0, with lam(k+1) stored to LAM[k+1][off + j3] on the way;
-        // prep(k) fetches what step k needs that does not depend on the recursion, eight stages ahead
+        // lam(k) = step(prep(k), lam(k+1)) for k = N-1..0, lam(k+1) stored to LAM[k+1][off + j3] on the way
         auto scan_down = [&](int off, double lam, auto prep, auto step) {
-            int k = N - 1;
-            for (; k - 7 >= 0; k -= 8) {
-                decltype(prep(0)) o[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    o[i] = prep(k - i);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    LAM[(k - i + 1) * nx + off + j3] = lam;
-                    lam = step(o[i], lam);
-                }
-            }
-            for (; k >= 0; --k) {
-                LAM[(k + 1) * nx + off + j3] = lam;
-                lam = step(prep(k), lam);
-            }
+            stage_recursion<false, 4>(lam, LAM + off + j3, prep, step);
         };
-        const double pf = j3 == 2 ? 0.5 : 0.25; // M::pf(j3)
-        struct Two {
-            double a, b;
-        };
+        // The operands of the two running sums are prepared for all stages at once (lane = stage), two per
+        // stage and component at scr[6 k + 2 j], so that a stage of the recursion is one 16-byte read, its
+        // additions and a store (a lone wavefront issues an instruction every ~8 cycles: the recursions
+        // cost what they count).
+        auto pair_at = [&](int k) { return *reinterpret_cast<const double2 *>(scr + 6 * k + 2 * j3); };
         // ---- 1: position adjoints ----
+        for (int k = lane; k < N; k += WAVE) {
+            const double y3 = yh[nc * k + 3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double sk    = X[k * nx + j];
+                scr[6 * k + 2 * j]     = (2.0 * 10.0) * (sk - M::pf(j));
+                scr[6 * k + 2 * j + 1] = j < 2 ? (2.0 * sk) * y3 : 0.0;
+            }
+        }
+        wave_sync();
         {
-            const double sN = X[N * nx + j3];
+            const double sN = X[N * nx + j3], pf = j3 == 2 ? 0.5 : 0.25; // M::pf(j3)
             double lam = 0.0 + (2.0 * 250.0) * (sN - pf);
             if (j3 < 2)
                 lam = lam - ((2.0 * sN) * yh[nc * N + 3]);
-            scan_down(
-                0, lam,
-                [&](int k) {
-                    const double sk = X[k * nx + j3];
-                    return Two{(2.0 * 10.0) * (sk - pf), j3 < 2 ? (2.0 * sk) * yh[nc * k + 3] : 0.0};
-                },
-                [&](const Two &o, double mu) { return (mu + o.a) - o.b; });
+            scan_down(0, lam, pair_at, [](const double2 &o, double mu) { return (mu + o.x) - o.y; });
         }
         wave_sync();
         // ---- 2: velocity adjoints ----
-        {
-            double lam = 0.0 + (2.0 * 25.0) * X[N * nx + 3 + j3];
-            scan_down(
-                3, lam,
-                [&](int k) { return Two{M::c6 * LAM[(k + 1) * nx + j3], (2.0 * 1.0) * X[k * nx + 3 + j3]}; },
-                [&](const Two &o, double mu) {
-                    const double t2 = 2.0 * o.a;
-                    return ((((mu + o.a) + t2) + t2) + o.a) + o.b;
-                });
+        for (int k = lane; k < N; k += WAVE) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                scr[6 * k + 2 * j]     = M::c6 * LAM[(k + 1) * nx + j];
+                scr[6 * k + 2 * j + 1] = (2.0 * 1.0) * X[k * nx + 3 + j];
+            }
         }
         wave_sync();
-        // ---- 3: substage adjoints of f_c on the velocity parts of their seeds (lane = stage) ----
+        {
+            double lam = 0.0 + (2.0 * 25.0) * X[N * nx + 3 + j3];
+            scan_down(3, lam, pair_at, [](const double2 &o, double mu) {
+                const double t2 = 2.0 * o.x;
+                return ((((mu + o.x) + t2) + t2) + o.x) + o.y;
+            });
+        }
+        wave_sync();
+        // ---- 3: substage adjoints of f_c on the velocity parts of their seeds (lane = stage).  Leaves, per
+        //         stage and angle j, the record R = (A_4, A_3, A_2, A_1, dl/da, (dc/da)' yhat)_j at scr[18 k + 6 j]
+        //         (what the recursion of lam_a adds, in the order it adds it), and the thrust gradient ----
         for (int k = lane; k < N; k += WAVE) {
             const double2 *tg = TG + 12 * k;
             double uk[nu], kb[nx], sb[nx], ub[nu], ub0[4];
@@ -497,7 +531,7 @@ struct ScalarALProblem {
                 sgp[i] = M::c6 * LAM[(k + 1) * nx + i];
                 sgv[i] = M::c6 * LAM[(k + 1) * nx + 3 + i];
             }
-            double *A = scr + 13 * k;
+            double *R = scr + 18 * k;
             // substage 4: seed c6 lam
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -506,7 +540,7 @@ struct ScalarALProblem {
             ub0[0] = ub[0];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                A[j] = sb[6 + j];
+                R[6 * j] = sb[6 + j];
             // substage 3: seed 2 c6 lam + Ts a_4, a_4[v] = the position part of seed 4
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -515,7 +549,7 @@ struct ScalarALProblem {
             ub0[1] = ub[0];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                A[3 + j] = sb[6 + j];
+                R[6 * j + 1] = sb[6 + j];
             // substage 2: seed 2 c6 lam + Ts/2 a_3
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -524,17 +558,25 @@ struct ScalarALProblem {
             ub0[2] = ub[0];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                A[6 + j] = sb[6 + j];
+                R[6 * j + 2] = sb[6 + j];
             // substage 1: seed c6 lam + Ts/2 a_2
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 kb[3 + i] = madd(M::hTs, 2.0 * sgp[i], sgv[i]);
-            M::fc_adj_translation(M::trig_load(tg), uk, kb, sb, ub);
+            const auto t1 = M::trig_load(tg);
+            M::fc_adj_translation(t1, uk, kb, sb, ub);
             ub0[3] = ub[0];
+            const double *yb = yh + nc * k;
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                A[9 + j] = sb[6 + j];
-            A[12] = ((ub0[0] + ub0[1]) + ub0[2]) + ub0[3];
+            for (int j = 0; j < 3; ++j) {
+                R[6 * j + 3] = sb[6 + j];
+                R[6 * j + 4] = (2.0 * 1.0) * X[k * nx + 6 + j];
+            }
+            // (dc/da)' yhat: c_0 = phi, c_1 = theta, c_2 = cos phi cos theta
+            R[5]  = yb[0] - ((t1.s0 * t1.c1) * yb[2]);
+            R[11] = yb[1] - ((t1.c0 * t1.s1) * yb[2]);
+            R[17] = 0.0;
+            grad[nu * k] = (((ub0[0] + ub0[1]) + ub0[2]) + ub0[3]) + (2e-4 * uk[0]);
             if constexpr (!M::angles_are_integrated_inputs) {
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) { // in the order the recursion visits them: substage 4 first
@@ -550,125 +592,116 @@ struct ScalarALProblem {
         }
         wave_sync();
         // ---- 4: angle adjoints ----
-        if constexpr (M::angles_are_integrated_inputs) {
-            // (dc/da)' yhat of stage k on this lane's angle: c_0 = phi, c_1 = theta, c_2 = cos phi cos theta
-            auto constr_term = [&](int k) {
-                const auto t      = M::trig_load(TG + 12 * k);
-                const double *yb  = yh + nc * k;
-                return j3 == 0 ? yb[0] - ((t.s0 * t.c1) * yb[2]) : j3 == 1 ? yb[1] - ((t.c0 * t.s1) * yb[2]) : 0.0;
-            };
-            double lam = 0.0 + (2.0 * 10.0) * X[N * nx + 6 + j3];
-            if (j3 < 2)
-                lam = lam + constr_term(N);
-            struct Six {
-                double a4, a3, a2, a1, g, c;
-            };
-            scan_down(
-                6, lam,
-                [&](int k) {
-                    const double *A = scr + 13 * k;
-                    return Six{A[j3], A[3 + j3], A[6 + j3], A[9 + j3], (2.0 * 1.0) * X[k * nx + 6 + j3], constr_term(k)};
-                },
-                [&](const Six &o, double mu) {
-                    const double l = ((((mu + o.a4) + o.a3) + o.a2) + o.a1) + o.g;
-                    return j3 < 2 ? l + o.c : l;
-                });
-        } else {
-            // the angle rates depend on the angles: the four substage adjoints of a stage chain through
-            // angle_rates_adj (values the same on every lane), on top of the A_s of phase 3; this is also
-            // where the gradients of the three rate inputs come from
-            auto sel3 = [&](const double (&v)[3]) { return j3 == 0 ? v[0] : j3 == 1 ? v[1] : v[2]; };
-            auto constr_adj_angles = [&](int k, double (&l)[3]) {
-                const auto t     = M::trig_load(TG + 12 * k);
-                const double *yb = yh + nc * k;
-                l[0] = l[0] + (yb[0] - ((t.s0 * t.c1) * yb[2]));
-                l[1] = l[1] + (yb[1] - ((t.c0 * t.s1) * yb[2]));
-            };
-            double mu[3];
+        {
+            // terminal stage: dl_N/da + (dc/da)' yhat_N
+            const auto tN     = M::trig_load(TG + 12 * N);
+            const double *ybN = yh + nc * N;
+            double muN[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                mu[j] = 0.0 + (2.0 * 10.0) * X[N * nx + 6 + j];
-            constr_adj_angles(N, mu);
-            for (int k = N - 1; k >= 0; --k) {
-                LAM[(k + 1) * nx + 6 + j3] = sel3(mu);
-                const double *A   = scr + 13 * k;
-                const double2 *tg = TG + 12 * k;
-                auto rates_adj    = [&](int sub, const double (&kba)[3], double (&sba)[3], double (&uba)[3]) {
-                    const double *o  = coef + COEF * k + 5 * sub;
-                    const double2 e0 = tg[9 - 3 * sub], e1 = tg[10 - 3 * sub]; // (sin, cos) of phi, theta
-                    M::angle_rates_adj_apply(e0.x, e1.x, e1.y, typename M::template RateAdjCoef<double>{o[0], o[1], o[2], o[3], o[4]},
-                                             kba, sba, uba);
+                muN[j] = 0.0 + (2.0 * 10.0) * X[N * nx + 6 + j];
+            muN[0] = muN[0] + (ybN[0] - ((tN.s0 * tN.c1) * ybN[2]));
+            muN[1] = muN[1] + (ybN[1] - ((tN.c0 * tN.s1) * ybN[2]));
+            if constexpr (M::angles_are_integrated_inputs) {
+                struct Six {
+                    double2 a, b, c; // (A_4, A_3), (A_2, A_1), (dl/da, (dc/da)' yhat)
                 };
-                double uk[nu], kb1[3], kb2[3], kb3[3], kb4[3], sbar[3], a[3], ubar[3], ua[3];
+                scan_down(
+                    6, j3 == 0 ? muN[0] : j3 == 1 ? muN[1] : muN[2],
+                    [&](int k) {
+                        const double2 *r = reinterpret_cast<const double2 *>(scr + 18 * k + 6 * j3);
+                        return Six{r[0], r[1], r[2]};
+                    },
+                    [&](const Six &o, double mu) {
+                        const double l = ((((mu + o.a.x) + o.a.y) + o.b.x) + o.b.y) + o.c.x;
+                        return j3 < 2 ? l + o.c.y : l;
+                    });
+            } else {
+                // the angle rates depend on the angles: the four substage adjoints of a stage chain through
+                // angle_rates_adj (values the same on every lane), on top of the A_s of phase 3; this is also
+                // where the gradients of the three rate inputs come from
+                auto sel3 = [&](const double (&v)[3]) { return j3 == 0 ? v[0] : j3 == 1 ? v[1] : v[2]; };
+                double mu[3] = {muN[0], muN[1], muN[2]};
+                for (int k = N - 1; k >= 0; --k) {
+                    LAM[(k + 1) * nx + 6 + j3] = sel3(mu);
+                    const double *R   = scr + 18 * k;
+                    const double2 *tg = TG + 12 * k;
+                    auto rates_adj    = [&](int sub, const double (&kba)[3], double (&sba)[3], double (&uba)[3]) {
+                        const double *o  = coef + COEF * k + 5 * sub;
+                        const double2 e0 = tg[9 - 3 * sub], e1 = tg[10 - 3 * sub]; // (sin, cos) of phi, theta
+                        M::angle_rates_adj_apply(e0.x, e1.x, e1.y, typename M::template RateAdjCoef<double>{o[0], o[1], o[2], o[3], o[4]},
+                                                 kba, sba, uba);
+                    };
+                    double uk[nu], kb1[3], kb2[3], kb3[3], kb4[3], sbar[3], a[3], ubar[3], ua[3];
 #pragma unroll
-                for (int c = 0; c < nu; ++c)
-                    uk[c] = u[nu * k + c];
+                    for (int c = 0; c < nu; ++c)
+                        uk[c] = u[nu * k + c];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const double sg = M::c6 * mu[j];
-                    kb1[j]  = sg;
-                    kb2[j]  = 2.0 * sg;
-                    kb3[j]  = 2.0 * sg;
-                    kb4[j]  = sg;
-                    sbar[j] = mu[j];
-                    a[j]    = A[j];
+                    for (int j = 0; j < 3; ++j) {
+                        const double sg = M::c6 * mu[j];
+                        kb1[j]  = sg;
+                        kb2[j]  = 2.0 * sg;
+                        kb3[j]  = 2.0 * sg;
+                        kb4[j]  = sg;
+                        sbar[j] = mu[j];
+                        a[j]    = R[6 * j];
+                    }
+                    rates_adj(0, kb4, a, ubar);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        sbar[j] = sbar[j] + a[j];
+                        kb3[j]  = madd(M::Ts, a[j], kb3[j]);
+                        a[j]    = R[6 * j + 1];
+                    }
+                    rates_adj(1, kb3, a, ua);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        ubar[j] = ubar[j] + ua[j];
+                        sbar[j] = sbar[j] + a[j];
+                        kb2[j]  = madd(M::hTs, a[j], kb2[j]);
+                        a[j]    = R[6 * j + 2];
+                    }
+                    rates_adj(2, kb2, a, ua);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        ubar[j] = ubar[j] + ua[j];
+                        sbar[j] = sbar[j] + a[j];
+                        kb1[j]  = madd(M::hTs, a[j], kb1[j]);
+                        a[j]    = R[6 * j + 3];
+                    }
+                    rates_adj(3, kb1, a, ua);
+                    double g[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        ubar[j] = ubar[j] + ua[j];
+                        sbar[j] = sbar[j] + a[j];
+                        mu[j]   = sbar[j] + R[6 * j + 4];
+                        g[j]    = ubar[j] + ((2e-4 * uk[1 + j]) + (20.0 * uk[1 + j]));
+                    }
+                    grad[nu * k + 1 + j3] = sel3(g);
+                    mu[0] = mu[0] + R[5];
+                    mu[1] = mu[1] + R[11];
                 }
-                rates_adj(0, kb4, a, ubar);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    sbar[j] = sbar[j] + a[j];
-                    kb3[j]  = madd(M::Ts, a[j], kb3[j]);
-                    a[j]    = A[3 + j];
-                }
-                rates_adj(1, kb3, a, ua);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    ubar[j] = ubar[j] + ua[j];
-                    sbar[j] = sbar[j] + a[j];
-                    kb2[j]  = madd(M::hTs, a[j], kb2[j]);
-                    a[j]    = A[6 + j];
-                }
-                rates_adj(2, kb2, a, ua);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    ubar[j] = ubar[j] + ua[j];
-                    sbar[j] = sbar[j] + a[j];
-                    kb1[j]  = madd(M::hTs, a[j], kb1[j]);
-                    a[j]    = A[9 + j];
-                }
-                rates_adj(3, kb1, a, ua);
-                double g[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    ubar[j] = ubar[j] + ua[j];
-                    sbar[j] = sbar[j] + a[j];
-                    mu[j]   = sbar[j] + (2.0 * 1.0) * X[k * nx + 6 + j];
-                    g[j]    = ubar[j] + ((2e-4 * uk[1 + j]) + (20.0 * uk[1 + j]));
-                }
-                grad[nu * k + 1 + j3] = sel3(g);
-                constr_adj_angles(k, mu);
             }
         }
         wave_sync();
-        // ---- 5: gradients (lane = stage) ----
-        for (int k = lane; k < N; k += WAVE) {
-            const double *A = scr + 13 * k;
-            const double u0 = u[nu * k];
-            grad[nu * k] = A[12] + (2e-4 * u0);
-            if constexpr (M::angles_are_integrated_inputs) {
+        // ---- 5: gradients of the rate inputs (lane = stage; realistic_quadcopter: done by the recursion) ----
+        if constexpr (M::angles_are_integrated_inputs) {
+            for (int k = lane; k < N; k += WAVE) {
+                const double *R = scr + 18 * k;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const double sga = M::c6 * LAM[(k + 1) * nx + 6 + j];
                     const double kb4 = sga;
-                    const double kb3 = madd(M::Ts, A[j], 2.0 * sga);
-                    const double kb2 = madd(M::hTs, A[3 + j], 2.0 * sga);
-                    const double kb1 = madd(M::hTs, A[6 + j], sga);
+                    const double kb3 = madd(M::Ts, R[6 * j], 2.0 * sga);
+                    const double kb2 = madd(M::hTs, R[6 * j + 1], 2.0 * sga);
+                    const double kb1 = madd(M::hTs, R[6 * j + 2], sga);
                     const double uj  = u[nu * k + 1 + j];
                     grad[nu * k + 1 + j] = (((kb4 + kb3) + kb2) + kb1) + ((2e-4 * uj) + (20.0 * uj));
                 }
             }
+            wave_sync();
         }
-        wave_sync();
     }
 
     /// Adjoint sweep over the stored trajectory and trig store with multipliers yh: grad_i; the adjoints
@@ -1022,73 +1055,29 @@ struct ScalarALProblem {
         }
         wave_sync();
     }
-    /// The 3 x 3 recursions of realistic_quadcopter's attitude: y <- s_j + sum_e c_je y_e, lane j of every
-    /// row holding component j (lanes 3..15: shadows of lane 2), the three components reaching the
-    /// multiply-adds as row-broadcast DPP operands.  UP: stages 0..N-1, y(k) stored to out[k] and the
-    /// final value to out[N] (a'); otherwise stages N-1..0 with y(k+1) stored to out[k+1] (la).
-    /// Operands: 4 doubles (s_j, c_j0, c_j1, c_j2) per component at rec[24 k + 4 j] (two 16-byte LDS
-    /// reads per stage), fetched one group of four stages ahead.
+    /// The 3 x 3 recursions of realistic_quadcopter's attitude in a product: y <- s_j + sum_e c_je y_e, the
+    /// three components reaching the multiply-adds as row broadcasts (three independent DPP moves; a
+    /// DPP operand fused into each multiply-add would put the long DPP latency of v_fmac_f64 on the
+    /// dependent chain three times per stage).  UP: a' (stages 0..N-1), otherwise la (N-1..0).
+    /// Operands: 4 doubles (s_j, c_j0, c_j1, c_j2) per component at rec[24 k + 4 j].
     template <bool UP>
     __device__ __forceinline__ void attitude_recursion(const double *rec, double *out, double y0) const {
-        const int j3      = (lane & 15) < 3 ? (lane & 15) : 2;
-        const bool writer = lane < 3;
-        double y          = y0;
-        // the three broadcasts are independent moves; a DPP operand fused into each multiply-add would
-        // put the (long) DPP latency of v_fmac_f64 on the dependent chain three times per stage
-        auto step = [&](const double2 &a, const double2 &b) { // a = (s, c0), b = (c1, c2)
-            const double y0_ = row_bcast<0>(y), y1_ = row_bcast<1>(y), y2_ = row_bcast<2>(y);
-            double nxt = __builtin_fma(a.y, y0_, a.x);
-            nxt        = __builtin_fma(b.x, y1_, nxt);
-            nxt        = __builtin_fma(b.y, y2_, nxt);
-            y = nxt;
+        const int j3 = (lane & 15) < 3 ? (lane & 15) : 2;
+        struct Rec {
+            double2 a, b; // (s, c0), (c1, c2)
         };
-        auto at = [&](int i) { // i-th stage visited (clamped: the operand fetch runs one group ahead)
-            i = i < N ? i : N - 1;
-            return UP ? i : N - 1 - i;
-        };
-        constexpr int G = 4;
-        auto fetch = [&](int i0, double2 (&a)[G], double2 (&b)[G]) {
-#pragma unroll
-            for (int q = 0; q < G; ++q) {
-                const double2 *p = reinterpret_cast<const double2 *>(rec + 24 * at(i0 + q) + 4 * j3);
-                a[q] = p[0];
-                b[q] = p[1];
-            }
-        };
-        auto run = [&](int i0, const double2 (&a)[G], const double2 (&b)[G]) {
-            if (i0 + G <= N) {
-                double kept[G];
-#pragma unroll
-                for (int q = 0; q < G; ++q) {
-                    kept[q] = y;
-                    step(a[q], b[q]);
-                }
-                if (writer)
-#pragma unroll
-                    for (int q = 0; q < G; ++q)
-                        out[(UP ? at(i0 + q) : at(i0 + q) + 1) * nx + j3] = kept[q];
-            } else {
-#pragma unroll
-                for (int q = 0; q < G; ++q)
-                    if (i0 + q < N) {
-                        if (writer)
-                            out[(UP ? at(i0 + q) : at(i0 + q) + 1) * nx + j3] = y;
-                        step(a[q], b[q]);
-                    }
-            }
-        };
-        double2 aA[G], bA[G], aB[G], bB[G];
-        fetch(0, aA, bA);
-        for (int i = 0; i < N; i += 2 * G) {
-            fetch(i + G, aB, bB);
-            run(i, aA, bA);
-            if (i + G >= N)
-                break;
-            fetch(i + 2 * G, aA, bA);
-            run(i + G, aB, bB);
-        }
-        if (UP && writer)
-            out[N * nx + j3] = y;
+        stage_recursion<UP, 4>(
+            y0, out + j3,
+            [&](int k) {
+                const double2 *p = reinterpret_cast<const double2 *>(rec + 24 * k + 4 * j3);
+                return Rec{p[0], p[1]};
+            },
+            [](const Rec &o, double y) {
+                const double y0_ = row_bcast<0>(y), y1_ = row_bcast<1>(y), y2_ = row_bcast<2>(y);
+                double nxt = __builtin_fma(o.a.y, y0_, o.a.x);
+                nxt        = __builtin_fma(o.b.x, y1_, nxt);
+                return __builtin_fma(o.b.y, y2_, nxt);
+            });
     }
     /// y / Sigma for the sweeps; call whenever y or Sigma changed (they are fixed during an inner solve).
     __device__ __forceinline__ void set_al() const {
@@ -1375,7 +1364,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
             x0_lds[lane] = a.x0[(size_t)inst * M::nx + lane];
         pb.x0 = x0_lds;
         pb.coef = x0_lds + PB::X0_DOUBLES;
-        pb.scr  = pb.vec(PB::CG_BASE + 3); // four vector slots this kernel does not use
+        pb.scr  = pb.vec(PB::CG_BASE + 3); // five vector slots this kernel does not use
     }
     double *u = pb.vec(0), *v = pb.vec(1), *o = pb.vec(2);
     for (int i = lane; i < a.n; i += WAVE) {
@@ -1390,8 +1379,10 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
     pb.set_al();
     double psi = 0.0;
     if (a.mode == ALM_EVAL_PSI_GRAD) {
-        psi = pb.eval_psi_xhat(u, 0);
-        pb.eval_grad_xhat(u, o, 0);
+        for (int rep = 0; rep < a.reps; ++rep) {
+            psi = pb.eval_psi_xhat(u, 0);
+            pb.eval_grad_xhat(u, o, 0);
+        }
         for (int j = lane; j < a.m; j += WAVE)
             a.out_m[(size_t)inst * a.m + j] = pb.mvec(PB::MV_YH)[j];
     } else if (a.mode == ALM_EVAL_PROX) {
@@ -1411,8 +1402,10 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
     } else if (a.mode == ALM_EVAL_GRAD_L) {
         // grad_x L(x, y) = grad f + grad g' y (formulation.hpp:98,170-174): the trajectory at u, then
         // the adjoint sweep with the caller's y as the multipliers (Sigma plays no role)
-        pb.eval_psi_xhat(u, 0);
-        pb.template reverse<false>(u, pb.mvec(PB::MV_Y), o);
+        for (int rep = 0; rep < a.reps; ++rep) { // reps > 1: timing aid (pantr_debug_set_eval_reps), same result
+            pb.eval_psi_xhat(u, 0);
+            pb.template reverse<false>(u, pb.mvec(PB::MV_Y), o);
+        }
     } else {
         pb.eval_psi_xhat(u, 0);
         pb.eval_grad_xhat(u, pb.vec(3), 0); // records the tape at u

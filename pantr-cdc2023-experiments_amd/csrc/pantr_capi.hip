@@ -556,6 +556,8 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
                         : ScalarALProblem<QuadModelT<false>>::lds_doubles(b->N, b->npad, b->mpad, dedicated_scratch)) *
                    sizeof(double);
         };
+        if ((size_t)5 * b->npad < ScalarALProblem<QuadModelT<false>>::scratch_doubles(b->N))
+            return fail(PANTR_ERR_OUT_OF_RANGE, "internal: the sweeps' scratch does not fit the five vector slots lent to it");
         b->lds_bytes     = lds_of(false); // method=pantr and the evaluation kernel
         b->lds_bytes_cmp = lds_of(true);  // the comparators: the cascade sweeps' scratch gets LDS of its own
     } else {
