@@ -85,6 +85,7 @@ struct ScalarALProblem {
     __host__ __device__ static size_t workspace_doubles(int N) { return (size_t)NCOEF * tape_pitch(N) + HNB; }
 
     static constexpr int CG_BASE = NUM_ITER_VEC; ///< all 20 vectors in LDS: iterates first, then the CG block
+    static constexpr int XIO_SLOT = CG_BASE + C_XIO;
     static constexpr int X0_DOUBLES = 16;        ///< the initial state, at the end of the dynamic LDS
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
     __device__ __forceinline__ double *ivec(int slot) const { return lds + slot * npad; }

@@ -98,13 +98,13 @@ constexpr int TRACE_COLS = 11;
 constexpr int NUM_VEC    = 20; ///< working vectors of the inner solvers (slots S_* inside them)
 constexpr int NUM_ITER_VEC = 12; ///< three iterates x {x, xhat, grad, p}
 /// PANTR on the hanging chain keeps only the vectors of the trust-region subproblem in LDS (q, Hv,
-/// r_J, z, r, d, Bd, step) plus one staging slot for the decision vector a sweep reads stage by
-/// stage; the three iterates live in HBM/L2 (WaveProblem<M, true>): they are touched by
-/// element-wise passes only, every lane reading and writing its own elements as coalesced
-/// 512-byte rows.  9 slots x 192 doubles + the 10 KiB landing buffers = 23.5 KiB at N = 60 (six
-/// instances per CU) and 37 KiB at N = 120 (four per CU: all 1024 instances of the stress
-/// configuration resident at once); with everything in LDS it was 40 KiB and 70 KiB.
-constexpr int NUM_CG_VEC = 9;
+/// r_J, z, r, d, step; the decision vector a sweep reads stage by stage is staged in z's slot, which
+/// is dead outside the CG loop); the three iterates live in HBM/L2 (WaveProblem<M, true>): they are
+/// touched by element-wise passes only, every lane reading and writing its own elements as coalesced
+/// 512-byte rows.  7 slots x 192 doubles + the 10 KiB landing buffers = 20.5 KiB at N = 60 (seven
+/// instances per CU) and 31 KiB at N = 120 (five per CU); with everything in LDS it was 40 KiB and
+/// 70 KiB.
+constexpr int NUM_CG_VEC = 7;
 /// The in/out vector of an inner solve shares the slot of the direction's scratch vector (PANTR:
 /// the CG step; PANOC: unused): it is read before the first and written after the last use of
 /// that scratch.  Offset inside the CG block (slot PB::CG_BASE + C_XIO).
@@ -150,7 +150,11 @@ struct WaveProblem {
     /// LDS vector `slot`; the CG block starts at CG_BASE.
     static constexpr int CG_BASE   = ITER_GLOBAL ? 0 : NUM_ITER_VEC;
     static constexpr int LDS_SLOTS = ITER_GLOBAL ? NUM_CG_VEC : NUM_VEC;
-    static constexpr int S_STAGE   = CG_BASE + 8; ///< ITER_GLOBAL: staging copy of a sweep's decision vector
+    /// slot of the in/out vector of an inner solve = the direction's step vector (see C_XIO)
+    static constexpr int XIO_SLOT  = CG_BASE + (ITER_GLOBAL ? NUM_CG_VEC - 1 : C_XIO);
+    /// ITER_GLOBAL: staging copy of a sweep's decision vector; shares the slot of the CG iterate z, which
+    /// lives only inside the CG loop (no sweep runs there)
+    static constexpr int S_STAGE   = CG_BASE + 3;
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
     /// Iterate vector `slot` (0..11): HBM (ITER_GLOBAL) or the first twelve LDS slots.
     __device__ __forceinline__ double *ivec(int slot) const {
@@ -454,8 +458,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
     const int n = pb.n, nj = pb.nj;
     // iterate vectors (pb.ivec: HBM or LDS, the problem decides) and the CG block in LDS
     enum { S_IT0 = 0, S_IT1 = 4, S_IT2 = 8, S_Q = PB::CG_BASE + 0, S_WORK = PB::CG_BASE + 1, S_RJ = PB::CG_BASE + 2,
-           S_Z = PB::CG_BASE + 3, S_R = PB::CG_BASE + 4, S_D = PB::CG_BASE + 5, S_BD = PB::CG_BASE + 6,
-           S_STEP = PB::CG_BASE + C_XIO };
+           S_Z = PB::CG_BASE + 3, S_R = PB::CG_BASE + 4, S_D = PB::CG_BASE + 5, S_STEP = PB::XIO_SLOT };
     IterateRef curr{S_IT0, 0}, prox{S_IT1, 1}, cand{S_IT2, 2};
     auto X_  = [&](const IterateRef &it) { return pb.ivec(it.base + 0); };
     auto XH_ = [&](const IterateRef &it) { return pb.ivec(it.base + 1); };
@@ -858,7 +861,7 @@ __global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // 
         for (int i = lane; i < NUM_ITER_VEC * a.npad; i += WAVE)
             pb.giter[i] = 0.0;
     wave_sync();
-    double *x_io = pb.vec(PB::CG_BASE + C_XIO);
+    double *x_io = pb.vec(PB::XIO_SLOT);
     for (int j = 0; j < nj; ++j) {
         int i = j * WAVE + lane;
         if (i < n)
