@@ -570,6 +570,57 @@ struct SingleShootingAL {
         }
         excl[n] = carry;
     }
+    /// An affine map y -> A y + b of a pair, and (later o earlier) with the products in this order.
+    struct Affine2 {
+        double A[2][2], b[2];
+        static Affine2 identity() { return {{{1.0, 0.0}, {0.0, 1.0}}, {0.0, 0.0}}; }
+        void apply(const double *y, double *out) const {
+            for (int i = 0; i < 2; ++i)
+                out[i] = std::fma(A[i][1], y[1], std::fma(A[i][0], y[0], b[i]));
+        }
+        static Affine2 compose(const Affine2 &later, const Affine2 &earlier) {
+            Affine2 c;
+            for (int i = 0; i < 2; ++i) {
+                for (int j = 0; j < 2; ++j)
+                    c.A[i][j] = std::fma(later.A[i][1], earlier.A[1][j], later.A[i][0] * earlier.A[0][j]);
+                c.b[i] = std::fma(later.A[i][1], earlier.b[1], std::fma(later.A[i][0], earlier.b[0], later.b[i]));
+            }
+            return c;
+        }
+    };
+    /// y(k+1) = m[k](y(k)) for a sequence of affine maps of a pair, with the compositions grouped like
+    /// the additions of prefix_scan(): blocks of 64 consecutive maps (a short block is padded with the
+    /// identity); inside a block Kogge-Stone at distances 1, 2, 4, 8 within groups of 16 (an entry
+    /// without a partner composes with the identity), then the odd groups compose with the total of the
+    /// group before them, then the upper half with the total of the lower half; y(k+1) = (composition
+    /// of the block's maps up to k) applied to the block's initial value.  out: y(0..n), 2 values each.
+    static void affine_scan(const Affine2 *m, int n, const double *y0, double *out /* 2 (n + 1) */) {
+        double carry[2] = {y0[0], y0[1]};
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            Affine2 x[64], t[64];
+            const Affine2 id = Affine2::identity();
+            for (int i = 0; i < 64; ++i)
+                x[i] = k0 + i < n ? m[k0 + i] : id;
+            for (int d = 1; d <= 8; d *= 2) {
+                for (int i = 0; i < 64; ++i)
+                    t[i] = Affine2::compose(x[i], (i & 15) >= d ? x[i - d] : id);
+                std::copy(t, t + 64, x);
+            }
+            for (int i = 0; i < 64; ++i)
+                t[i] = Affine2::compose(x[i], (i & 16) ? x[(i & ~15) - 1] : id);
+            std::copy(t, t + 64, x);
+            for (int i = 0; i < 64; ++i)
+                t[i] = Affine2::compose(x[i], (i & 32) ? x[31] : id);
+            std::copy(t, t + 64, x);
+            const int cnt = std::min(64, n - k0);
+            out[2 * k0] = carry[0], out[2 * k0 + 1] = carry[1];
+            for (int i = 0; i < cnt; ++i)
+                x[i].apply(carry, out + 2 * (k0 + i + 1));
+            carry[0] = out[2 * (k0 + cnt)], carry[1] = out[2 * (k0 + cnt) + 1];
+        }
+        if (n == 0)
+            out[0] = carry[0], out[1] = carry[1];
+    }
     /// Hv over the tape.  Forward: the tangent trajectory x' = (p', v', a'); each state is its initial
     /// value plus the running sum of increments that do not involve it, so the increments are formed
     /// for all stages first and summed by prefix_scan (attitude of realistic_quadcopter: a 3 x 3
@@ -590,11 +641,27 @@ struct SingleShootingAL {
             }
         }
         if (!angle_rates_are_inputs) {
-            for (int k = 0; k < N; ++k)
-                for (int i = 0; i < 3; ++i) {
-                    const double Sw = dot_seq<3>(tape_[k].Ja[i] + 3, v + nu * k + 1);
-                    xt(k + 1, 6 + i) = dot_seq<3, true>(tape_[k].Ja[i], &xt(k, 6), Sw);
-                }
+            // (phi', theta') is an affine recursion (the yaw does not feed back): affine_scan; the yaw's
+            // tangent is a running sum of increments that involve the other two
+            std::vector<Affine2> am(N);
+            std::vector<double> y2(2 * (N + 1));
+            for (int k = 0; k < N; ++k) {
+                const auto &Ja = tape_[k].Ja;
+                am[k]          = {{{Ja[0][0], Ja[0][1]}, {Ja[1][0], Ja[1][1]}},
+                                  {dot_seq<3>(Ja[0] + 3, v + nu * k + 1), dot_seq<3>(Ja[1] + 3, v + nu * k + 1)}};
+            }
+            const double zero2[2] = {0.0, 0.0};
+            affine_scan(am.data(), N, zero2, y2.data());
+            for (int k = 0; k <= N; ++k)
+                xt(k, 6) = y2[2 * k], xt(k, 7) = y2[2 * k + 1];
+            for (int k = 0; k < N; ++k) {
+                const auto &Ja  = tape_[k].Ja;
+                const double Sw = dot_seq<3>(Ja[2] + 3, v + nu * k + 1);
+                inc[k]          = std::fma(Ja[2][1], xt(k, 7), std::fma(Ja[2][0], xt(k, 6), Sw));
+            }
+            prefix_scan(inc.data(), N, 0.0, run.data());
+            for (int k = 0; k <= N; ++k)
+                xt(k, 8) = run[k];
         }
         // velocity, position
         std::vector<double> Rp(3 * N);
@@ -659,16 +726,30 @@ struct SingleShootingAL {
                     Hv[nu * k + 1 + i] = std::fma(tape_[k].Ja[i][3 + i], lm(k + 1, 6 + i), T[nau * k + 4 + i]);
             }
         } else {
-            for (int k = N - 1; k >= 0; --k) {
+            // yaw: lam_psi(k) = lam_psi(k+1) + T_psi(k); then (lam_phi, lam_theta) by the transposed affine
+            // recursion over the reversed stages, its constant term holding the yaw's contribution
+            for (int j = 0; j < N; ++j)
+                inc[j] = T[nau * (N - 1 - j) + 2];
+            suffix(8);
+            std::vector<Affine2> am(N);
+            std::vector<double> y2(2 * (N + 1));
+            for (int j = 0; j < N; ++j) {
+                const int k    = N - 1 - j;
+                const auto &Ja = tape_[k].Ja;
+                am[j]          = {{{Ja[0][0], Ja[1][0]}, {Ja[0][1], Ja[1][1]}},
+                                  {std::fma(Ja[2][0], lm(k + 1, 8), T[nau * k]), std::fma(Ja[2][1], lm(k + 1, 8), T[nau * k + 1])}};
+            }
+            const double lN[2] = {lm(N, 6), lm(N, 7)};
+            affine_scan(am.data(), N, lN, y2.data());
+            for (int j = 0; j <= N; ++j)
+                lm(N - j, 6) = y2[2 * j], lm(N - j, 7) = y2[2 * j + 1];
+            for (int k = 0; k < N; ++k) {
                 const StageTape &tp = tape_[k];
                 for (int j = 0; j < 3; ++j) {
-                    double acc = T[nau * k + 4 + j], acl = T[nau * k + j];
-                    for (int i = 0; i < 3; ++i) {
+                    double acc = T[nau * k + 4 + j];
+                    for (int i = 0; i < 3; ++i)
                         acc = std::fma(tp.Ja[i][3 + j], lm(k + 1, 6 + i), acc);
-                        acl = std::fma(tp.Ja[i][j], lm(k + 1, 6 + i), acl);
-                    }
                     Hv[nu * k + 1 + j] = acc;
-                    lm(k, 6 + j)       = acl;
                 }
             }
         }

@@ -866,7 +866,6 @@ struct ScalarALProblem {
         asm volatile("" : "+s"(pitch));
         constexpr bool RATES_ARE_INPUTS = M::angles_are_integrated_inputs;
         constexpr int NJA = RATES_ARE_INPUTS ? 3 : 18, NJ = 6 * NAU, NH = NAU * NAU + 9;
-        double *LM = X, *W = reinterpret_cast<double *>(TG);
         auto load_ja = [&](int k, double (&ja)[NJA]) {
 #pragma unroll
             for (int q = 0; q < NJA; ++q)
@@ -891,31 +890,20 @@ struct ScalarALProblem {
             return out;
         };
 
-        if constexpr (!RATES_ARE_INPUTS) {
-            // ---- attitude tangent: operands of the two recursions to LDS (W: 24 doubles per stage; see
-            //      attitude_recursion), then the recursion of a' ----
-            for (int k = lane; k < N; k += WAVE) {
-                double ja[NJA];
-                load_ja(k, ja);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    double acc = ja[6 * i + 3] * v[nu * k + 1];
-                    acc        = __builtin_fma(ja[6 * i + 4], v[nu * k + 2], acc);
-                    acc        = __builtin_fma(ja[6 * i + 5], v[nu * k + 3], acc);
-                    W[24 * k + 4 * i] = acc; // Sw_i
-#pragma unroll
-                    for (int e = 0; e < 3; ++e) {
-                        W[24 * k + 4 * i + 1 + e]      = ja[6 * i + e]; // a'_i: row i of Ja
-                        W[24 * k + 12 + 4 * e + 1 + i] = ja[6 * i + e]; // la_e: column e of Ja
-                    }
-                }
-            }
-            wave_sync();
-            attitude_recursion<true>(W, Xt + 6, 0.0);
-            wave_sync();
-        }
+        // (phi, theta) of realistic_quadcopter: y <- A y + b over the stages; returns y of the stages before this
+        // lane's (the block's initial value on lane 0) and moves the carry on
+        auto scan2 = [&](const Affine2 &m, double (&carry)[2], int cnt, double &o0, double &o1) {
+            const Affine2 P = wave_affine_scan(m);
+            double y0, y1;
+            P.apply(carry[0], carry[1], y0, y1); // y after this lane's stage
+            const double b0 = lane_below(y0), b1 = lane_below(y1);
+            o0       = lane == 0 ? carry[0] : b0;
+            o1       = lane == 0 ? carry[1] : b1;
+            carry[0] = lane_value(y0, cnt - 1);
+            carry[1] = lane_value(y1, cnt - 1);
+        };
         // ---- forward: lane = stage ----
-        double ca[3] = {0.0, 0.0, 0.0}, cv[3] = {0.0, 0.0, 0.0}, cp[3] = {0.0, 0.0, 0.0};
+        double ca[3] = {0.0, 0.0, 0.0}, cv[3] = {0.0, 0.0, 0.0}, cp[3] = {0.0, 0.0, 0.0}, ca2[2] = {0.0, 0.0};
         for (int k0 = 0; k0 < N; k0 += WAVE) {
             const int cnt = N - k0 < WAVE ? N - k0 : WAVE;
             const bool on = lane < cnt;
@@ -930,9 +918,16 @@ struct ScalarALProblem {
                 for (int i = 0; i < 3; ++i)
                     z[i] = scan(on ? cw[i] * z[4 + i] : 0.0, ca[i], cnt);
             } else {
+                double ja[NJA], sw[3];
+                load_ja(k, ja);
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    z[i] = Xt[k * nx + 6 + i];
+                for (int i = 0; i < 3; ++i) {
+                    sw[i] = ja[6 * i + 3] * z[4];
+                    sw[i] = __builtin_fma(ja[6 * i + 4], z[5], sw[i]);
+                    sw[i] = __builtin_fma(ja[6 * i + 5], z[6], sw[i]);
+                }
+                scan2(on ? Affine2{ja[0], ja[1], ja[6], ja[7], sw[0], sw[1]} : affine_identity(), ca2, cnt, z[0], z[1]);
+                z[2] = scan(on ? __builtin_fma(ja[13], z[1], __builtin_fma(ja[12], z[0], sw[2])) : 0.0, ca[2], cnt);
             }
             double pt[3], vt[3];
 #pragma unroll
@@ -951,16 +946,18 @@ struct ScalarALProblem {
                 for (int i = 0; i < 3; ++i) {
                     Xt[k * nx + i]     = pt[i];
                     Xt[k * nx + 3 + i] = vt[i];
-                    if constexpr (RATES_ARE_INPUTS)
-                        Xt[k * nx + 6 + i] = z[i];
+                    Xt[k * nx + 6 + i] = z[i];
                 }
             }
+        }
+        if constexpr (!RATES_ARE_INPUTS) {
+            ca[0] = ca2[0];
+            ca[1] = ca2[1];
         }
         if (lane < 3) { // x'_N: the totals
             Xt[N * nx + lane]     = lane == 0 ? cp[0] : lane == 1 ? cp[1] : cp[2];
             Xt[N * nx + 3 + lane] = lane == 0 ? cv[0] : lane == 1 ? cv[1] : cv[2];
-            if constexpr (RATES_ARE_INPUTS)
-                Xt[N * nx + 6 + lane] = lane == 0 ? ca[0] : lane == 1 ? ca[1] : ca[2];
+            Xt[N * nx + 6 + lane] = lane == 0 ? ca[0] : lane == 1 ? ca[1] : ca[2];
         }
         wave_sync();
         // ---- lam'_N (same values on every lane) ----
@@ -979,6 +976,7 @@ struct ScalarALProblem {
                 la[i] = __builtin_fma(HN[9 + 3 * i + 2], xN[8], la[i]);
             }
         }
+        double la2[2] = {la[0], la[1]};
         // ---- backward: lane = N - 1 - stage ----
         for (int j0 = 0; j0 < N; j0 += WAVE) {
             const int cnt = N - j0 < WAVE ? N - j0 : WAVE;
@@ -1028,57 +1026,27 @@ struct ScalarALProblem {
                     if (on)
                         Hv[nu * k + 1 + i] = __builtin_fma(cw[i], lan, T[4 + i]);
                 }
-            } else if (on) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    W[24 * k + 12 + 4 * i] = T[i];     // start value of la_i's step
-                    LM[(k + 1) * nx + i]   = T[4 + i]; // T_w: free columns of the rows la is stored to
-                }
-            }
-        }
-        if constexpr (!RATES_ARE_INPUTS) {
-            wave_sync();
-            const int j3 = (lane & 15) < 3 ? (lane & 15) : 2;
-            attitude_recursion<false>(W + 12, LM + 6, j3 == 0 ? la[0] : j3 == 1 ? la[1] : la[2]);
-            wave_sync();
-            for (int k = lane; k < N; k += WAVE) {
-                double ja[NJA];
+            } else {
+                double ja[NJA], lan[3];
                 load_ja(k, ja);
+                lan[2] = scan(on ? T[2] : 0.0, la[2], cnt); // the yaw does not feed back: a running sum
+                scan2(on ? Affine2{ja[0], ja[6], ja[1], ja[7], __builtin_fma(ja[12], lan[2], T[0]),
+                                   __builtin_fma(ja[13], lan[2], T[1])}
+                         : affine_identity(),
+                      la2, cnt, lan[0], lan[1]);
+                if (on) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    double t = LM[(k + 1) * nx + j];
+                    for (int j = 0; j < 3; ++j) {
+                        double t = T[4 + j];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
-                        t = __builtin_fma(ja[6 * i + 3 + j], LM[(k + 1) * nx + 6 + i], t);
-                    Hv[nu * k + 1 + j] = t;
+                        for (int i = 0; i < 3; ++i)
+                            t = __builtin_fma(ja[6 * i + 3 + j], lan[i], t);
+                        Hv[nu * k + 1 + j] = t;
+                    }
                 }
             }
         }
         wave_sync();
-    }
-    /// The 3 x 3 recursions of realistic_quadcopter's attitude in a product: y <- s_j + sum_e c_je y_e, the
-    /// three components reaching the multiply-adds as row broadcasts (three independent DPP moves; a
-    /// DPP operand fused into each multiply-add would put the long DPP latency of v_fmac_f64 on the
-    /// dependent chain three times per stage).  UP: a' (stages 0..N-1), otherwise la (N-1..0).
-    /// Operands: 4 doubles (s_j, c_j0, c_j1, c_j2) per component at rec[24 k + 4 j].
-    template <bool UP>
-    __device__ __forceinline__ void attitude_recursion(const double *rec, double *out, double y0) const {
-        const int j3 = (lane & 15) < 3 ? (lane & 15) : 2;
-        struct Rec {
-            double2 a, b; // (s, c0), (c1, c2)
-        };
-        stage_recursion<UP, 4>(
-            y0, out + j3,
-            [&](int k) {
-                const double2 *p = reinterpret_cast<const double2 *>(rec + 24 * k + 4 * j3);
-                return Rec{p[0], p[1]};
-            },
-            [](const Rec &o, double y) {
-                const double y0_ = row_bcast<0>(y), y1_ = row_bcast<1>(y), y2_ = row_bcast<2>(y);
-                double nxt = __builtin_fma(o.a.y, y0_, o.a.x);
-                nxt        = __builtin_fma(o.b.x, y1_, nxt);
-                return __builtin_fma(o.b.y, y2_, nxt);
-            });
     }
     /// y / Sigma for the sweeps; call whenever y or Sigma changed (they are fixed during an inner solve).
     __device__ __forceinline__ void set_al() const {

@@ -143,6 +143,52 @@ __device__ __forceinline__ double wave_running_sum(double x) {
     x = x + dpp_move_rows<0x143, 0xC>(x);
     return x;
 }
+/// Like dpp_move_rows, but a lane without a source (outside ROW_MASK, or shifted in from outside its
+/// row) keeps `old`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_or(double old, double v) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+/// An affine map of a pair, y -> A y + b (oracle: SingleShootingAL::Affine2, same arithmetic).
+struct Affine2 {
+    double a00, a01, a10, a11, b0, b1;
+    __device__ __forceinline__ void apply(double y0, double y1, double &o0, double &o1) const {
+        o0 = __builtin_fma(a01, y1, __builtin_fma(a00, y0, b0));
+        o1 = __builtin_fma(a11, y1, __builtin_fma(a10, y0, b1));
+    }
+};
+__device__ __forceinline__ Affine2 affine_identity() { return {1.0, 0.0, 0.0, 1.0, 0.0, 0.0}; }
+/// later o earlier
+__device__ __forceinline__ Affine2 affine_compose(const Affine2 &l, const Affine2 &e) {
+    Affine2 c;
+    c.a00 = __builtin_fma(l.a01, e.a10, l.a00 * e.a00);
+    c.a01 = __builtin_fma(l.a01, e.a11, l.a00 * e.a01);
+    c.a10 = __builtin_fma(l.a11, e.a10, l.a10 * e.a00);
+    c.a11 = __builtin_fma(l.a11, e.a11, l.a10 * e.a01);
+    c.b0  = __builtin_fma(l.a01, e.b1, __builtin_fma(l.a00, e.b0, l.b0));
+    c.b1  = __builtin_fma(l.a11, e.b1, __builtin_fma(l.a10, e.b0, l.b1));
+    return c;
+}
+/// Inclusive composition over the 64 lanes, lane i <- m_i o ... o m_0, grouped as the oracle's
+/// affine_scan() groups it (the levels of wave_running_sum; a lane without a partner composes with
+/// the identity).  All lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Affine2 affine_partner(const Affine2 &m) {
+    return {dpp_move_or<CTRL, ROW_MASK>(1.0, m.a00), dpp_move_or<CTRL, ROW_MASK>(0.0, m.a01),
+            dpp_move_or<CTRL, ROW_MASK>(0.0, m.a10), dpp_move_or<CTRL, ROW_MASK>(1.0, m.a11),
+            dpp_move_or<CTRL, ROW_MASK>(0.0, m.b0),  dpp_move_or<CTRL, ROW_MASK>(0.0, m.b1)};
+}
+__device__ __forceinline__ Affine2 wave_affine_scan(Affine2 m) {
+    m = affine_compose(m, affine_partner<0x111, 0xF>(m));
+    m = affine_compose(m, affine_partner<0x112, 0xF>(m));
+    m = affine_compose(m, affine_partner<0x114, 0xF>(m));
+    m = affine_compose(m, affine_partner<0x118, 0xF>(m));
+    m = affine_compose(m, affine_partner<0x142, 0xA>(m));
+    m = affine_compose(m, affine_partner<0x143, 0xC>(m));
+    return m;
+}
 /// The value of the lane below (lane 0: +0.0): wave_shr:1.
 __device__ __forceinline__ double lane_below(double v) { return dpp_move<0x138>(v); }
 /// The value lane `src` (wave-uniform) holds, on every lane.
