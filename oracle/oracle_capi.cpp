@@ -391,6 +391,18 @@ double oracle_quad_psi_grad(int realistic, int N, const double *x0, const double
         return p.eval_psi_grad_psi(u, grad);
     });
 }
+/// grad psi through the stage-by-stage adjoint sweep (the check of the affine sweep realistic_quadcopter uses)
+void oracle_quad_grad_generic(int realistic, int N, const double *x0, const double *y, const double *Sig,
+                              const double *u, double *grad) {
+    with_quad(realistic, N, [&](auto &p) {
+        std::copy(x0, x0 + 9, p.x0.begin());
+        p.set_al(y, Sig);
+        std::vector<double> X((N + 1) * 9), yh(4 * N + 4);
+        p.forward(u, X.data(), yh.data());
+        p.reverse_generic(u, X.data(), yh.data(), grad);
+        return 0;
+    });
+}
 void oracle_quad_hess_prod(int realistic, int N, const double *x0, const double *y, const double *Sig,
                            const double *u, const double *v, double *Hv) {
     with_quad(realistic, N, [&](auto &p) {

@@ -384,7 +384,16 @@ struct SingleShootingAL {
     /// Adjoint sweep over a stored trajectory with multipliers yhat: grad = grad_u (f + yhat' g).
     template <class T>
     void reverse(const T *u, const T *X, const T *yhat, T *grad) const {
-        T lam[nx], sbar[nx], ubar[nu], gu[nu];
+        if constexpr (std::is_same_v<T, double> && Model::realistic)
+            return reverse_affine(u, X, yhat, grad, nullptr);
+        else
+            reverse_generic(u, X, yhat, grad);
+    }
+    /// Stage by stage through the full stage adjoint (what reverse() is for quadcopter, and the check of
+    /// reverse_affine for realistic_quadcopter).
+    template <class T>
+    void reverse_generic(const T *u, const T *X, const T *yhat, T *grad) const {
+        T lam[nx], sbar[nx], ubar[nu], gu[nu] = {};
         for (int l = 0; l < nx; ++l)
             lam[l] = T{};
         Model::cost_grad(X + N * nx, static_cast<const T *>(nullptr), lam, gu);
@@ -399,6 +408,81 @@ struct SingleShootingAL {
                 grad[nu * k + c] = ubar[c] + gu[c];
             Model::constr_adj(s, yhat + nc * k, lam);
         }
+    }
+
+    /// Adjoint sweep of realistic_quadcopter (grad, and lam_{k+1} of every stage in LAM if given), as the
+    /// kernels form it.  The adjoints of position and velocity do not depend on the attitude's, and the
+    /// attitude adjoint of a stage is an AFFINE function of the next stage's: lam_a(k) = M_k lam_a(k+1) +
+    /// c_k.  c_k and the thrust gradient come from the stage adjoint with a zero attitude seed (which
+    /// carries the position / velocity recursion exactly as reverse() does), the columns of M_k and of
+    /// d grad_w / d lam_a from the stage adjoint on the three unit attitude seeds; then the yaw adjoint is a
+    /// running sum (nothing depends on the yaw), (lam_phi, lam_theta) an affine_scan over the reversed
+    /// stages, and the rate gradients fma chains over lam_a(k+1).  Equal to reverse() up to rounding.
+    void reverse_affine(const double *u, const double *X, const double *yhat, double *grad, double *LAM) const {
+        std::vector<double> lam_all((N + 1) * nx, 0.0), ctot(3 * N), cu(3 * N), cw(3 * N), Mc(9 * N), Uc(9 * N);
+        double lam[nx], sbar[nx], ubar[nu], gu[nu] = {0.0, 0.0, 0.0, 0.0};
+        for (int l = 0; l < nx; ++l)
+            lam[l] = 0.0;
+        Model::cost_grad(X + N * nx, static_cast<const double *>(nullptr), lam, gu);
+        Model::constr_adj(X + N * nx, yhat + nc * N, lam);
+        std::copy(lam, lam + nx, &lam_all[N * nx]);
+        for (int k = N - 1; k >= 0; --k) {
+            const double *s = X + k * nx, *uk = u + nu * k;
+            double mu[nx] = {lam[0], lam[1], lam[2], lam[3], lam[4], lam[5], 0.0, 0.0, 0.0};
+            rk4_adj(s, uk, mu, sbar, ubar);
+            Model::cost_grad(s, uk, sbar, gu);
+            grad[nu * k] = ubar[0] + gu[0];
+            Model::constr_adj(s, yhat + nc * k, sbar);
+            for (int j = 0; j < 3; ++j) {
+                ctot[3 * k + j] = sbar[6 + j];
+                cu[3 * k + j]   = ubar[1 + j];
+                cw[3 * k + j]   = gu[1 + j];
+            }
+            for (int l = 0; l < 6; ++l)
+                lam[l] = lam_all[k * nx + l] = sbar[l];
+            for (int e = 0; e < 3; ++e) {
+                double seed[nx] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sb[nx], ub[nu];
+                seed[6 + e] = 1.0;
+                rk4_adj(s, uk, seed, sb, ub);
+                for (int j = 0; j < 3; ++j) {
+                    Mc[9 * k + 3 * e + j] = sb[6 + j];
+                    Uc[9 * k + 3 * e + j] = ub[1 + j];
+                }
+            }
+        }
+        // yaw: lam_psi(k) = lam_psi(k+1) + c_k[psi]
+        std::vector<double> inc(N), run(N + 1);
+        for (int j = 0; j < N; ++j)
+            inc[j] = ctot[3 * (N - 1 - j) + 2];
+        prefix_scan(inc.data(), N, lam_all[N * nx + 8], run.data());
+        for (int j = 0; j <= N; ++j)
+            lam_all[(N - j) * nx + 8] = run[j];
+        std::vector<Affine2> am(N);
+        std::vector<double> y2(2 * (N + 1));
+        for (int j = 0; j < N; ++j) {
+            const int k      = N - 1 - j;
+            const double *M  = &Mc[9 * k]; // M[3 e + i]: d lam_a(k)[i] / d lam_a(k+1)[e]
+            const double lps = lam_all[(k + 1) * nx + 8];
+            am[j]            = {{{M[0], M[3]}, {M[1], M[4]}},
+                                {std::fma(M[6], lps, ctot[3 * k]), std::fma(M[7], lps, ctot[3 * k + 1])}};
+        }
+        const double lN[2] = {lam_all[N * nx + 6], lam_all[N * nx + 7]};
+        affine_scan(am.data(), N, lN, y2.data());
+        for (int j = 0; j <= N; ++j) {
+            lam_all[(N - j) * nx + 6] = y2[2 * j];
+            lam_all[(N - j) * nx + 7] = y2[2 * j + 1];
+        }
+        for (int k = 0; k < N; ++k) {
+            const double *ln = &lam_all[(k + 1) * nx + 6];
+            for (int i = 0; i < 3; ++i) {
+                double t = cu[3 * k + i];
+                for (int e = 0; e < 3; ++e)
+                    t = std::fma(Uc[9 * k + 3 * e + i], ln[e], t);
+                grad[nu * k + 1 + i] = t + cw[3 * k + i];
+            }
+        }
+        if (LAM)
+            std::copy(lam_all.begin(), lam_all.end(), LAM);
     }
 
     // ---- the second-order tape ------------------------------------------------------------------
@@ -485,9 +569,21 @@ struct SingleShootingAL {
                     HNaa_[d][e] = lt[6 + e].t;
             }
         }
+        // realistic_quadcopter: gradient and adjoints as reverse() forms them (reverse_affine); the dual
+        // evaluations below then only supply the tangent parts
+        std::vector<double> LAM;
+        if (Model::realistic) {
+            std::vector<double> yh(m());
+            for (int k = 0; k <= N; ++k)
+                stage_multipliers(X + k * nx, k, yh.data() + nc * k);
+            LAM.resize((N + 1) * nx);
+            reverse_affine(u, X, yh.data(), grad, LAM.data());
+        }
         for (int k = N - 1; k >= 0; --k) {
             StageTape &tp = tape_[k];
             double lam_k[nx];
+            if (Model::realistic)
+                std::copy(&LAM[(k + 1) * nx], &LAM[(k + 1) * nx] + nx, lam);
             for (int l = 0; l < nau; ++l) { // direction (a,u)_l = z_{6 + l}
                 const int d = 6 + l;
                 Dual s[nx], ud[nu], xn[nx], yk[nc], mu[nx], sbar[nx], ubar[nu], gu[nu];
@@ -510,7 +606,8 @@ struct SingleShootingAL {
                 for (int c = 0; c < nu; ++c) {
                     Dual g           = ubar[c] + gu[c];
                     tp.Hau[l][3 + c] = g.t;
-                    grad[nu * k + c] = g.v;
+                    if (!Model::realistic)
+                        grad[nu * k + c] = g.v;
                 }
                 Model::constr_adj(s, yk, sbar);
                 for (int e = 0; e < 3; ++e)

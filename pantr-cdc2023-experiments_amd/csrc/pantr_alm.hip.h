@@ -618,70 +618,124 @@ struct ScalarALProblem {
                         return j3 < 2 ? l + o.c.y : l;
                     });
             } else {
-                // the angle rates depend on the angles: the four substage adjoints of a stage chain through
-                // angle_rates_adj (values the same on every lane), on top of the A_s of phase 3; this is also
-                // where the gradients of the three rate inputs come from
-                auto sel3 = [&](const double (&v)[3]) { return j3 == 0 ? v[0] : j3 == 1 ? v[1] : v[2]; };
-                double mu[3] = {muN[0], muN[1], muN[2]};
-                for (int k = N - 1; k >= 0; --k) {
-                    LAM[(k + 1) * nx + 6 + j3] = sel3(mu);
+                // The angle rates depend on the angles: the four substage adjoints of a stage chain through
+                // angle_rates_adj, on top of the A_s of phase 3 - an AFFINE function of lam_a(k+1).  With
+                // lane = N - 1 - stage: the chain on a zero seed (with the A_s: the constant term) and on the
+                // three unit seeds (the columns of the linear part and of d grad_w / d lam_a), then the yaw
+                // adjoint as a running sum (nothing depends on the yaw), (lam_phi, lam_theta) as a wavefront
+                // scan of affine 2 x 2 maps, the rate gradients as fma chains (oracle: reverse_affine).
+                double lpsi = muN[2], la2[2] = {muN[0], muN[1]};
+                for (int j0 = 0; j0 < N; j0 += WAVE) {
+                    const int cnt = N - j0 < WAVE ? N - j0 : WAVE;
+                    const bool on = lane < cnt;
+                    const int k   = on ? N - 1 - (j0 + lane) : 0;
                     const double *R   = scr + 18 * k;
                     const double2 *tg = TG + 12 * k;
-                    auto rates_adj    = [&](int sub, const double (&kba)[3], double (&sba)[3], double (&uba)[3]) {
-                        const double *o  = coef + COEF * k + 5 * sub;
-                        const double2 e0 = tg[9 - 3 * sub], e1 = tg[10 - 3 * sub]; // (sin, cos) of phi, theta
-                        M::angle_rates_adj_apply(e0.x, e1.x, e1.y, typename M::template RateAdjCoef<double>{o[0], o[1], o[2], o[3], o[4]},
-                                                 kba, sba, uba);
-                    };
-                    double uk[nu], kb1[3], kb2[3], kb3[3], kb4[3], sbar[3], a[3], ubar[3], ua[3];
+                    double uk[nu], Rv[18], co[COEF], tr[4][3]; // tr: sin phi, sin theta, cos theta of the substage
 #pragma unroll
                     for (int c = 0; c < nu; ++c)
                         uk[c] = u[nu * k + c];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const double sg = M::c6 * mu[j];
-                        kb1[j]  = sg;
-                        kb2[j]  = 2.0 * sg;
-                        kb3[j]  = 2.0 * sg;
-                        kb4[j]  = sg;
-                        sbar[j] = mu[j];
-                        a[j]    = R[6 * j];
-                    }
-                    rates_adj(0, kb4, a, ubar);
+                    for (int q = 0; q < 18; ++q)
+                        Rv[q] = R[q];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        sbar[j] = sbar[j] + a[j];
-                        kb3[j]  = madd(M::Ts, a[j], kb3[j]);
-                        a[j]    = R[6 * j + 1];
-                    }
-                    rates_adj(1, kb3, a, ua);
+                    for (int q = 0; q < COEF; ++q)
+                        co[q] = coef[COEF * k + q];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        ubar[j] = ubar[j] + ua[j];
-                        sbar[j] = sbar[j] + a[j];
-                        kb2[j]  = madd(M::hTs, a[j], kb2[j]);
-                        a[j]    = R[6 * j + 2];
+                    for (int sub = 0; sub < 4; ++sub) {
+                        const double2 e0 = tg[9 - 3 * sub], e1 = tg[10 - 3 * sub];
+                        tr[sub][0] = e0.x; tr[sub][1] = e1.x; tr[sub][2] = e1.y;
                     }
-                    rates_adj(2, kb2, a, ua);
+                    auto rates_adj = [&](int sub, const double (&kba)[3], double (&sba)[3], double (&uba)[3]) {
+                        const double *o = co + 5 * sub;
+                        M::angle_rates_adj_apply(tr[sub][0], tr[sub][1], tr[sub][2],
+                                                 typename M::template RateAdjCoef<double>{o[0], o[1], o[2], o[3], o[4]}, kba, sba, uba);
+                    };
+                    // sbar = mu + a_4 + a_3 + a_2 + a_1 and the summed input adjoints for the seed mu
+                    auto chain = [&](const double (&mu)[3], bool withA, double (&sbar)[3], double (&ubar)[3]) {
+                        double kb1[3], kb2[3], kb3[3], kb4[3], a[3], ua[3];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        ubar[j] = ubar[j] + ua[j];
-                        sbar[j] = sbar[j] + a[j];
-                        kb1[j]  = madd(M::hTs, a[j], kb1[j]);
-                        a[j]    = R[6 * j + 3];
-                    }
-                    rates_adj(3, kb1, a, ua);
-                    double g[3];
+                        for (int j = 0; j < 3; ++j) {
+                            const double sg = M::c6 * mu[j];
+                            kb1[j]  = sg;
+                            kb2[j]  = 2.0 * sg;
+                            kb3[j]  = 2.0 * sg;
+                            kb4[j]  = sg;
+                            sbar[j] = mu[j];
+                            a[j]    = withA ? Rv[6 * j] : 0.0;
+                        }
+                        rates_adj(0, kb4, a, ubar);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        ubar[j] = ubar[j] + ua[j];
-                        sbar[j] = sbar[j] + a[j];
-                        mu[j]   = sbar[j] + R[6 * j + 4];
-                        g[j]    = ubar[j] + ((2e-4 * uk[1 + j]) + (20.0 * uk[1 + j]));
+                        for (int j = 0; j < 3; ++j) {
+                            sbar[j] = sbar[j] + a[j];
+                            kb3[j]  = madd(M::Ts, a[j], kb3[j]);
+                            a[j]    = withA ? Rv[6 * j + 1] : 0.0;
+                        }
+                        rates_adj(1, kb3, a, ua);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            ubar[j] = ubar[j] + ua[j];
+                            sbar[j] = sbar[j] + a[j];
+                            kb2[j]  = madd(M::hTs, a[j], kb2[j]);
+                            a[j]    = withA ? Rv[6 * j + 2] : 0.0;
+                        }
+                        rates_adj(2, kb2, a, ua);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            ubar[j] = ubar[j] + ua[j];
+                            sbar[j] = sbar[j] + a[j];
+                            kb1[j]  = madd(M::hTs, a[j], kb1[j]);
+                            a[j]    = withA ? Rv[6 * j + 3] : 0.0;
+                        }
+                        rates_adj(3, kb1, a, ua);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            ubar[j] = ubar[j] + ua[j];
+                            sbar[j] = sbar[j] + a[j];
+                        }
+                    };
+                    double cpre[3], cu[3], Mc[3][3], Uc[3][3]; // Mc[e][j] = d lam_a(k)[j] / d lam_a(k+1)[e]
+                    {
+                        const double zero[3] = {0.0, 0.0, 0.0};
+                        chain(zero, true, cpre, cu);
                     }
-                    grad[nu * k + 1 + j3] = sel3(g);
-                    mu[0] = mu[0] + R[5];
-                    mu[1] = mu[1] + R[11];
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        const double seed[3] = {e == 0 ? 1.0 : 0.0, e == 1 ? 1.0 : 0.0, e == 2 ? 1.0 : 0.0};
+                        chain(seed, false, Mc[e], Uc[e]);
+                    }
+                    const double ct0 = (cpre[0] + Rv[4]) + Rv[5], ct1 = (cpre[1] + Rv[10]) + Rv[11], ct2 = cpre[2] + Rv[16];
+                    // running sum / affine scan over the lanes (as in hess_prod)
+                    double lan[3];
+                    {
+                        const double sps = wave_running_sum(on ? ct2 : 0.0);
+                        lan[2]           = lpsi + lane_below(sps);
+                        lpsi             = lpsi + lane_value(sps, cnt - 1);
+                    }
+                    {
+                        const Affine2 mm = on ? Affine2{Mc[0][0], Mc[1][0], Mc[0][1], Mc[1][1], __builtin_fma(Mc[2][0], lan[2], ct0),
+                                                        __builtin_fma(Mc[2][1], lan[2], ct1)}
+                                              : affine_identity();
+                        const Affine2 P  = wave_affine_scan(mm);
+                        double y0, y1;
+                        P.apply(la2[0], la2[1], y0, y1);
+                        const double b0 = lane_below(y0), b1 = lane_below(y1);
+                        lan[0] = lane == 0 ? la2[0] : b0;
+                        lan[1] = lane == 0 ? la2[1] : b1;
+                        la2[0] = lane_value(y0, cnt - 1);
+                        la2[1] = lane_value(y1, cnt - 1);
+                    }
+                    if (on) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            LAM[(k + 1) * nx + 6 + i] = lan[i];
+                            double t = cu[i];
+#pragma unroll
+                            for (int e = 0; e < 3; ++e)
+                                t = __builtin_fma(Uc[e][i], lan[e], t);
+                            grad[nu * k + 1 + i] = t + ((2e-4 * uk[1 + i]) + (20.0 * uk[1 + i]));
+                        }
+                    }
                 }
             }
         }

@@ -139,6 +139,7 @@ def lib():
         L.oracle_quad_psi_grad.argtypes = [C.c_int, C.c_int, _pd, _pd, _pd, _pd, _pd, _pd]
         L.oracle_quad_psi_grad.restype = _dbl
         L.oracle_quad_hess_prod.argtypes = [C.c_int, C.c_int, _pd, _pd, _pd, _pd, _pd, _pd]
+        L.oracle_quad_grad_generic.argtypes = [C.c_int, C.c_int, _pd, _pd, _pd, _pd, _pd]
         L.oracle_quad_hess_prod_dual.argtypes = [C.c_int, C.c_int, _pd, _pd, _pd, _pd, _pd, _pd]
         L.oracle_quad_solve.argtypes = [C.c_int, C.c_int, C.POINTER(OracleParams), _pd, _pd, _pd,
                                         C.POINTER(OracleStats)]
@@ -331,6 +332,13 @@ def quad_psi_grad(problem, N, x0, y, Sig, u):
     psi = lib().oracle_quad_psi_grad(QUAD[problem], N, *[np.ascontiguousarray(a, float) for a in (x0, y, Sig, u)],
                                      grad, yhat)
     return psi, grad, yhat
+
+
+def quad_grad_generic(problem, N, x0, y, Sig, u):
+    """grad psi by the stage-by-stage adjoint sweep (check of the affine sweep of realistic_quadcopter)."""
+    grad = np.zeros(4 * N)
+    lib().oracle_quad_grad_generic(QUAD[problem], N, *[np.ascontiguousarray(a, float) for a in (x0, y, Sig, u)], grad)
+    return grad
 
 
 def quad_hess_prod(problem, N, x0, y, Sig, u, v, dual=False):

@@ -305,6 +305,10 @@ def test_quadcopter_dynamics_and_derivatives(rng, problem):
           ob.quad_psi_grad(problem, N, x0, y, Sig, u - h * v)[1]) / (2 * h)
     assert np.abs(Hv - fd).max() <= 1e-6 * np.abs(Hv).max()
     assert abs(w @ Hv - v @ Hw) <= 1e-11 * abs(w @ Hv)
+    # the adjoint sweep the solvers use (realistic_quadcopter: affine in the attitude adjoints) against the
+    # stage-by-stage sweep through the full stage adjoint
+    gg = ob.quad_grad_generic(problem, N, x0, y, Sig, u)
+    assert np.abs(g - gg).max() <= 1e-13 * np.abs(gg).max()
     # the stage-matrix tape against dual numbers through the whole horizon
     Hd = ob.quad_hess_prod(problem, N, x0, y, Sig, u, v, dual=True)
     assert np.abs(Hv - Hd).max() <= 1e-12 * np.abs(Hd).max()
