@@ -68,9 +68,13 @@ __device__ __forceinline__ void sincos_det(double x, double &s, double &c) {
     pc        = __builtin_fma(z, pc, -1.38888888888741095749e-03);
     pc        = __builtin_fma(z, pc, 4.16666666666666019037e-02);
     const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
-    const int q = static_cast<int>(kd) & 3; // |x| < 3e9 (64-bit conversions are emulated on the GPU)
-    s = q == 0 ? sr : q == 1 ? cr : q == 2 ? -sr : -cr;
-    c = q == 0 ? cr : q == 1 ? -sr : q == 2 ? -cr : sr;
+    // quadrant q = kd mod 4: s = sr, cr, -sr, -cr and c = cr, -sr, -cr, sr for q = 0..3, as one swap on
+    // the low bit of q and one sign-bit flip each (the same bits as the selects, in a third of the instructions)
+    const int q = static_cast<int>(kd); // |x| < 3e9 (64-bit conversions are emulated on the GPU)
+    const bool sw = q & 1;
+    const double s_ = sw ? cr : sr, c_ = sw ? sr : cr;
+    s = __hiloint2double(__double2hiint(s_) ^ ((q & 2) << 30), __double2loint(s_));
+    c = __hiloint2double(__double2hiint(c_) ^ (((q + 1) & 2) << 30), __double2loint(c_));
 }
 __device__ __forceinline__ void sincos_t(double x, double &s, double &c) { sincos_det(x, s, c); }
 __device__ __forceinline__ void sincos_t(dual x, dual &s, dual &c) {
