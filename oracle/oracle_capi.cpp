@@ -391,6 +391,18 @@ double oracle_quad_psi_grad(int realistic, int N, const double *x0, const double
         return p.eval_psi_grad_psi(u, grad);
     });
 }
+/// The two scan orders of the quadcopter-family specification (tests/test_oracle.py pins them).
+void oracle_prefix_scan(const double *r, int n, double init, double *excl) {
+    oracle::SingleShootingAL<oracle::Quadcopter>::prefix_scan(r, n, init, excl);
+}
+/// maps: n x 6 doubles (A00, A01, A10, A11, b0, b1); out: 2 (n + 1)
+void oracle_affine_scan(const double *maps, int n, const double *y0, double *out) {
+    using P = oracle::SingleShootingAL<oracle::Quadcopter>;
+    std::vector<P::Affine2> m(n);
+    for (int k = 0; k < n; ++k)
+        m[k] = {{{maps[6 * k], maps[6 * k + 1]}, {maps[6 * k + 2], maps[6 * k + 3]}}, {maps[6 * k + 4], maps[6 * k + 5]}};
+    P::affine_scan(m.data(), n, y0, out);
+}
 /// grad psi through the stage-by-stage adjoint sweep (the check of the affine sweep realistic_quadcopter uses)
 void oracle_quad_grad_generic(int realistic, int N, const double *x0, const double *y, const double *Sig,
                               const double *u, double *grad) {

@@ -140,6 +140,8 @@ def lib():
         L.oracle_quad_psi_grad.restype = _dbl
         L.oracle_quad_hess_prod.argtypes = [C.c_int, C.c_int, _pd, _pd, _pd, _pd, _pd, _pd]
         L.oracle_quad_grad_generic.argtypes = [C.c_int, C.c_int, _pd, _pd, _pd, _pd, _pd]
+        L.oracle_prefix_scan.argtypes = [_pd, C.c_int, C.c_double, _pd]
+        L.oracle_affine_scan.argtypes = [_pd, C.c_int, _pd, _pd]
         L.oracle_quad_hess_prod_dual.argtypes = [C.c_int, C.c_int, _pd, _pd, _pd, _pd, _pd, _pd]
         L.oracle_quad_solve.argtypes = [C.c_int, C.c_int, C.POINTER(OracleParams), _pd, _pd, _pd,
                                         C.POINTER(OracleStats)]
@@ -332,6 +334,22 @@ def quad_psi_grad(problem, N, x0, y, Sig, u):
     psi = lib().oracle_quad_psi_grad(QUAD[problem], N, *[np.ascontiguousarray(a, float) for a in (x0, y, Sig, u)],
                                      grad, yhat)
     return psi, grad, yhat
+
+
+def prefix_scan(r, init=0.0):
+    """excl[k] = init + r[0] + ... + r[k-1], k = 0..n, in the order of the specification (wavefront scan)."""
+    r = np.ascontiguousarray(r, float)
+    out = np.zeros(len(r) + 1)
+    lib().oracle_prefix_scan(r, len(r), float(init), out)
+    return out
+
+
+def affine_scan(maps, y0):
+    """y(k+1) = A_k y(k) + b_k for maps[k] = (A00, A01, A10, A11, b0, b1), in the order of the specification."""
+    maps = np.ascontiguousarray(maps, float).reshape(-1, 6)
+    out = np.zeros((len(maps) + 1, 2))
+    lib().oracle_affine_scan(maps, len(maps), np.ascontiguousarray(y0, float), out)
+    return out
 
 
 def quad_grad_generic(problem, N, x0, y, Sig, u):

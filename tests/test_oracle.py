@@ -457,3 +457,30 @@ def test_golden_quadcopter_functions(golden_dir, problem):
     assert psi == g("psi") and np.array_equal(grad, g("grad")) and np.array_equal(yhat, g("yhat"))
     assert np.array_equal(ob.quad_hess_prod(problem, 9, g("x0"), g("y"), g("Sig"), g("u"), g("v")), g("Hv"))
 
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 63, 64, 65, 130])
+def test_scan_orders_of_the_specification(rng, n):
+    """prefix_scan / affine_scan (the summation and composition orders the quadcopter-family kernels'
+    wavefront scans follow): equal to the sequential recursion up to rounding, exactly on inputs whose
+    sums are exact, block boundaries at 64 included."""
+    r = rng.standard_normal(n)
+    e = ob.prefix_scan(r, 0.75)
+    assert e.shape == (n + 1,) and e[0] == 0.75
+    assert np.allclose(e, 0.75 + np.concatenate([[0.0], np.cumsum(r)]), rtol=0, atol=1e-13 * max(1, n))
+    ri = rng.integers(-1000, 1000, n).astype(float)  # integer sums are exact in any order
+    assert np.array_equal(ob.prefix_scan(ri, 3.0), 3.0 + np.concatenate([[0.0], np.cumsum(ri)]))
+    maps = np.column_stack([1 + 0.1 * rng.standard_normal(n), 0.1 * rng.standard_normal(n), 0.1 * rng.standard_normal(n),
+                            1 + 0.1 * rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)]).reshape(n, 6)
+    y0 = np.array([0.3, -0.2])
+    out = ob.affine_scan(maps, y0)
+    y, seq = y0.copy(), [y0.copy()]
+    for m in maps:
+        y = np.array([m[0] * y[0] + m[1] * y[1] + m[4], m[2] * y[0] + m[3] * y[1] + m[5]])
+        seq.append(y)
+    seq = np.array(seq)
+    assert out.shape == (n + 1, 2) and np.array_equal(out[0], y0)
+    assert np.abs(out - seq).max() <= 1e-12 * max(1.0, np.abs(seq).max())
+    shifts = np.column_stack([np.ones(n), np.zeros(n), np.zeros(n), np.ones(n), rng.integers(-9, 9, n), rng.integers(-9, 9, n)]).astype(float)
+    acc = np.array([1.0, 2.0]) + np.concatenate([[[0.0, 0.0]], np.cumsum(shifts[:, 4:], axis=0)]) if n else np.array([[1.0, 2.0]])
+    assert np.array_equal(ob.affine_scan(shifts, [1.0, 2.0]), acc)  # translations compose exactly
