@@ -822,6 +822,16 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                 x_io[i] = XH_(curr)[i];
         }
         wave_sync();
+    } else {
+        // nothing to report (the Lipschitz estimate was not finite): x_io keeps the initial guess.  Its slot is
+        // scratch during the solve (CG step; sweep scratch of the scalar models), so it is written back
+        // from the iterate that still holds it.
+        for (int j = 0; j < nj; ++j) {
+            int i = j * WAVE + lane;
+            if (i < n)
+                x_io[i] = X_(curr)[i];
+        }
+        wave_sync();
     }
     return {status, k, eps_k, curr.gamma, curr.psi_xh, curr.fbe(), radius};
 }

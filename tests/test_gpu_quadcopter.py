@@ -142,3 +142,21 @@ def test_closed_loop_records_what_a_replay_needs(warm):
     b.close()
     assert np.array_equal(u, inputs[:, 0]) and np.array_equal(y, rec["multipliers"][:, 0])
     assert st["iterations"].tolist() == stats["iterations"][:, 0].tolist()
+
+
+@pytest.mark.parametrize("problem", ["quadcopter", "realistic_quadcopter"])
+def test_non_finite_state_is_handled_like_the_oracle(problem):
+    """A NaN in the initial state of one instance: that instance ends as the oracle's does (status, counters,
+    whatever the solution slot holds), its neighbour in the batch is unaffected."""
+    N = 12
+    b = pa.PantrBatch(problem, N, 2, opts=quad_opts(problem))
+    x0 = np.vstack([ob.quad_initial_state(), ob.quad_initial_state()])
+    x0[1, 2] = np.nan
+    u0 = np.tile(ob.quad_initial_guess(N), (2, 1)) + 0.01
+    u, y, st = b.solve_al(x0, u0)
+    b.close()
+    for i in range(2):
+        u_o, y_o, st_o = ob.quad_solve(problem, N, x0[i], u0[i])
+        assert st["status"][i] == st_o["status"] and np.array_equal(u[i], u_o, equal_nan=True)
+        assert st["outer_iterations"][i] == st_o["outer_iterations"] and st["iterations"][i] == st_o["iterations"]
+    assert st["status"][0] == 1 and np.all(np.isfinite(u[0]))
