@@ -8,15 +8,19 @@
 //   alpaqa::ALMSolver::operator() (m > 0)                        drivers/mpc-driver.cpp:104-115,217
 //   ALM options                                                  new-benchmarks-paper/dodo.py:12-22,101-105
 // One wavefront per MPC instance as for the chain.  The nine-state stage is small and its states are a
-// cascade (attitude -> velocities -> positions), so the first-order sweeps keep only what truly is a
-// recursion sequential - three short scans, and for realistic_quadcopter the attitude itself - and
-// evaluate everything else for all stages at once, lane = stage (forward_cascade, reverse_cascade;
-// trajectories, multipliers and the sin/cos values of every substage state live in LDS).  The
-// second-order work is spread over lanes as well: grad_L is followed by one task per (stage, direction)
-// on dual numbers, which yields the stage Jacobian J_k and the stage Hessian H_k of the Lagrangian-like
-// recursion column by column; each Hessian-vector product of the CG iterations is then 13x13 / 13x9
-// matrix-vector work per stage, split over the four 16-lane rows, streamed from the HBM tape ahead of
-// the arithmetic.
+// cascade (attitude -> velocities -> positions), so very little is a recursion over the stages, and what
+// is not runs with lane = stage (trajectories, multipliers and the sin/cos values of every substage
+// state live in LDS):
+//   forward sweep   running fmas for velocities and positions (quadcopter: the angles too); only the
+//                   attitude of realistic_quadcopter is integrated stage by stage        forward_cascade
+//   adjoint sweep   running sums; realistic_quadcopter's attitude adjoints as a wavefront scan of
+//                   affine 2 x 2 maps                                                      reverse_cascade
+//   recording       one (stage, direction) pair per lane on dual numbers, 7 directions + the position
+//                   block: the nonzero blocks of J_k and H_k, coefficient-major in HBM     eval_grad_xhat
+//   products        tape rows into registers, a few dozen FMAs per lane, wavefront prefix sums (and
+//                   the same affine scans): no loop over the stages                        hess_prod
+// The summation / composition orders of the scans are those of the oracle's prefix_scan / affine_scan
+// (oracle/quad_models.hpp), which is what keeps the results bit-identical.
 #pragma once
 #include "pantr_kernel.hip.h"
 #include <type_traits>
@@ -449,21 +453,23 @@ struct ScalarALProblem {
     /// Forward sweep: psi, trajectory, yhat, and the trig store of every substage state.
     __device__ __forceinline__ double forward(const double *u, double *yh) const { return forward_cascade(u, yh); }
     /// Adjoint sweep, as a cascade in the opposite direction: position adjoints feed the velocity
-    /// adjoints feed the angle adjoints, and no adjoint feeds back.  Sequential: scans of a few
-    /// dependent additions per stage and component (operands fetched eight stages ahead); for
-    /// realistic_quadcopter the angle adjoints chain through the four substage adjoints of the angle
-    /// rates instead (phase 4 as a stage-by-stage recursion over coefficients phase 3 has prepared).
+    /// adjoints feed the angle adjoints, and no adjoint feeds back.  Sequential: running sums of a few
+    /// dependent additions per stage and component (stage_recursion); for realistic_quadcopter the
+    /// angle adjoint of a stage is an affine function of the next stage's (through the four substage
+    /// adjoints of the angle rates), and phase 4 is a wavefront scan of those maps (oracle: reverse_affine).
     /// All the rest - the substage adjoints of f_c with their trigonometric coefficients, the input
     /// gradients - is evaluated for all stages at once, lane = stage, by the pieces M::fc_adj is made
     /// of, on the operands a stage-by-stage adjoint sweep would hand them (oracle:
-    /// SingleShootingAL::reverse).  Value for value the same arithmetic (what that sweep adds of exact
-    /// zeros - the position adjoint of f_c is 0 * u_0 - is skipped: same values, possibly another sign
-    /// of a zero).
+    /// SingleShootingAL::reverse).  For quadcopter value for value the arithmetic of the stage-by-stage
+    /// sweep (what that sweep adds of exact zeros - the position adjoint of f_c is 0 * u_0 - is skipped:
+    /// same values, possibly another sign of a zero).
     ///   1  lam_p(k) = (lam_p(k+1) + dl/dp) - (dc/dp)' yhat                                       (scan)
     ///   2  lam_v(k) = ((((lam_v + sg) + 2 sg) + 2 sg) + sg) + dl/dv,   sg = c6 lam_p(k+1)         (scan)
     ///   3  velocity parts of the four substage adjoint seeds, fc_adj on them: A_s (angle parts), u_0 gradient
     ///   4  lam_a(k) = (((((lam_a + A_4) + A_3) + A_2) + A_1) + dl/da) + (dc/da)' yhat             (scan)
-    ///   5  angle parts of the seeds -> gradients of the three rate inputs; + cost gradient -> grad
+    ///      realistic_quadcopter: lam_a(k) = M_k lam_a(k+1) + c_k, the maps from the stage adjoint on zero and
+    ///      unit seeds; yaw: running sum, (phi, theta): wavefront scan of 2 x 2 affine maps, then the gradients
+    ///   5  quadcopter: angle parts of the seeds -> gradients of the three rate inputs; + cost gradient -> grad
     /// lam_(k+1) of every stage is left in LAM (= rows of Xt) for the second-order recording.
     __device__ __forceinline__ void reverse_cascade(const double *u, const double *yh, double *grad) const {
         wave_sync();
@@ -471,7 +477,7 @@ struct ScalarALProblem {
         double *LAM = Xt;
         // lam(k) = step(prep(k), lam(k+1)) for k = N-1..0, lam(k+1) stored to LAM[k+1][off + j3] on the way
         auto scan_down = [&](int off, double lam, auto prep, auto step) {
-            stage_recursion<false, 4>(lam, LAM + off + j3, prep, step);
+            stage_recursion<false, sizeof(decltype(prep(0))) <= 16 ? 8 : 4>(lam, LAM + off + j3, prep, step);
         };
         // The operands of the two running sums are prepared for all stages at once (lane = stage), two per
         // stage and component at scr[6 k + 2 j], so that a stage of the recursion is one 16-byte read, its
@@ -1234,8 +1240,8 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
         if (lane < M::nx)
             x0_lds[lane] = a.x0[(size_t)inst * M::nx + lane];
         pb.x0 = x0_lds;
-        // scratch of the cascade sweeps: PANTR lends the CG vectors z, r, d, Bd (dead outside the direction
-        // computation); the comparators keep L-BFGS scalars in the CG block and get LDS of their own
+        // scratch of the cascade sweeps: PANTR lends the five vector slots from z on (dead outside the
+        // direction computation); the comparators keep L-BFGS scalars in the CG block and get LDS of their own
         pb.coef = x0_lds + PB::X0_DOUBLES;
         pb.scr  = METHOD == 0 ? pb.vec(PB::CG_BASE + 3) : pb.coef + PB::coef_doubles(a.N);
     }

@@ -9,9 +9,10 @@
 //   box prox step / inactive set                                      problems/problems/formulation.hpp:220-227
 //
 // Data placement (DESIGN.md "Layout"):
-//   LDS     : the 20 decision-space vectors of the solve (3 iterates x {x, xhat, grad, p}, q,
-//             Hv output, r_J, and the CG vectors z, r, d, Bd, step; the step slot doubles as the
-//             in/out vector of the solve), n_pad doubles each
+//   LDS     : the decision-space vectors of the trust-region subproblem (q, Hv output, r_J, and the CG
+//             vectors z, r, d, step; the step slot doubles as the in/out vector of the solve), n_pad
+//             doubles each; the three iterates x {x, xhat, grad, p} too, except for PANTR on the
+//             hanging chain (WaveProblem<M, true>), which keeps them in HBM
 //   HBM/L2  : the state trajectory X[(N+1)][64] and its tangent Xt written by the forward
 //             sweeps and re-read (one stage ahead) by the reverse sweeps, one 512-byte row
 //             per stage per wavefront

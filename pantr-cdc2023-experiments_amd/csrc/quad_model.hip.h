@@ -4,13 +4,14 @@
 // problem generated from the Python models, problems/generate_problem.py:26-61):
 //   quadcopter ............ python/alpaqa_mpc_benchmarks/problems/quadcopter.py:6-112
 //   realistic_quadcopter .. python/alpaqa_mpc_benchmarks/problems/realistic_quadcopter.py:6-118
-// The nine-state stage is evaluated in scalar form by every lane of the wavefront (the
-// decision-vector algebra of the solver is still spread over the 64 lanes).  Its expensive part is
-// sin/cos of the three angles (wave_math's deterministic routine): with a wave-uniform state,
-// trig_uniform() evaluates one angle per lane and broadcasts (v_readlane), and callers hand the
-// Trig of a state to every function that needs it instead of recomputing it.  First derivatives
-// are hand-written adjoints; second-order information comes from running the same templates on
-// dual numbers whose tangent parts differ per lane (pantr_alm.hip.h).
+// The stage is scalar code, called with lane = stage, lane = (stage, direction) or - only in the attitude
+// integration of realistic_quadcopter - with the same values on every lane (trig_uniform() then
+// evaluates one angle per lane and broadcasts).  The pieces the cascade sweeps of pantr_alm.hip.h are
+// built from are separate functions: accel, angle_rates, fc_adj_translation, angle_rates_adj_coef /
+// _apply; fc and fc_adj are their compositions (the dual-number recording and the plant step use
+// those).  sin/cos values come from wave_math's deterministic routine and are handed around as a Trig
+// instead of being recomputed.  First derivatives are hand-written adjoints; second-order information
+// comes from running the same templates on dual numbers whose tangent parts differ per lane.
 #pragma once
 #include "wave_math.hip.h"
 
@@ -68,8 +69,8 @@ struct QuadModelT {
         const int lane = threadIdx.x & 63, j = lane & 15; // lane j of every 16-lane row: angle j
         double sv, cv;
         sincos_det(j == 1 ? a1 : j == 2 ? a2 : a0, sv, cv);
-        if (store && lane < 3)
-            store[lane] = make_double2(sv, cv);
+        if (store) // every lane stores: lanes 3..15 of a row hold angle 0 again (same value, same address)
+            store[j < 3 ? j : 0] = make_double2(sv, cv);
         return {row_bcast<0>(sv), row_bcast<0>(cv), row_bcast<1>(sv), row_bcast<1>(cv), row_bcast<2>(sv),
                 row_bcast<2>(cv)};
     }
