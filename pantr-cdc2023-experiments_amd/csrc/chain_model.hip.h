@@ -102,6 +102,31 @@ struct ChainModel {
         row_partner<true>(odd, c1, c3);   // row 1's (and the idle row 3's)
         return {c0, c1, c2};
     }
+    /// The same through LDS: one 8-byte write to the point's compact slot, three reads - 3 instructions
+    /// against 12 (copies + swaps), a round trip ~25 cycles longer.  The sweeps issue an instruction
+    /// every 6-7 cycles and their dependent chains are shorter than that adds up to, so instructions are
+    /// what counts: one product 58.8 -> 52.6 us at N = 60 (round 3).  xs: 32 doubles of this wavefront's
+    /// dynamic LDS.  LDS executes a wavefront's accesses in order: the fence is for the compiler only.
+    __device__ static __forceinline__ Comps comps_lds(const Lane &L, double v, double *xs) {
+        xs[L.q] = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double *s = xs + DIM * L.pc;
+        return {s[0], s[1], s[2]};
+    }
+    /// Two gathers at once, an exchange row each (xs: 64 doubles): both writes, then both sets of reads.
+    __device__ static __forceinline__ void comps_lds2(const Lane &L, double vA, double vB, double *xs, Comps &cA,
+                                                      Comps &cB) {
+        xs[L.q]      = vA;
+        xs[32 + L.q] = vB;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double *s = xs + DIM * L.pc;
+        cA = {s[0], s[1], s[2]};
+        cB = {s[32], s[33], s[34]};
+    }
     /// (v0 + v1) + v2 over the three components of this lane's point: the cross-row sum
     /// (row 0 + row 1) + (row 2 + row 3) with the idle row 3 holding 0 (lanes of row 3 contribute
     /// whatever they hold: the callers keep them at 0).
@@ -234,8 +259,8 @@ struct ChainModel {
     static constexpr int XT_DOUBLES        = 32; ///< tangent-state row per stage (compact slots)
 
     __device__ static __forceinline__ void tape_store(const Lane &L, double4 *stage, int j, const Springs &sp,
-                                                      const AdjAux &ax) {
-        const Comps dc = comps(sp.d), lc = comps(ax.lF);
+                                                      const AdjAux &ax, double *xs) {
+        const Comps dc = comps_lds(L, sp.d, xs), lc = comps_lds(L, ax.lF, xs);
         const double dq[DIM] = {dc.c0, dc.c1, dc.c2}, lq[DIM] = {lc.c0, lc.c1, lc.c2};
         const double e  = 3.0 / sp.n2;
         const double wd = ax.w * sp.d;
@@ -291,75 +316,107 @@ struct ChainModel {
     }
 
     // ---- tangent sweeps over the tape ---------------------------------------------------------------
-    /// Tangent of f_c: F_t = K d_t.  Writes d_t to the tangent tape.
-    __device__ static __forceinline__ State fc_tan(const Lane &L, const TapeK &g, const State &s_t,
-                                                   double4 *st_stage, int j) {
-        double d_t = s_t.x - prev_point(L, s_t.x);
-        reinterpret_cast<double *>(reinterpret_cast<char *>(st_stage) + j * 256)[L.q] = d_t; // idle lanes: slot 31
-        const Comps dc = comps(d_t);
-        double F  = g.K[0] * dc.c0;
-        F         = __builtin_fma(g.K[1], dc.c1, F);
-        F         = __builtin_fma(g.K[2], dc.c2, F);
-        double Fn = next_point(L, F);
-        return {s_t.v, L.inv_m_l * (Fn - F)};
+    // Within a stage the four substage forces form two independent chains of two: the position a
+    // substage evaluates f_c at depends on the force of the substage two before it (x_2 = x + h/2 v
+    // needs none, x_3 needs a_1, x_4 needs a_2), and the same holds for the adjoint substages.  The
+    // sweeps are written pair by pair - both neighbour differences, both gathers (an exchange row
+    // each), both products - so that one chain's LDS round trip and FMA latencies are filled by the
+    // other's instructions.  Every value is computed by the expression of the substage-by-substage
+    // form.
+    /// Tangent of f_c at two positions: a = inv_m (F_{p+1} - F_p), F = K d_t.  Writes both d_t to the
+    /// tangent tape (substages jA, jB).
+    __device__ static __forceinline__ void fc_tan2(const Lane &L, const TapeK &gA, const TapeK &gB, double xA,
+                                                   double xB, double4 *st_stage, int jA, int jB, double *xs,
+                                                   double &aA, double &aB) {
+        double dA = xA - prev_point(L, xA);
+        double dB = xB - prev_point(L, xB);
+        reinterpret_cast<double *>(reinterpret_cast<char *>(st_stage) + jA * 256)[L.q] = dA; // idle lanes: slot 31
+        reinterpret_cast<double *>(reinterpret_cast<char *>(st_stage) + jB * 256)[L.q] = dB;
+        Comps cA, cB;
+        comps_lds2(L, dA, dB, xs, cA, cB);
+        double FA = gA.K[0] * cA.c0;
+        double FB = gB.K[0] * cB.c0;
+        FA        = __builtin_fma(gA.K[1], cA.c1, FA);
+        FB        = __builtin_fma(gB.K[1], cB.c1, FB);
+        FA        = __builtin_fma(gA.K[2], cA.c2, FA);
+        FB        = __builtin_fma(gB.K[2], cB.c2, FB);
+        aA        = L.inv_m_l * (next_point(L, FA) - FA);
+        aB        = L.inv_m_l * (next_point(L, FB) - FB);
     }
-    /// Tangent of the f_c adjoint: ld_t = K lF_t + M d_t.
-    __device__ static __forceinline__ State fc_adj_tan(const Lane &L, const TapeKM &g, const State &kbar_t) {
-        double A   = prev_point(L, kbar_t.v);
-        double lF  = inv_m * (A - kbar_t.v); // kbar_t.v stays 0 off the masses (see the return)
-        const Comps lc = comps(lF);
-        double ld  = g.K[0] * lc.c0;
-        ld         = __builtin_fma(g.K[1], lc.c1, ld);
-        ld         = __builtin_fma(g.K[2], lc.c2, ld);
-        ld         = __builtin_fma(g.M[0], g.D[0], ld);
-        ld         = __builtin_fma(g.M[1], g.D[1], ld);
-        ld         = __builtin_fma(g.M[2], g.D[2], ld);
-        double ldn = next_point(L, ld);
-        return {L.end ? ld : ld - ldn, L.mass ? kbar_t.x : 0.0};
+    /// Tangent of the f_c adjoint for two substages: the position part ld_p - ld_{p+1} of
+    /// ld_t = K lF_t + M d_t, lF_t = inv_m (kv_{p-1} - kv_p); kv = the velocity part of the substage's
+    /// incoming adjoint (0 off the masses).
+    __device__ static __forceinline__ void fc_adj_tan2(const Lane &L, const TapeKM &gA, const TapeKM &gB, double kvA,
+                                                       double kvB, double *xs, double &oA, double &oB) {
+        double lFA = inv_m * (prev_point(L, kvA) - kvA);
+        double lFB = inv_m * (prev_point(L, kvB) - kvB);
+        Comps cA, cB;
+        comps_lds2(L, lFA, lFB, xs, cA, cB);
+        double ldA = gA.K[0] * cA.c0;
+        double ldB = gB.K[0] * cB.c0;
+        ldA        = __builtin_fma(gA.K[1], cA.c1, ldA);
+        ldB        = __builtin_fma(gB.K[1], cB.c1, ldB);
+        ldA        = __builtin_fma(gA.K[2], cA.c2, ldA);
+        ldB        = __builtin_fma(gB.K[2], cB.c2, ldB);
+        ldA        = __builtin_fma(gA.M[0], gA.D[0], ldA);
+        ldB        = __builtin_fma(gB.M[0], gB.D[0], ldB);
+        ldA        = __builtin_fma(gA.M[1], gA.D[1], ldA);
+        ldB        = __builtin_fma(gB.M[1], gB.D[1], ldB);
+        ldA        = __builtin_fma(gA.M[2], gA.D[2], ldA);
+        ldB        = __builtin_fma(gB.M[2], gB.D[2], ldB);
+        double nA = next_point(L, ldA), nB = next_point(L, ldB);
+        oA = L.end ? ldA : ldA - nA;
+        oB = L.end ? ldB : ldB - nB;
     }
     /// Tangent of one RK4 step; the stage's K rows are in LDS at `buf`.
     __device__ static __forceinline__ State rk4_tan(const Lane &L, const char *buf, const State &s_in, double uc_t,
-                                                    double4 *st_stage) {
-        State s_t = with_input(L, s_in, uc_t);
-        State k1  = fc_tan(L, tape_fwd(L, buf, 0), s_t, st_stage, 0);
-        State k2 = fc_tan(L, tape_fwd(L, buf, 1),
-                          {__builtin_fma(hTs, k1.x, s_t.x), __builtin_fma(hTs, k1.v, s_t.v)}, st_stage, 1);
-        State k3 = fc_tan(L, tape_fwd(L, buf, 2),
-                          {__builtin_fma(hTs, k2.x, s_t.x), __builtin_fma(hTs, k2.v, s_t.v)}, st_stage, 2);
-        State k4 = fc_tan(L, tape_fwd(L, buf, 3),
-                          {__builtin_fma(Ts, k3.x, s_t.x), __builtin_fma(Ts, k3.v, s_t.v)}, st_stage, 3);
-        double tx = __builtin_fma(2.0, k2.x, k1.x), tv = __builtin_fma(2.0, k2.v, k1.v);
-        tx        = __builtin_fma(2.0, k3.x, tx);
-        tv        = __builtin_fma(2.0, k3.v, tv);
-        tx        = tx + k4.x;
-        tv        = tv + k4.v;
+                                                    double4 *st_stage, double *xs) {
+        const State s_t = with_input(L, s_in, uc_t);
+        // k_j = {kx_j, a_j}: kx_1 = v, kx_{j+1} = v + c_j a_j; a_j = a(x + c_{j-1} kx_{j-1})
+        double a1, a2, a3, a4;
+        const double x2 = __builtin_fma(hTs, s_t.v, s_t.x);
+        fc_tan2(L, tape_fwd(L, buf, 0), tape_fwd(L, buf, 1), s_t.x, x2, st_stage, 0, 1, xs, a1, a2);
+        const double kx2 = __builtin_fma(hTs, a1, s_t.v), kx3 = __builtin_fma(hTs, a2, s_t.v);
+        const double x3 = __builtin_fma(hTs, kx2, s_t.x), x4 = __builtin_fma(Ts, kx3, s_t.x);
+        fc_tan2(L, tape_fwd(L, buf, 2), tape_fwd(L, buf, 3), x3, x4, st_stage, 2, 3, xs, a3, a4);
+        const double kx4 = __builtin_fma(Ts, a3, s_t.v);
+        double tx = __builtin_fma(2.0, kx2, s_t.v), tv = __builtin_fma(2.0, a2, a1);
+        tx        = __builtin_fma(2.0, kx3, tx);
+        tv        = __builtin_fma(2.0, a3, tv);
+        tx        = tx + kx4;
+        tv        = tv + a4;
         return {__builtin_fma(c6, tx, s_t.x), __builtin_fma(c6, tv, s_t.v)};
     }
     /// Tangent of the RK4 adjoint (second-order adjoint).  ubar_t is valid on the end point's lanes.
     __device__ static __forceinline__ void rk4_adj_tan(const Lane &L, const char *buf, const State &mu_t,
-                                                       State &sbar_t, double &ubar_t) {
-        double sgx = c6 * mu_t.x, sgv = c6 * mu_t.v;
-        State kb1{sgx, sgv}, kb2{2.0 * sgx, 2.0 * sgv}, kb3{2.0 * sgx, 2.0 * sgv}, kb4{sgx, sgv};
-        sbar_t  = mu_t;
-        State a = fc_adj_tan(L, tape_rev(L, buf, 3), kb4);
-        sbar_t  = {sbar_t.x + a.x, sbar_t.v + a.v};
-        kb3     = {__builtin_fma(Ts, a.x, kb3.x), __builtin_fma(Ts, a.v, kb3.v)};
-        a       = fc_adj_tan(L, tape_rev(L, buf, 2), kb3);
-        sbar_t  = {sbar_t.x + a.x, sbar_t.v + a.v};
-        kb2     = {__builtin_fma(hTs, a.x, kb2.x), __builtin_fma(hTs, a.v, kb2.v)};
-        a       = fc_adj_tan(L, tape_rev(L, buf, 1), kb2);
-        sbar_t  = {sbar_t.x + a.x, sbar_t.v + a.v};
-        kb1     = {__builtin_fma(hTs, a.x, kb1.x), __builtin_fma(hTs, a.v, kb1.v)};
-        a       = fc_adj_tan(L, tape_rev(L, buf, 0), kb1);
-        sbar_t  = {sbar_t.x + a.x, sbar_t.v + a.v};
-        ubar_t  = ((kb4.x + kb3.x) + kb2.x) + kb1.x;
+                                                       State &sbar_t, double &ubar_t, double *xs) {
+        // incoming substage adjoints kb_j = {kbx_j, kbv_j}; the adjoint of f_c returns {G_j, m_j}:
+        // G_j from kbv_j (springs), m_j = kbx_j on the masses (0 elsewhere: keeps kbv at 0 off the masses)
+        const double sgx = c6 * mu_t.x, sgv = c6 * mu_t.v;
+        const double sgx2 = 2.0 * sgx, sgv2 = 2.0 * sgv;
+        const double m4   = L.mass ? sgx : 0.0;
+        const double kbv3 = __builtin_fma(Ts, m4, sgv2);
+        double G4, G3, G2, G1;
+        fc_adj_tan2(L, tape_rev(L, buf, 3), tape_rev(L, buf, 2), sgv, kbv3, xs, G4, G3);
+        const double kbx3 = __builtin_fma(Ts, G4, sgx2);
+        const double m3   = L.mass ? kbx3 : 0.0;
+        const double kbv2 = __builtin_fma(hTs, m3, sgv2);
+        const double kbx2 = __builtin_fma(hTs, G3, sgx2);
+        const double m2   = L.mass ? kbx2 : 0.0;
+        const double kbv1 = __builtin_fma(hTs, m2, sgv);
+        fc_adj_tan2(L, tape_rev(L, buf, 1), tape_rev(L, buf, 0), kbv2, kbv1, xs, G2, G1);
+        const double kbx1 = __builtin_fma(hTs, G2, sgx);
+        const double m1   = L.mass ? kbx1 : 0.0;
+        sbar_t = {(((mu_t.x + G4) + G3) + G2) + G1, (((mu_t.v + m4) + m3) + m2) + m1};
+        ubar_t = ((sgx + kbx3) + kbx2) + kbx1;
     }
 
     /// Adjoint of one RK4 step.  mu = adjoint of x_next; sbar = adjoint of s; ubar (valid on the
     /// end point's lanes) = adjoint of u through the dynamics.  With tape_stage != nullptr the
     /// K and M rows of the four substages are recorded.
     __device__ static __forceinline__ void rk4_adj(const Lane &L, const State &s_in, double uc, const State &mu,
-                                                   State &sbar, double &ubar, double4 *tape_stage = nullptr) {
+                                                   State &sbar, double &ubar, double4 *tape_stage = nullptr,
+                                                   double *xs = nullptr) {
         Springs sp1, sp2, sp3, sp4;
         AdjAux ax;
         State s = with_input(L, s_in, uc);
@@ -373,22 +430,22 @@ struct ChainModel {
         sbar    = mu;
         State a = fc_adj(L, sp4, kb4, ax);
         if (tape_stage)
-            tape_store(L, tape_stage, 3, sp4, ax);
+            tape_store(L, tape_stage, 3, sp4, ax, xs);
         sbar = {sbar.x + a.x, sbar.v + a.v};
         kb3  = {kb3.x + Ts * a.x, kb3.v + Ts * a.v};
         a    = fc_adj(L, sp3, kb3, ax);
         if (tape_stage)
-            tape_store(L, tape_stage, 2, sp3, ax);
+            tape_store(L, tape_stage, 2, sp3, ax, xs);
         sbar = {sbar.x + a.x, sbar.v + a.v};
         kb2  = {kb2.x + 0.5 * (Ts * a.x), kb2.v + 0.5 * (Ts * a.v)};
         a    = fc_adj(L, sp2, kb2, ax);
         if (tape_stage)
-            tape_store(L, tape_stage, 1, sp2, ax);
+            tape_store(L, tape_stage, 1, sp2, ax, xs);
         sbar = {sbar.x + a.x, sbar.v + a.v};
         kb1  = {kb1.x + 0.5 * (Ts * a.x), kb1.v + 0.5 * (Ts * a.v)};
         a    = fc_adj(L, sp1, kb1, ax);
         if (tape_stage)
-            tape_store(L, tape_stage, 0, sp1, ax);
+            tape_store(L, tape_stage, 0, sp1, ax, xs);
         sbar = {sbar.x + a.x, sbar.v + a.v};
         ubar = ((kb4.x + kb3.x) + kb2.x) + kb1.x;
     }

@@ -139,6 +139,11 @@ int dev_alloc(T *&p, size_t count) {
     return PANTR_OK;
 }
 
+/// Dynamic LDS of the chain's evaluation kernel: four vectors and the exchange row of the component gather.
+size_t eval_lds_bytes(const pantr_batch &b) {
+    return (4 * (size_t)b.npad + WaveProblem<ChainModel>::XS_DOUBLES) * sizeof(double);
+}
+
 /// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a handle: keep a
 /// running maximum per kernel and never lower it (a later, smaller handle must not shrink the limit
 /// of a live, larger one).
@@ -384,7 +389,7 @@ int run_eval(pantr_batch *b, int32_t B, int mode, double gamma, const double *x0
     a.x0 = b->d_x0; a.u = b->d_u; a.v = v ? b->d_v : nullptr;
     a.out_s = b->d_s; a.out_v = b->d_o1; a.out_v2 = b->d_o2; a.ws = b->d_ws; a.gamma = gamma;
     a.box = b->box;
-    hipLaunchKernelGGL(pantr_eval_kernel<ChainModel>, dim3(B), dim3(WAVE), 4 * b->npad * sizeof(double), 0, a);
+    hipLaunchKernelGGL(pantr_eval_kernel<ChainModel>, dim3(B), dim3(WAVE), eval_lds_bytes(*b), 0, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     std::vector<double> s((size_t)B * 4);
@@ -562,8 +567,9 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
         b->lds_bytes_cmp = lds_of(true);  // the comparators: the cascade sweeps' scratch gets LDS of its own
     } else {
         b->ws_per_instance = WaveProblem<ChainModel>::workspace_doubles(b->N);
-        b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double); // dynamic part: all vectors (comparators)
-        b->lds_bytes_pantr = (size_t)NUM_CG_VEC * b->npad * sizeof(double);
+        const size_t xs_bytes = WaveProblem<ChainModel>::XS_DOUBLES * sizeof(double);
+        b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double) + xs_bytes; // dynamic part: all vectors (comparators)
+        b->lds_bytes_pantr = (size_t)NUM_CG_VEC * b->npad * sizeof(double) + xs_bytes;
         static_lds         = WaveProblem<ChainModel>::tape_lds_bytes();
     }
     if ((b->al() ? b->lds_bytes : b->lds_bytes_pantr) + static_lds > 160 * 1024)
@@ -590,7 +596,7 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
                                   (const void *)&pantr_solve_kernel<ChainModel, 2>})
                 if (int rc = raise_dynamic_lds(k, b->lds_bytes))
                     return rc;
-        if (int rc = raise_dynamic_lds((const void *)&pantr_eval_kernel<ChainModel>, 4 * (size_t)b->npad * sizeof(double)))
+        if (int rc = raise_dynamic_lds((const void *)&pantr_eval_kernel<ChainModel>, eval_lds_bytes(*b)))
             return rc;
     }
     const size_t B  = b->maxB;

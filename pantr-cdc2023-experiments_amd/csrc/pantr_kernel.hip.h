@@ -157,6 +157,10 @@ struct WaveProblem {
     /// lives only inside the CG loop (no sweep runs there)
     static constexpr int S_STAGE   = CG_BASE + 3;
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
+    /// Exchange row of the component gather: XS_DOUBLES doubles of dynamic LDS behind the kernel's vectors.
+    static constexpr int XS_DOUBLES = 64;
+    double *xrow = nullptr;
+    __device__ __forceinline__ double *xs() const { return xrow; }
     /// Iterate vector `slot` (0..11): HBM (ITER_GLOBAL) or the first twelve LDS slots.
     __device__ __forceinline__ double *ivec(int slot) const {
         if constexpr (ITER_GLOBAL)
@@ -246,7 +250,7 @@ struct WaveProblem {
             double uc = M::load_input(L, u + M::nu * k);
             State sbar;
             double ubar;
-            M::rk4_adj(L, s, uc, lam, sbar, ubar, RECORD ? tape + (size_t)k * M::TAPE_D4_PER_STAGE : nullptr);
+            M::rk4_adj(L, s, uc, lam, sbar, ubar, RECORD ? tape + (size_t)k * M::TAPE_D4_PER_STAGE : nullptr, xs());
             M::store_input_grad(L, grad + M::nu * k, ubar + M::c2g * uc);
             lam = sbar;
             M::cost_grad_x_add(L, s, lam);
@@ -271,7 +275,7 @@ struct WaveProblem {
                 M::prefetch_fwd(L, tape + (size_t)(k + 1) * M::TAPE_D4_PER_STAGE, nxt);
             double uc_t = M::load_input(L, v + M::nu * k);
             M::xt_store(L, Xt + (size_t)k * M::XT_DOUBLES, s_t);
-            s_t = M::rk4_tan(L, cur, s_t, uc_t, st + (size_t)k * M::ST_D4_PER_STAGE);
+            s_t = M::rk4_tan(L, cur, s_t, uc_t, st + (size_t)k * M::ST_D4_PER_STAGE, xs());
         };
         if (!primed)
             M::prefetch_fwd(L, tape, tbuf0);
@@ -288,15 +292,15 @@ struct WaveProblem {
         auto stage_rev = [&](int k, char *cur, char *nxt) {
             wait_vmem(); // stage k's rows and Xt row have landed
             xt = xt_n;
+            double uc_t = M::load_input(L, v + M::nu * k);
             if (k > 0) { // one stage ahead
                 M::prefetch_rev(L, tape + (size_t)(k - 1) * M::TAPE_D4_PER_STAGE,
                                 st + (size_t)(k - 1) * M::ST_D4_PER_STAGE, nxt);
                 xt_n = M::xt_load(L, Xt + (size_t)(k - 1) * M::XT_DOUBLES);
             }
-            double uc_t = M::load_input(L, v + M::nu * k);
             State sbar_t;
             double ubar_t;
-            M::rk4_adj_tan(L, cur, lam_t, sbar_t, ubar_t);
+            M::rk4_adj_tan(L, cur, lam_t, sbar_t, ubar_t, xs());
             M::store_input_grad(L, Hv + M::nu * k, __builtin_fma(M::c2g, uc_t, ubar_t));
             lam_t = sbar_t;
             M::cost_grad_x_add_tan(L, xt, lam_t);
@@ -865,6 +869,7 @@ __global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // 
     PB pb{L, a.prm.box, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
     pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
+    pb.xrow = lds + PB::LDS_SLOTS * a.npad;
     const int n = a.n, nj = a.nj;
     for (int i = lane; i < PB::LDS_SLOTS * a.npad; i += WAVE)
         lds[i] = 0.0;
@@ -936,6 +941,7 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
     WaveProblem<M> pb{L, a.box, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
     pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
+    pb.xrow = lds + 4 * a.npad;
     double *u = pb.vec(0), *v = pb.vec(1), *o = pb.vec(2), *o2 = pb.vec(3);
     for (int i = lane; i < 4 * a.npad; i += WAVE)
         lds[i] = 0.0;
