@@ -56,6 +56,8 @@ struct ChainModel {
         return c <= c2 ? (c == 0 ? c2 : c == 1 ? 2 + c2 : 5) : sym(c2, c);
     }
 
+    /// A tape row is 64 doubles: ten springs x six entries and four unused slots; nobody reads the last one.
+    static constexpr int TAPE_ROW_DUMP = 63;
     /// Per-lane role.
     struct Lane {
         int l, p, c, q; ///< lane, point, component, compact slot 3p+c
@@ -192,8 +194,8 @@ struct ChainModel {
         sp.d      = s.x - prev_point(L, s.x); // point 0 is anchored at the origin: x - 0
         double sq = sp.d * sp.d;
         sp.n2     = quad_sum(sq);
-        sp.r      = __builtin_sqrt(sp.n2);
-        sp.c      = Dspring * (1.0 - Lspring / sp.r);
+        sp.r      = sqrt_inrange(sp.n2); // = sqrt(n2), L / r: wave_math.hip.h
+        sp.c      = Dspring * (1.0 - div_inrange(Lspring, sp.r));
     }
     /// The end point has no velocity state: its lanes carry the stage input there instead, so the
     /// time derivative of every position is just "the v slot" (with_input() once per stage; the
@@ -223,7 +225,7 @@ struct ChainModel {
         double pr  = sp.d * ax.lF;
         ax.dt      = quad_sum(pr);
         double n2r = sp.n2 * sp.r;
-        ax.w       = DL / n2r;
+        ax.w       = div_inrange(DL, n2r);
         double t   = ax.dt * ax.w;
         double ld  = (sp.c * ax.lF) + (t * sp.d);
         double ldn = next_point(L, ld);
@@ -262,11 +264,15 @@ struct ChainModel {
                                                       const AdjAux &ax, double *xs) {
         const Comps dc = comps_lds(L, sp.d, xs), lc = comps_lds(L, ax.lF, xs);
         const double dq[DIM] = {dc.c0, dc.c1, dc.c2}, lq[DIM] = {lc.c0, lc.c1, lc.c2};
-        const double e  = 3.0 / sp.n2;
+        const double e  = div_inrange(3.0, sp.n2);
         const double wd = ax.w * sp.d;
         const double g  = e * sp.d;
-        double *Krow = reinterpret_cast<double *>(reinterpret_cast<char *>(stage) + j * 512) + 6 * L.p;
-        double *Mrow = reinterpret_cast<double *>(reinterpret_cast<char *>(stage) + 2048 + j * 512) + 6 * L.p;
+        // Every lane computes its three entries of the row and stores them - the lanes that own no entry
+        // of the upper triangle (c > c2, idle lanes) into the row's unread last slot: stores under an exec
+        // mask would put each entry's arithmetic into a basic block of its own (twelve per stage), which
+        // the scheduler cannot overlap with the adjoint recursion.
+        double *Krow = reinterpret_cast<double *>(reinterpret_cast<char *>(stage) + j * 512);
+        double *Mrow = reinterpret_cast<double *>(reinterpret_cast<char *>(stage) + 2048 + j * 512);
 #pragma unroll
         for (int c2 = 0; c2 < DIM; ++c2) {
             double K  = __builtin_fma(wd, dq[c2], L.c == c2 ? sp.c : 0.0);
@@ -275,11 +281,11 @@ struct ChainModel {
             double kd = __builtin_fma(-g, dq[c2], L.c == c2 ? 1.0 : 0.0);
             m         = __builtin_fma(ax.dt, kd, m);
             double M  = ax.w * m;
-            if (L.active && L.c <= c2) { // upper triangle: row c, column c2 >= c
-                int e_idx    = L.c == 0 ? c2 : (L.c == 1 ? 2 + c2 : 5);
-                Krow[e_idx]  = K;
-                Mrow[e_idx]  = M;
-            }
+            // slot of entry (c, c2): recomputed here (three integer operations) rather than kept in the
+            // lane's registers for the whole solve
+            const int slot = (L.active && L.c <= c2) ? 6 * L.p + sym(L.c, c2) : TAPE_ROW_DUMP;
+            Krow[slot] = K;
+            Mrow[slot] = M;
         }
     }
     /// Start the LDS-DMA of one stage into the landing buffer `buf`: 2 KiB (K rows) for the
@@ -325,13 +331,13 @@ struct ChainModel {
     // form.
     /// Tangent of f_c at two positions: a = inv_m (F_{p+1} - F_p), F = K d_t.  Writes both d_t to the
     /// tangent tape (substages jA, jB).
-    __device__ static __forceinline__ void fc_tan2(const Lane &L, const TapeK &gA, const TapeK &gB, double xA,
-                                                   double xB, double4 *st_stage, int jA, int jB, double *xs,
-                                                   double &aA, double &aB) {
+    __device__ static __forceinline__ void fc_tan2(const Lane &L, const char *buf, int jA, int jB, double xA,
+                                                   double xB, double4 *st_stage, double *xs, double &aA, double &aB) {
         double dA = xA - prev_point(L, xA);
         double dB = xB - prev_point(L, xB);
         reinterpret_cast<double *>(reinterpret_cast<char *>(st_stage) + jA * 256)[L.q] = dA; // idle lanes: slot 31
         reinterpret_cast<double *>(reinterpret_cast<char *>(st_stage) + jB * 256)[L.q] = dB;
+        const TapeK gA = tape_fwd(L, buf, jA), gB = tape_fwd(L, buf, jB);
         Comps cA, cB;
         comps_lds2(L, dA, dB, xs, cA, cB);
         double FA = gA.K[0] * cA.c0;
@@ -346,10 +352,11 @@ struct ChainModel {
     /// Tangent of the f_c adjoint for two substages: the position part ld_p - ld_{p+1} of
     /// ld_t = K lF_t + M d_t, lF_t = inv_m (kv_{p-1} - kv_p); kv = the velocity part of the substage's
     /// incoming adjoint (0 off the masses).
-    __device__ static __forceinline__ void fc_adj_tan2(const Lane &L, const TapeKM &gA, const TapeKM &gB, double kvA,
+    __device__ static __forceinline__ void fc_adj_tan2(const Lane &L, const char *buf, int jA, int jB, double kvA,
                                                        double kvB, double *xs, double &oA, double &oB) {
         double lFA = inv_m * (prev_point(L, kvA) - kvA);
         double lFB = inv_m * (prev_point(L, kvB) - kvB);
+        const TapeKM gA = tape_rev(L, buf, jA), gB = tape_rev(L, buf, jB);
         Comps cA, cB;
         comps_lds2(L, lFA, lFB, xs, cA, cB);
         double ldA = gA.K[0] * cA.c0;
@@ -375,10 +382,10 @@ struct ChainModel {
         // k_j = {kx_j, a_j}: kx_1 = v, kx_{j+1} = v + c_j a_j; a_j = a(x + c_{j-1} kx_{j-1})
         double a1, a2, a3, a4;
         const double x2 = __builtin_fma(hTs, s_t.v, s_t.x);
-        fc_tan2(L, tape_fwd(L, buf, 0), tape_fwd(L, buf, 1), s_t.x, x2, st_stage, 0, 1, xs, a1, a2);
+        fc_tan2(L, buf, 0, 1, s_t.x, x2, st_stage, xs, a1, a2);
         const double kx2 = __builtin_fma(hTs, a1, s_t.v), kx3 = __builtin_fma(hTs, a2, s_t.v);
         const double x3 = __builtin_fma(hTs, kx2, s_t.x), x4 = __builtin_fma(Ts, kx3, s_t.x);
-        fc_tan2(L, tape_fwd(L, buf, 2), tape_fwd(L, buf, 3), x3, x4, st_stage, 2, 3, xs, a3, a4);
+        fc_tan2(L, buf, 2, 3, x3, x4, st_stage, xs, a3, a4);
         const double kx4 = __builtin_fma(Ts, a3, s_t.v);
         double tx = __builtin_fma(2.0, kx2, s_t.v), tv = __builtin_fma(2.0, a2, a1);
         tx        = __builtin_fma(2.0, kx3, tx);
@@ -397,14 +404,14 @@ struct ChainModel {
         const double m4   = L.mass ? sgx : 0.0;
         const double kbv3 = __builtin_fma(Ts, m4, sgv2);
         double G4, G3, G2, G1;
-        fc_adj_tan2(L, tape_rev(L, buf, 3), tape_rev(L, buf, 2), sgv, kbv3, xs, G4, G3);
+        fc_adj_tan2(L, buf, 3, 2, sgv, kbv3, xs, G4, G3);
         const double kbx3 = __builtin_fma(Ts, G4, sgx2);
         const double m3   = L.mass ? kbx3 : 0.0;
         const double kbv2 = __builtin_fma(hTs, m3, sgv2);
         const double kbx2 = __builtin_fma(hTs, G3, sgx2);
         const double m2   = L.mass ? kbx2 : 0.0;
         const double kbv1 = __builtin_fma(hTs, m2, sgv);
-        fc_adj_tan2(L, tape_rev(L, buf, 1), tape_rev(L, buf, 0), kbv2, kbv1, xs, G2, G1);
+        fc_adj_tan2(L, buf, 1, 0, kbv2, kbv1, xs, G2, G1);
         const double kbx1 = __builtin_fma(hTs, G2, sgx);
         const double m1   = L.mass ? kbx1 : 0.0;
         sbar_t = {(((mu_t.x + G4) + G3) + G2) + G1, (((mu_t.v + m4) + m3) + m2) + m1};

@@ -147,6 +147,9 @@ struct WaveProblem {
     /// waits for them.
     mutable bool primed = false;
     double *giter = nullptr; ///< ITER_GLOBAL: this instance's NUM_ITER_VEC iterate vectors in the HBM workspace
+#ifdef PANTR_PHASE_TIMING
+    mutable long long fwd_cycles = 0; ///< profiling build: shader cycles spent in the forward half of the products
+#endif
 
     /// LDS vector `slot`; the CG block starts at CG_BASE.
     static constexpr int CG_BASE   = ITER_GLOBAL ? 0 : NUM_ITER_VEC;
@@ -267,13 +270,16 @@ struct WaveProblem {
     /// in-flight DMA with vmcnt(0) before each read and the prefetch hides nothing).
     __device__ __forceinline__ void hess_prod_tape(const double *v, double *Hv) const {
         wave_sync();
+#ifdef PANTR_PHASE_TIMING
+        const long long hv_t0_ = clock64();
+#endif
         // ---- forward tangent sweep ----
         State s_t{0.0, 0.0};
         auto stage_fwd = [&](int k, char *cur, char *nxt) {
             wait_vmem(); // stage k's rows have landed in `cur`
             if (k + 1 < N)
                 M::prefetch_fwd(L, tape + (size_t)(k + 1) * M::TAPE_D4_PER_STAGE, nxt);
-            double uc_t = M::load_input(L, v + M::nu * k);
+            const double uc_t = M::load_input(L, v + M::nu * k);
             M::xt_store(L, Xt + (size_t)k * M::XT_DOUBLES, s_t);
             s_t = M::rk4_tan(L, cur, s_t, uc_t, st + (size_t)k * M::ST_D4_PER_STAGE, xs());
         };
@@ -285,6 +291,9 @@ struct WaveProblem {
                 stage_fwd(k + 1, tbuf1, tbuf0);
         }
         wave_sync();
+#ifdef PANTR_PHASE_TIMING
+        fwd_cycles += clock64() - hv_t0_;
+#endif
         // ---- second-order adjoint sweep (even stages land in tbuf0, odd ones in tbuf1) ----
         State lam_t{0.0, 0.0};
         M::cost_grad_x_add_tan(L, L.end ? s_t.x : s_t.v, lam_t);
@@ -853,7 +862,7 @@ __device__ __forceinline__ InnerResult inner_solve(PB &pb, const KernelParams &P
 // The solve kernel for problems without general constraints (m = 0: ALM = one inner solve)
 // ---------------------------------------------------------------------------------------
 template <class M, int METHOD>
-__global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // <= 256 VGPRs: two wavefronts per SIMD
+__global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // <= 256 VGPRs: two wavefronts per SIMD (uncapped it would take 260)
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
@@ -963,6 +972,9 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
             pb.hess_prod_tape(v, o);
         s1 = (double)(clock64() - c0);      // shader cycles
         s2 = (double)(wall_clock64() - w0); // constant-rate clock ticks
+#ifdef PANTR_PHASE_TIMING
+        s3 = (double)pb.fwd_cycles;         // of which the forward sweeps (profiling build)
+#endif
         wait_vmem();                        // the rows left in flight for a successor
     } else {
         pb.prox_grad_step(a.gamma, u, v, o, o2, s0, s1);

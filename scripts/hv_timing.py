@@ -26,5 +26,8 @@ L.pantr_debug_hess_prod_timed(b._h, B, x0c.ctypes.data_as(vp), uc.ctypes.data_as
 cyc, ticks = sc[:, 1], sc[:, 2]
 print(f"in-kernel: {np.median(cyc)/101/60:.0f} shader cycles per stage (fwd+adj), clock {np.median(cyc/ticks)*100:.0f} MHz, "
       f"{np.median(ticks)/101*10/1e3:.1f} us per product")
+if "+phase-timing" in pa.version():
+    f = np.median(sc[:, 3]) / 101 / 60
+    print(f"   forward sweep {f:.0f} cycles per stage, adjoint sweep {np.median(cyc)/101/60 - f:.0f}")
 print(f"B={B}: Hv (tape replay) = {(res[101]-res[1])/100*1e6:.1f} us per product per wave "
       f"({60*(res[101]-res[1])/100/60*1e9/60:.0f} ns/stage)")
