@@ -117,17 +117,14 @@ struct ChainModel {
         const double *s = xs + DIM * L.pc;
         return {s[0], s[1], s[2]};
     }
-    /// Two gathers at once, an exchange row each (xs: 64 doubles): both writes, then both sets of reads.
-    __device__ static __forceinline__ void comps_lds2(const Lane &L, double vA, double vB, double *xs, Comps &cA,
-                                                      Comps &cB) {
-        xs[L.q]      = vA;
-        xs[32 + L.q] = vB;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double *s = xs + DIM * L.pc;
-        cA = {s[0], s[1], s[2]};
-        cB = {s[32], s[33], s[34]};
+    /// Two gathers side by side, one each way: A through the permlane swaps (12 instructions, ~45 cycles),
+    /// B through the exchange row (3 instructions, ~120 cycles behind the tape reads queued before it).
+    /// The paired sweeps are bound by their dependent chains, with issue slots to spare: the swaps of
+    /// one chain fill the LDS wait of the other (both through LDS: 51.6 us per product at N = 60, both
+    /// through swaps: 50.4, one each: 48.4).
+    __device__ static __forceinline__ void comps2(const Lane &L, double vA, double vB, double *xs, Comps &cA, Comps &cB) {
+        cB = comps_lds(L, vB, xs);
+        cA = comps(vA);
     }
     /// (v0 + v1) + v2 over the three components of this lane's point: the cross-row sum
     /// (row 0 + row 1) + (row 2 + row 3) with the idle row 3 holding 0 (lanes of row 3 contribute
@@ -325,9 +322,9 @@ struct ChainModel {
     // Within a stage the four substage forces form two independent chains of two: the position a
     // substage evaluates f_c at depends on the force of the substage two before it (x_2 = x + h/2 v
     // needs none, x_3 needs a_1, x_4 needs a_2), and the same holds for the adjoint substages.  The
-    // sweeps are written pair by pair - both neighbour differences, both gathers (an exchange row
-    // each), both products - so that one chain's LDS round trip and FMA latencies are filled by the
-    // other's instructions.  Every value is computed by the expression of the substage-by-substage
+    // sweeps are written pair by pair - both neighbour differences, both gathers (comps2), both
+    // products - so that one chain's LDS round trip and FMA latencies are filled by the other's
+    // instructions.  Every value is computed by the expression of the substage-by-substage
     // form.
     /// Tangent of f_c at two positions: a = inv_m (F_{p+1} - F_p), F = K d_t.  Writes both d_t to the
     /// tangent tape (substages jA, jB).
@@ -339,7 +336,7 @@ struct ChainModel {
         reinterpret_cast<double *>(reinterpret_cast<char *>(st_stage) + jB * 256)[L.q] = dB;
         const TapeK gA = tape_fwd(L, buf, jA), gB = tape_fwd(L, buf, jB);
         Comps cA, cB;
-        comps_lds2(L, dA, dB, xs, cA, cB);
+        comps2(L, dA, dB, xs, cA, cB);
         double FA = gA.K[0] * cA.c0;
         double FB = gB.K[0] * cB.c0;
         FA        = __builtin_fma(gA.K[1], cA.c1, FA);
@@ -358,7 +355,7 @@ struct ChainModel {
         double lFB = inv_m * (prev_point(L, kvB) - kvB);
         const TapeKM gA = tape_rev(L, buf, jA), gB = tape_rev(L, buf, jB);
         Comps cA, cB;
-        comps_lds2(L, lFA, lFB, xs, cA, cB);
+        comps2(L, lFA, lFB, xs, cA, cB);
         double ldA = gA.K[0] * cA.c0;
         double ldB = gB.K[0] * cB.c0;
         ldA        = __builtin_fma(gA.K[1], cA.c1, ldA);

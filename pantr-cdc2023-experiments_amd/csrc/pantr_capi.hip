@@ -1009,6 +1009,13 @@ extern "C" int pantr_debug_hess_prod_timed(pantr_batch_t *b, int32_t B, const do
     return run_eval(b, B, EVAL_HESS_PROD_TAPE, 0, x0, u, v, scal, Hv, nullptr);
 }
 
+/// Development aid (profiling build): (psi, grad psi) returning {psi, cycles of `reps` forward sweeps, of
+/// `reps` adjoint sweeps, of `reps` recording adjoint sweeps} per instance.
+extern "C" int pantr_debug_psi_grad_timed(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
+                                          double *grad, double *scal) {
+    return run_eval(b, B, EVAL_PSI_GRAD, 0, x0, u, nullptr, scal, grad, nullptr);
+}
+
 extern "C" void pantr_debug_set_eval_reps(pantr_batch_t *b, int r) {
     if (b)
         b->eval_reps = r > 0 ? r : 1;

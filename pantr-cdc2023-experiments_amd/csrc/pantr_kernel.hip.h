@@ -159,9 +159,14 @@ struct WaveProblem {
     /// ITER_GLOBAL: staging copy of a sweep's decision vector; shares the slot of the CG iterate z, which
     /// lives only inside the CG loop (no sweep runs there)
     static constexpr int S_STAGE   = CG_BASE + 3;
+    /// ITER_GLOBAL: the adjoint sweep collects the gradient here and copies it to its HBM vector once at
+    /// the end (a store to HBM inside the stage loop is waited for - with everything else outstanding -
+    /// by the next stage's read of its prefetched state).  The slot of the CG residual r: dead outside
+    /// the CG loop like z.
+    static constexpr int S_GSTAGE  = CG_BASE + 4;
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
     /// Exchange row of the component gather: XS_DOUBLES doubles of dynamic LDS behind the kernel's vectors.
-    static constexpr int XS_DOUBLES = 64;
+    static constexpr int XS_DOUBLES = 32;
     double *xrow = nullptr;
     __device__ __forceinline__ double *xs() const { return xrow; }
     /// Iterate vector `slot` (0..11): HBM (ITER_GLOBAL) or the first twelve LDS slots.
@@ -240,8 +245,9 @@ struct WaveProblem {
     }
     /// The adjoint sweep alone, over the trajectory the last psi_forward<true>(u) stored (same u).
     template <bool RECORD = false>
-    __device__ __forceinline__ void grad_reverse(const double *u_in, double *grad) const {
+    __device__ __forceinline__ void grad_reverse(const double *u_in, double *grad_out) const {
         const double *u = staged(u_in);
+        double *grad = ITER_GLOBAL ? vec(S_GSTAGE) : grad_out;
         wave_sync(); // the sweep below re-reads rows this wavefront has just written
         State lam{0.0, 0.0};
         M::cost_grad_x_add(L, M::traj_load(L, X + (size_t)N * M::TRAJ_DOUBLES), lam);
@@ -260,6 +266,13 @@ struct WaveProblem {
             s = s_prev;
         }
         wave_sync(); // grad was written by the owner of the input adjoint
+        if constexpr (ITER_GLOBAL) {
+            for (int j = 0; j < nj; ++j) {
+                int i = j * WAVE + L.l;
+                if (i < n)
+                    grad_out[i] = grad[i];
+            }
+        }
     }
 
     /// Hv = d/du (grad psi(u)^T v) at the point the tape was recorded at (psi_grad<true>):
@@ -965,6 +978,21 @@ __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
         s0 = pb.template psi_forward<false>(u);
     } else if (a.mode == EVAL_PSI_GRAD) {
         s0 = pb.psi_grad(u, o);
+#ifdef PANTR_PHASE_TIMING
+        // profiling build: shader cycles of the three first-order sweeps, `reps` runs each (scripts/sweep_timing.py)
+        const int reps = a.reps > 0 ? a.reps : 1;
+        long long c0 = clock64();
+        for (int r = 0; r < reps; ++r)
+            s0 = pb.template psi_forward<true>(u);
+        long long c1 = clock64();
+        for (int r = 0; r < reps; ++r)
+            pb.template grad_reverse<false>(u, o);
+        long long c2 = clock64();
+        for (int r = 0; r < reps; ++r)
+            pb.template grad_reverse<true>(u, o);
+        long long c3 = clock64();
+        s1 = (double)(c1 - c0), s2 = (double)(c2 - c1), s3 = (double)(c3 - c2);
+#endif
     } else if (a.mode == EVAL_HESS_PROD_TAPE) {
         s0 = pb.template psi_grad<true>(u, o2); // record at u, then replay (the solver's path)
         long long c0 = clock64(), w0 = wall_clock64();
