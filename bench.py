@@ -329,9 +329,10 @@ def strong_mode(args, torch, pa, dev, local_rank, rank, world, distributed, rehe
         one_pass()
         torch.cuda.synchronize()
     barrier()
-    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, None if rehearsal else dev)
-    for r in rs:
-        r.check(args.workload)
+    cdev = None if rehearsal else dev
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, cdev)
+    # a failure on one rank ends all ranks here, before the next collective
+    sharding.raise_together(next((m for m in (sharding.local_failure(r.check, args.workload) for r in rs) if m), None), cdev)
     # gather every rank's solutions (first nu inputs of each instance: what the plant receives) and check
     # them on rank 0 against the unsharded solve of the same batch
     nu = rs[0].batch.nu
@@ -340,6 +341,7 @@ def strong_mode(args, torch, pa, dev, local_rank, rank, world, distributed, rehe
     gathered = sharding.gather_rows(local, local_idx, len(where), None if rehearsal else dev)
     kms = [r.kernel_ms() for r in rs]
     alg = sum(r.alg_bytes() for r in rs if r.B)
+    failure, same = None, None
     if rank == 0:
         full = [Resident(w, torch, pa, dev, local_rank) for w in ws]
         for r in full:
@@ -348,10 +350,12 @@ def strong_mode(args, torch, pa, dev, local_rank, rank, world, distributed, rehe
         ref = np.vstack([r.solutions()[:, :nu] for r in full])
         same = bool(np.array_equal(ref, gathered))
         for r in full:
-            r.check(args.workload + " (unsharded)")
+            failure = failure or sharding.local_failure(r.check, args.workload + " (unsharded)")
             r.close()
         if not same:
-            raise SystemExit("bench.py: the sharded solutions differ from the unsharded solve")
+            failure = failure or "bench.py: the sharded solutions differ from the unsharded solve"
+    sharding.raise_together(failure, cdev)  # every rank: rank 0's verdict on the gathered result
+    if rank == 0:
         total = len(where) * args.steps
         dom = int(np.argmax(kms))
         print(json.dumps({
@@ -461,9 +465,9 @@ def main():
     if S > 1:  # the last launch of every stream (durations overlap: they are latencies, not shares)
         kernel_ms = [r.kernel_ms() for r in rs[:min(S, args.steps)]]
     elapsed = sharding.max_over_ranks(elapsed, None if rehearsal else dev)  # MAX over ranks (identity at N = 1)
-    for r in rs:
-        if r.launched:
-            r.check("headline")
+    # a failure on one rank ends all ranks together (none is left waiting in the closing barrier)
+    sharding.raise_together(next((m for m in (sharding.local_failure(r.check, "headline") for r in rs if r.launched) if m),
+                                 None), None if rehearsal else dev)
 
     if rank == 0:
         total_steps = world * B * args.steps

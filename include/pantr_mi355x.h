@@ -14,6 +14,7 @@
 #ifndef PANTR_MI355X_H
 #define PANTR_MI355X_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -233,9 +234,12 @@ const char *pantr_last_error(void);
 /* Library name and version; any build switch that changes what is computed or reported is
  * appended ("+phase-timing"), so a caller can refuse a non-product build. */
 const char *pantr_version(void);
-/* sha256 (hex) over the kernel sources the library was built from (csrc/, in name order); the
- * Python binding compares it with the tree's and refuses a stale library. */
+/* sha256 (hex) over the sources the library was built from (the headers and .hip files of csrc/, the
+ * headers of host/, in name order, then this header); the Python binding compares it with the
+ * tree's and refuses a stale library. */
 const char *pantr_source_hash(void);
+/* sizeof(pantr_stats_t) as compiled into the library: a binding checks its own record layout against it. */
+size_t pantr_stats_size(void);
 int pantr_device_count(void);
 /* Achievable HBM bandwidth of `device`: a 16-bytes-per-lane device copy of `bytes` bytes (choose well
  * beyond the 256 MiB Infinity Cache), best of `reps` timed passes by HIP events, as read + written

@@ -127,8 +127,13 @@ struct ChainModel {
         cA = comps(vA);
     }
     /// (v0 + v1) + v2 over the three components of this lane's point: the cross-row sum
-    /// (row 0 + row 1) + (row 2 + row 3) with the idle row 3 holding 0 (lanes of row 3 contribute
-    /// whatever they hold: the callers keep them at 0).
+    /// (row 0 + row 1) + (row 2 + row 3) with the idle row 3 holding 0.  Lanes of row 3 contribute
+    /// whatever they hold; they hold exactly 0 by construction: load_x0 / traj_load give them a zero
+    /// state, and every quantity summed here is a product with a factor derived from that state by
+    /// differences and products (d = x - prev(x) = 0, so d d = 0 and d lF = 0).  A mask here would cost
+    /// two instructions on the dependent chain of every spring evaluation; instead
+    /// tests/test_gpu_parity.py::test_idle_row_of_the_lane_layout_stays_zero reads the stored
+    /// trajectories back and pins the invariant.
     __device__ static __forceinline__ double quad_sum(double v) {
         double a, b;
         row_partner<false>(v, a, b);

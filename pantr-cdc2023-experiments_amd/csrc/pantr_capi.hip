@@ -68,6 +68,7 @@ struct pantr_batch {
     int32_t mpad = 0, mj = 0;
     bool al() const { return problem != ProblemId::HangingChain; }
     DeviceStats *d_stats = nullptr;
+    const void *checked_ptrs[4] = {nullptr, nullptr, nullptr, nullptr}; ///< last buffer set pantr_batch_solve_device accepted
     int32_t *d_order     = nullptr;
     bool have_order      = false;
     int32_t trace_instances = 0, trace_cap = 0;
@@ -423,6 +424,7 @@ const char *pantr_source_hash(void) {
     return "";
 #endif
 }
+size_t pantr_stats_size(void) { return sizeof(pantr_stats_t); }
 int pantr_device_count(void) {
     int c = 0;
     if (hipGetDeviceCount(&c) != hipSuccess)
@@ -889,18 +891,26 @@ int pantr_batch_solve_device(pantr_batch_t *b, int32_t B, const double *d_x0, do
     // HIP runtime instance than the one this library is bound to (a process that loaded this
     // library before `import torch`), the runtime here does not know the pointers: fail loudly
     // instead of launching a kernel on addresses it cannot see.
-    for (const void *p : {(const void *)d_x0, (const void *)d_u, (const void *)d_stats, (const void *)d_y}) {
-        if (!p)
-            continue;
-        hipPointerAttribute_t attr{};
-        if (hipPointerGetAttributes(&attr, p) != hipSuccess || attr.type != hipMemoryTypeDevice ||
-            attr.device != b->device) {
-            (void)hipGetLastError();
-            return fail(PANTR_ERR_NO_DEVICE,
-                        "pantr_batch_solve_device: a buffer is not device memory of this handle's GPU as seen by "
-                        "the HIP runtime this library is bound to (in a process that also uses PyTorch, import "
-                        "torch and initialise torch.cuda before the first call into this library)");
+    // Checked once per set of base pointers (a caller passes the same buffers launch after launch; the
+    // attribute queries stay off the launch path).  Managed memory is device-accessible and accepted.
+    const void *ptrs[4] = {d_x0, d_u, d_stats, d_y};
+    if (std::memcmp(ptrs, b->checked_ptrs, sizeof ptrs) != 0) {
+        for (const void *p : ptrs) {
+            if (!p)
+                continue;
+            hipPointerAttribute_t attr{};
+            const bool known = hipPointerGetAttributes(&attr, p) == hipSuccess;
+            const bool ok = known && ((attr.type == hipMemoryTypeDevice && attr.device == b->device) ||
+                                      attr.type == hipMemoryTypeManaged);
+            if (!ok) {
+                (void)hipGetLastError();
+                return fail(PANTR_ERR_NO_DEVICE,
+                            "pantr_batch_solve_device: a buffer is not device (or managed) memory of this handle's GPU as "
+                            "seen by the HIP runtime this library is bound to (in a process that also uses PyTorch, "
+                            "import torch and initialise torch.cuda before the first call into this library)");
+            }
         }
+        std::memcpy(b->checked_ptrs, ptrs, sizeof ptrs);
     }
     return launch_solve(b, B, d_x0, d_u, d_y, reinterpret_cast<DeviceStats *>(d_stats),
                         static_cast<hipStream_t>(stream));
@@ -1014,6 +1024,18 @@ extern "C" int pantr_debug_hess_prod_timed(pantr_batch_t *b, int32_t B, const do
 extern "C" int pantr_debug_psi_grad_timed(pantr_batch_t *b, int32_t B, const double *x0, const double *u,
                                           double *grad, double *scal) {
     return run_eval(b, B, EVAL_PSI_GRAD, 0, x0, u, nullptr, scal, grad, nullptr);
+}
+
+/// Development aid / tests: `count` doubles of instance `inst`'s HBM workspace from `offset` (layout:
+/// WaveProblem::bind_workspace - the trajectory rows of the last stored forward sweep come first).
+extern "C" int pantr_debug_read_workspace(pantr_batch_t *b, int32_t inst, int64_t offset, int64_t count, double *out) {
+    if (!b || !out || inst < 0 || inst >= b->maxB || offset < 0 || count < 0 ||
+        (size_t)(offset + count) > b->ws_per_instance)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "pantr_debug_read_workspace: bad range");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpy(out, b->d_ws + (size_t)inst * b->ws_per_instance + offset, (size_t)count * sizeof(double),
+                      hipMemcpyDeviceToHost));
+    return PANTR_OK;
 }
 
 extern "C" void pantr_debug_set_eval_reps(pantr_batch_t *b, int r) {

@@ -93,7 +93,7 @@ EXPORTS = (
     "pantr_batch_footprint", "pantr_batch_eval_grad_L", "pantr_batch_create_from_files",
     "pantr_batch_get_penalty_alm_split", "pantr_problem_data_load", "pantr_problem_data_destroy",
     "pantr_problem_data_get", "pantr_problem_dims", "pantr_problem_defaults", "pantr_batch_eval_g",
-    "pantr_batch_mpc_record", "pantr_device_copy_bandwidth", "pantr_source_hash",
+    "pantr_batch_mpc_record", "pantr_device_copy_bandwidth", "pantr_source_hash", "pantr_stats_size",
 )
 
 
@@ -128,8 +128,12 @@ def lib():
         L.pantr_source_hash.restype = cp
         built, tree = L.pantr_source_hash().decode(), source_hash()
         if built != tree and not os.environ.get("PANTR_ALLOW_STALE_LIB"):
-            raise ImportError(f"{LIB_PATH} was built from other kernel sources than this tree's csrc/ "
-                              f"(library {built[:12]}..., tree {tree[:12]}...): run `make -C {PKG_DIR}`")
+            raise ImportError(f"{LIB_PATH} was built from other sources than this tree's csrc/, host/ and "
+                              f"include/ (library {built[:12]}..., tree {tree[:12]}...): run `make -C {PKG_DIR}`")
+        L.pantr_stats_size.restype = C.c_size_t
+        if L.pantr_stats_size() != STATS_DTYPE.itemsize:
+            raise ImportError(f"{LIB_PATH}: pantr_stats_t is {L.pantr_stats_size()} bytes, this binding reads "
+                              f"{STATS_DTYPE.itemsize}")
         L.pantr_params_create.argtypes = [C.POINTER(vp)]
         L.pantr_params_destroy.argtypes = [vp]
         L.pantr_params_destroy.restype = None
@@ -515,14 +519,18 @@ def version():
 
 
 def source_hash():
-    """sha256 over the kernel sources (csrc/*.h and csrc/*.hip, concatenated in name order; the Makefile
-    compiles the same digest into the library): ties a library, and a committed profile summary, to
-    the code they were made from."""
+    """sha256 over everything the library is compiled from (csrc/*.h and csrc/*.hip in name order, then
+    host/*.hpp in name order, then include/pantr_mi355x.h; the Makefile compiles the same digest into
+    the library): ties a library, and a committed profile summary, to the code they were made from."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(PKG_DIR, "csrc")
-    for name in sorted(n for n in os.listdir(d) if n.endswith((".h", ".hip"))):
-        with open(os.path.join(d, name), "rb") as f:
+    files = [os.path.join(d, n) for n in sorted(n for n in os.listdir(d) if n.endswith((".h", ".hip")))]
+    d = os.path.join(PKG_DIR, "host")
+    files += [os.path.join(d, n) for n in sorted(n for n in os.listdir(d) if n.endswith(".hpp"))]
+    files.append(os.path.join(os.path.dirname(PKG_DIR), "include", "pantr_mi355x.h"))
+    for path in files:
+        with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()
 

@@ -54,6 +54,23 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def raise_together(message, device=None):
+    """Called by EVERY rank at the same point with its local failure message (None = this rank is fine):
+    if any rank failed, all ranks raise SystemExit here - the failing ones with their own message -
+    instead of one rank leaving while its peers walk into the next collective and wait for its timeout."""
+    if max_over_ranks(1.0 if message else 0.0, device) > 0:
+        raise SystemExit(message or "another rank reported a failure (see its message); leaving with it")
+
+
+def local_failure(fn, *args):
+    """fn(*args), returning the message of the SystemExit it raises (None if it does not)."""
+    try:
+        fn(*args)
+    except SystemExit as e:
+        return str(e.code) if e.code is not None else "failed"
+    return None
+
+
 def gather_rows(local_rows, local_idx, total, device=None):
     """All-gather per-instance rows (solutions, stats columns) of a sharded batch.
 

@@ -20,6 +20,14 @@ from pantr_amd import sharding  # noqa: E402
 def main():
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    if len(sys.argv) > 2 and sys.argv[2] == "fail":
+        # rank 1 fails a local check: both ranks must leave together, before any further collective
+        def check():
+            if rank == 1:
+                raise SystemExit("worker: rank 1 failed its check")
+        sharding.raise_together(sharding.local_failure(check))
+        dist.barrier()  # never reached
+        return
     N, B = 6, 7
     rng = np.random.default_rng(5)
     x = ob.initial_state()

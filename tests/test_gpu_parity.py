@@ -298,6 +298,33 @@ def test_solve_device_refuses_pointers_it_cannot_see():
     not a fault."""
     b = pa.PantrBatch("hanging_chain", 5, 1, opts=pa.DODO_PANTR_OPTS)
     host = np.zeros(64)
-    with pytest.raises(pa.PantrError, match="not device memory"):
+    with pytest.raises(pa.PantrError, match="not device .or managed. memory"):
         b.solve_device(1, host.ctypes.data, host.ctypes.data, host.ctypes.data)
+    # a refused set is not remembered as checked: the same pointers are refused again
+    with pytest.raises(pa.PantrError, match="not device .or managed. memory"):
+        b.solve_device(1, host.ctypes.data, host.ctypes.data, host.ctypes.data)
+    b.close()
+
+
+def test_idle_row_of_the_lane_layout_stays_zero(rng):
+    """chain_model.hip.h: quad_sum adds rows 0..3 of the 16c+p lane layout and relies on the idle row 3
+    (lanes 48..63) holding exactly 0; the lanes p = 10..15 of rows 0..2 may hold anything.  The stored
+    trajectory rows ({x, v} per lane, 1 KiB per stage) show what the lanes carried through a forward
+    sweep: row 3 must be all +0.0 / -0.0 in every stage, and the active lanes must be finite."""
+    import ctypes as C
+    N, B = 22, 3
+    b = pa.PantrBatch("hanging_chain", N, B)
+    x0, u = random_states(rng, B), random_inputs(rng, B, N)
+    b.eval_psi_grad_psi(x0, u)
+    rows = np.zeros((N + 1) * 128)
+    for inst in range(B):
+        rc = pa.lib().pantr_debug_read_workspace(b._h, inst, C.c_int64(0), C.c_int64(rows.size),
+                                                 rows.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        lanes = rows.reshape(N + 1, 64, 2)
+        assert np.all(lanes[:, 48:, :] == 0.0)
+        active = np.array([16 * c + p for c in range(3) for p in range(10)])
+        assert np.all(np.isfinite(lanes[:, active, :]))
+        # the stage-0 row is the initial state itself: lane 16c+p holds component c of point p
+        assert np.array_equal(lanes[0, active, 0], x0[inst][[3 * p + c for c in range(3) for p in range(10)]])
     b.close()

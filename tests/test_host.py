@@ -7,6 +7,7 @@ import os
 import re
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -152,6 +153,18 @@ def test_two_rank_sharded_batch_gloo(tmp_path):
     assert np.array_equal(d["gathered"], d["serial"])      # sharded == unsharded, bit for bit
     assert d["tmax"] >= max(d["t0"], d["t1"]) - 1e-12 and d["world"] == 2
     assert sorted(np.concatenate([d["idx0"], d["idx1"]]).tolist()) == list(range(len(d["serial"])))
+
+
+def test_two_rank_failure_ends_both_ranks_gloo(tmp_path):
+    """A check failing on one rank ends every rank at the same point (no peer left in a collective)."""
+    script = os.path.join(ROOT, "tests", "gloo_shard_worker.py")
+    port = 31500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script, str(tmp_path / "unused.npz"), "fail"]
+    t = time.time()
+    r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and time.time() - t < 120
+    assert "rank 1 failed its check" in r.stderr and "another rank reported a failure" in r.stderr
 
 
 def test_mt19937_64_and_config5_disturbances():
