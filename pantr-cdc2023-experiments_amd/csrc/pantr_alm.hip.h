@@ -54,6 +54,7 @@ struct AlmSolveArgs {
 template <class M>
 struct ScalarALProblem {
     static constexpr int nx = M::nx, nu = M::nu, nc = M::nc;
+    static constexpr bool HAS_SPEC = false; ///< no helper wavefront (pantr_kernel.hip.h: SpecBox)
     int lane;
     const BoxData *box; ///< bounds of u (box C) and of the constraints (box D), kernel argument
     double *lds; ///< n-vectors: NUM_VEC slots of npad doubles

@@ -69,6 +69,7 @@ struct pantr_batch {
     bool al() const { return problem != ProblemId::HangingChain; }
     DeviceStats *d_stats = nullptr;
     const void *checked_ptrs[4] = {nullptr, nullptr, nullptr, nullptr}; ///< last buffer set pantr_batch_solve_device accepted
+    int num_cus = 256; ///< compute units of `device` (hipDeviceAttributeMultiprocessorCount)
     int32_t *d_order     = nullptr;
     bool have_order      = false;
     int32_t trace_instances = 0, trace_cap = 0;
@@ -263,6 +264,20 @@ int set_option(SolverOptions &o, const char *kv) {
     }
 }
 
+/// Hanging chain, method = pantr: two wavefronts per instance (pantr_solve_spec_kernel)?  `speculation=on`
+/// wherever the doubled LDS fits a CU; auto: while the batch leaves SIMDs idle - at most three
+/// instances per CU (their six wavefronts on its four SIMDs: the helpers sleep most of the time) and
+/// all of them resident at once.
+bool use_speculation(const pantr_batch *b, int32_t B) {
+    const size_t wg_lds = 2 * b->lds_bytes_pantr + WaveProblem<ChainModel>::tape_lds_bytes() + sizeof(SpecBox);
+    if (b->opts.speculation == 0 || wg_lds > 160 * 1024)
+        return false;
+    if (b->opts.speculation == 1)
+        return true;
+    const size_t per_cu = std::min<size_t>(3, (160 * 1024) / wg_lds);
+    return (size_t)B <= per_cu * (size_t)b->num_cus;
+}
+
 int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, double *d_y,
                  DeviceStats *d_stats, hipStream_t stream) {
     if (int rc = check_supported(b->opts))
@@ -325,7 +340,9 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
     if (method != 0 && b->lds_bytes + WaveProblem<ChainModel>::tape_lds_bytes() > 160 * 1024)
         return fail(PANTR_ERR_OUT_OF_RANGE, "horizon too long for method=panoc|strucpanoc: their vectors do not fit the 160 KiB LDS");
     HIP_TRY(hipEventRecord(b->ev_start, stream));
-    if (method == 0)
+    if (method == 0 && use_speculation(b, B))
+        hipLaunchKernelGGL(pantr_solve_spec_kernel<ChainModel>, dim3(B), dim3(2 * WAVE), 2 * b->lds_bytes_pantr, stream, a);
+    else if (method == 0)
         hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 0>), dim3(B), dim3(WAVE), b->lds_bytes_pantr, stream, a);
     else if (method == 1)
         hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 1>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
@@ -539,6 +556,9 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
         int khz = 0; // wall_clock64() rate
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0)
             b->tick_s = 1.0 / (1e3 * (double)khz);
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            b->num_cus = cus;
     }
     b->problem = id; b->name = name; b->device = device; b->N = horizon;
     {
@@ -593,6 +613,9 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
     } else {
         if (int rc = raise_dynamic_lds((const void *)&pantr_solve_kernel<ChainModel, 0>, b->lds_bytes_pantr))
             return rc;
+        if (2 * b->lds_bytes_pantr + static_lds + sizeof(SpecBox) <= 160 * 1024)
+            if (int rc = raise_dynamic_lds((const void *)&pantr_solve_spec_kernel<ChainModel>, 2 * b->lds_bytes_pantr))
+                return rc;
         if (b->lds_bytes + static_lds <= 160 * 1024) // else the comparators are refused at launch
             for (const void *k : {(const void *)&pantr_solve_kernel<ChainModel, 1>,
                                   (const void *)&pantr_solve_kernel<ChainModel, 2>})

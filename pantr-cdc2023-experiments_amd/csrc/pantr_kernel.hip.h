@@ -126,9 +126,32 @@ struct SolveArgs {
 };
 
 // ---------------------------------------------------------------------------------------
+// Speculation on a rejected candidate (two-wavefront workgroups; hanging chain, method = pantr)
+// ---------------------------------------------------------------------------------------
+// Six iterations in ten of the benchmark reject their trust-region candidate and continue from the
+// prox iterate xbar - whose next steps (psi(xhat(xbar)), the quadratic-upper-bound test, grad_L(xhat)
+// and the tape there) depend on nothing the trust-region subproblem computes.  With a second
+// wavefront in the workgroup, those steps run WHILE the main wavefront solves the subproblem: the
+// main wavefront posts the request before its CG loop, and on a rejection takes the result (the
+// value, the gradient, the recorded tape) instead of computing it; on an acceptance the result is
+// dropped.  Both wavefronts run the same device functions on the same inputs, so a taken result has
+// the bits the main wavefront would have produced.  Mailbox in LDS; sequence numbers written with
+// release, read with acquire semantics at workgroup scope.
+struct SpecBox {
+    int req_seq, done_seq; ///< main: requests posted; helper: requests finished
+    int cmd;               ///< SPEC_EVAL | SPEC_EXIT
+    int xh_slot;           ///< iterate vector (pb.ivec index) holding the point to evaluate: xhat of the prox iterate
+    int tape_sel;          ///< tape buffer (0 | 1) the helper records into
+    int ok;                ///< response: the quadratic upper bound held (no backtracking: the result is usable)
+    double psi_x, gradTp, pTp, L, qub_factor, L_max; ///< request: what the quadratic-upper-bound test needs
+    double psi_xh;         ///< response: psi(xhat)
+};
+enum : int { SPEC_EVAL = 1, SPEC_EXIT = 2 };
+
+// ---------------------------------------------------------------------------------------
 // Wave-cooperative problem functions of the single-shooting problem
 // ---------------------------------------------------------------------------------------
-template <class M, bool ITER_GLOBAL = false>
+template <class M, bool ITER_GLOBAL = false, bool SPEC = false>
 struct WaveProblem {
     using Lane  = typename M::Lane;
     using State = typename M::State;
@@ -147,6 +170,14 @@ struct WaveProblem {
     /// waits for them.
     mutable bool primed = false;
     double *giter = nullptr; ///< ITER_GLOBAL: this instance's NUM_ITER_VEC iterate vectors in the HBM workspace
+    // speculation (see SpecBox): nullptr / unused in one-wavefront workgroups
+    SpecBox *spec = nullptr;   ///< LDS mailbox
+    double4 *tape0 = nullptr, *tape1 = nullptr; ///< the two tape buffers; `tape` is the one the products read
+    double *X2 = nullptr, *G2 = nullptr;    ///< the helper's trajectory rows and its gradient (HBM)
+    mutable int tape_cur = 0;               ///< which of the two `tape` is
+    mutable bool spec_pending = false;      ///< a request is out whose result has been neither taken nor dropped
+    mutable bool spec_dead = false;         ///< the helper missed a deadline: no further requests
+    double spec_tick_s = 1e-8, spec_patience_s = 1.0; ///< clock period; how long the main wavefront waits for a result
 #ifdef PANTR_PHASE_TIMING
     mutable long long fwd_cycles = 0; ///< profiling build: shader cycles spent in the forward half of the products
 #endif
@@ -196,7 +227,9 @@ struct WaveProblem {
     __host__ __device__ static size_t workspace_doubles(int N) {
         const size_t npad_ = (size_t)((M::nu * N + WAVE - 1) / WAVE) * WAVE;
         return (size_t)(N + 1) * (M::TRAJ_DOUBLES + M::XT_DOUBLES) +
-               (size_t)N * (M::TAPE_D4_PER_STAGE + M::ST_D4_PER_STAGE) * 4 + NUM_ITER_VEC * npad_;
+               (size_t)N * (M::TAPE_D4_PER_STAGE + M::ST_D4_PER_STAGE) * 4 + NUM_ITER_VEC * npad_ +
+               // speculation: second tape, the helper's trajectory rows and gradient
+               (size_t)N * M::TAPE_D4_PER_STAGE * 4 + (size_t)(N + 1) * M::TRAJ_DOUBLES + npad_;
     }
     __device__ __forceinline__ void bind_workspace(double *ws, int inst) {
         X     = ws + (size_t)inst * workspace_doubles(N);
@@ -204,6 +237,114 @@ struct WaveProblem {
         tape  = reinterpret_cast<double4 *>(Xt + (size_t)(N + 1) * M::XT_DOUBLES);
         st    = tape + (size_t)N * M::TAPE_D4_PER_STAGE;
         giter = reinterpret_cast<double *>(st + (size_t)N * M::ST_D4_PER_STAGE);
+        tape0    = tape;
+        tape1    = reinterpret_cast<double4 *>(giter + (size_t)NUM_ITER_VEC * npad);
+        X2       = reinterpret_cast<double *>(tape1 + (size_t)N * M::TAPE_D4_PER_STAGE);
+        G2       = X2 + (size_t)(N + 1) * M::TRAJ_DOUBLES;
+    }
+
+    // ---- speculation: the main wavefront's side (no-ops without a mailbox) ---------------------
+    static constexpr bool HAS_SPEC = SPEC; ///< only the two-wavefront kernel instantiates the hooks
+    static_assert(!SPEC || ITER_GLOBAL, "speculation needs the iterates in HBM");
+    /// Post "evaluate psi, the bound test and grad_L + tape at ivec(xh_slot)"; the helper starts at once.
+    __device__ __forceinline__ void spec_request(int xh_slot, double psi_x, double gradTp, double pTp, double Lip,
+                                                 const KernelParams &P) const {
+        if (!spec || spec_dead)
+            return;
+        wave_sync(); // the iterate vectors the helper will read are written (and, in HBM, acknowledged)
+        if (L.l == 0) {
+            spec->cmd = SPEC_EVAL; spec->xh_slot = xh_slot; spec->tape_sel = 1 - tape_cur;
+            spec->psi_x = psi_x; spec->gradTp = gradTp; spec->pTp = pTp; spec->L = Lip;
+            spec->qub_factor = P.quadratic_upperbound_tolerance_factor; spec->L_max = P.L_max;
+            __hip_atomic_store(&spec->req_seq, spec->req_seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        spec_pending = true;
+    }
+    /// Wait until the helper has finished the posted request (bounded work: it always does).  false: it
+    /// has not within the time after which the helper itself gives up (spec_serve) - nothing of its
+    /// result is used then.
+    __device__ __forceinline__ bool spec_wait() const {
+        const int want = __hip_atomic_load(&spec->req_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(&spec->done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((double)(wall_clock64() - t0) * spec_tick_s > spec_patience_s) {
+                spec_dead = true; // no further requests (the helper ends on SPEC_EXIT or on its own clock)
+                return false;
+            }
+        }
+        return true;
+    }
+    /// The candidate was accepted (or nothing depends on the result any more): let the helper finish and forget it.
+    __device__ __forceinline__ void spec_drop() const {
+        if (spec && spec_pending)
+            spec_wait();
+        spec_pending = false;
+    }
+    /// The candidate was rejected: the value of psi(xhat) if the helper's result is usable.
+    __device__ __forceinline__ bool spec_take(double &psi_xh) const {
+        if (!spec || !spec_pending)
+            return false;
+        const bool done = spec_wait();
+        spec_pending = false;
+        const bool ok = done && uniform(spec->ok) != 0;
+        if (ok)
+            psi_xh = uniform(spec->psi_xh);
+        return ok;
+    }
+    /// The gradient and the tape that go with a taken value: grad <- the helper's, tape <- the one it recorded.
+    __device__ __forceinline__ void spec_adopt(double *grad) const {
+        wave_sync();
+        for (int j = 0; j < nj; ++j) {
+            int i = j * WAVE + L.l;
+            if (i < n)
+                grad[i] = G2[i];
+        }
+        tape_cur = 1 - tape_cur;
+        const_cast<WaveProblem *>(this)->tape = tape_cur ? tape1 : tape0;
+        primed = false;
+    }
+    __device__ __forceinline__ void spec_exit() const {
+        if (!spec)
+            return;
+        spec_drop();
+        if (L.l == 0) {
+            spec->cmd = SPEC_EXIT;
+            __hip_atomic_store(&spec->req_seq, spec->req_seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    /// The helper wavefront: serves requests until SPEC_EXIT (or until the instance's time is up: a
+    /// helper never outlives max_time by more than one request).  `this` is the helper's own problem
+    /// object: its own LDS vectors and exchange row, X = X2, the same iterate vectors and tapes.
+    __device__ __forceinline__ void spec_serve(const KernelParams &P, long long t_start) {
+        int seen = 0;
+        while (true) {
+            int r;
+            while ((r = __hip_atomic_load(&spec->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == seen) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((double)(wall_clock64() - t_start) * P.tick_s > 2.0 * P.max_time_s + 1.0)
+                    return;
+            }
+            seen = r;
+            if (uniform(spec->cmd) == SPEC_EXIT)
+                return;
+            const double *xh = ivec(uniform(spec->xh_slot));
+            tape             = uniform(spec->tape_sel) ? tape1 : tape0;
+            const double psi_xh = psi_forward<true>(xh);
+            const double psi_x = uniform(spec->psi_x), gradTp = uniform(spec->gradTp), pTp = uniform(spec->pTp),
+                         Lip = uniform(spec->L);
+            const double margin = (1.0 + fabs(psi_x)) * uniform(spec->qub_factor);
+            const bool violated = psi_xh > ((psi_x + gradTp) + (0.5 * Lip) * pTp) + margin;
+            const bool ok       = !(Lip < uniform(spec->L_max) && violated);
+            if (ok)
+                grad_reverse<true>(xh, G2);
+            wave_sync(); // G2 and the tape rows are written (and acknowledged) before the result is announced
+            if (L.l == 0) {
+                spec->psi_xh = psi_xh;
+                spec->ok     = ok ? 1 : 0;
+                __hip_atomic_store(&spec->done_seq, seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
     }
 
     // ---- the interface pantr_inner() drives (m = 0: no multipliers) ----------------------------
@@ -481,7 +622,7 @@ template <class PB>
 __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P, double tolerance,
                                                    double deadline_s, long long t_start, double *x_io,
                                                    DeviceStats &st, double *trace, int trace_cap) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1); // (two-wavefront workgroups: speculation)
     const int n = pb.n, nj = pb.nj;
     // iterate vectors (pb.ivec: HBM or LDS, the problem decides) and the CG block in LDS
     enum { S_IT0 = 0, S_IT1 = 4, S_IT2 = 8, S_Q = PB::CG_BASE + 0, S_WORK = PB::CG_BASE + 1, S_RJ = PB::CG_BASE + 2,
@@ -548,19 +689,33 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
     // pending: 0 = the initial iterate, 1 = the accepted candidate, 2 = the prox iterate.
     int which = 0;
     while (status == Busy) {
-        if (which == 1)
+        // speculation (PB::HAS_SPEC, two-wavefront workgroups): psi(xhat), the bound test, grad_L(xhat)
+        // and the tape of a rejected candidate's successor were evaluated by the helper wavefront
+        // during the CG loop; taken here, dropped if the candidate was accepted
+        bool have_spec  = false;
+        double spec_psi = 0.0;
+        if (which == 1) {
             swap_iter(curr, cand);
-        else if (which == 2)
+            if constexpr (PB::HAS_SPEC)
+                pb.spec_drop();
+        } else if (which == 2) {
             swap_iter(curr, prox);
+            if constexpr (PB::HAS_SPEC)
+                have_spec = pb.spec_take(spec_psi);
+        }
         // ---- psi(xhat) + quadratic upper bound backtracking on the new current iterate ----
         while (true) {
             // keeps the trajectory (and yhat) for grad_L(xhat)
-            PANTR_PHASE(PH_PSI_XHAT, curr.psi_xh = pb.eval_psi_xhat(XH_(curr), curr.yh));
+            if (have_spec)
+                curr.psi_xh = spec_psi; // (the helper made the test below with the same numbers: it holds)
+            else
+                PANTR_PHASE(PH_PSI_XHAT, curr.psi_xh = pb.eval_psi_xhat(XH_(curr), curr.yh));
             ++st.n_psi;
             double margin = (1.0 + fabs(curr.psi_x)) * P.quadratic_upperbound_tolerance_factor;
             bool violated = curr.psi_xh > ((curr.psi_x + curr.gradTp) + (0.5 * curr.L) * curr.pTp) + margin;
             if (!(curr.L < P.L_max && violated))
                 break;
+            have_spec = false;
             curr.gamma = curr.gamma / 2.0;
             curr.L     = curr.L * 2.0;
             pb.prox_grad_step(curr.gamma, X_(curr), G_(curr), XH_(curr), P_(curr), curr.pTp,
@@ -613,12 +768,20 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
         prox.psi_x = curr.psi_xh;
         // grad_L(xhat): xbar = xhat_k was the last point psi was evaluated at (trajectory X is still
         // in the workspace), so only the adjoint sweep runs; it records the tape at xbar
-        PANTR_PHASE(PH_GRAD_XHAT, pb.eval_grad_xhat(X_(prox), G_(prox), curr.yh));
+        if (have_spec) {
+            if constexpr (PB::HAS_SPEC)
+                pb.spec_adopt(G_(prox)); // the helper's gradient, the tape it recorded
+        } else {
+            PANTR_PHASE(PH_GRAD_XHAT, pb.eval_grad_xhat(X_(prox), G_(prox), curr.yh));
+        }
         ++st.n_grad_L;
         prox.gamma = curr.gamma;
         prox.L     = curr.L;
         pb.prox_grad_step(prox.gamma, X_(prox), G_(prox), XH_(prox), P_(prox), prox.pTp, prox.gradTp);
         ++st.n_prox_grad_step;
+        if constexpr (PB::HAS_SPEC)
+            if (!P.disable_acceleration) // should the candidate be rejected: xbar's own next steps, meanwhile
+                pb.spec_request(prox.base + 1, prox.psi_x, prox.gradTp, prox.pTp, prox.L, P);
 
         // ---- Newton trust-region direction at xbar (Steihaug-Toint CG on the inactive set) ----
         bool accept    = false;
@@ -845,6 +1008,8 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
         }
     }
 
+    if constexpr (PB::HAS_SPEC)
+        pb.spec_exit();
     // ---- results ----
     if ((status == Converged || status == Interrupted || P.always_overwrite_results) && is_finite(curr.L)) {
         pb.update_multipliers(curr.yh); // err_z = Sigma^{-1} (yhat - y), y <- yhat  (m > 0)
@@ -879,24 +1044,11 @@ __device__ __forceinline__ InnerResult inner_solve(PB &pb, const KernelParams &P
 // ---------------------------------------------------------------------------------------
 // The solve kernel for problems without general constraints (m = 0: ALM = one inner solve)
 // ---------------------------------------------------------------------------------------
-template <class M, int METHOD>
-__global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // <= 256 VGPRs: two wavefronts per SIMD (uncapped it would take 260)
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-    if (inst >= a.B)
-        return;
-    const long long t_start = wall_clock64(); // constant-rate clock, P.tick_s seconds per tick
-    const KernelParams &P   = a.prm;
-    typename M::Lane L(lane);
-
-    __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
-    __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
-    using PB = WaveProblem<M, METHOD == 0>; // PANTR: iterates in HBM; the comparators: everything in LDS
-    PB pb{L, a.prm.box, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
-    pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
-    pb.bind_workspace(a.ws, inst);
-    pb.xrow = lds + PB::LDS_SLOTS * a.npad;
+/// One instance, start to finish, on the calling wavefront (the body of both solve kernels).
+template <int METHOD, class PB, class M>
+__device__ __forceinline__ void solve_chain_instance(const SolveArgs &a, PB &pb, const typename M::Lane &, int lane,
+                                                     int inst, long long t_start, double *lds) {
+    const KernelParams &P = a.prm;
     const int n = a.n, nj = a.nj;
     for (int i = lane; i < PB::LDS_SLOTS * a.npad; i += WAVE)
         lds[i] = 0.0;
@@ -935,6 +1087,69 @@ __global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // 
         st.inner_convergence_failures = r.status == Converged ? 0 : 1;
         write_stats(a.stats + inst, st);
     }
+}
+
+template <class M, int METHOD>
+__global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // <= 256 VGPRs: two wavefronts per SIMD (uncapped it would take 260)
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if (inst >= a.B)
+        return;
+    const long long t_start = wall_clock64(); // constant-rate clock, P.tick_s seconds per tick
+    typename M::Lane L(lane);
+
+    __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
+    using PB = WaveProblem<M, METHOD == 0>; // PANTR: iterates in HBM; the comparators: everything in LDS
+    PB pb{L, a.prm.box, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
+    pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
+    pb.bind_workspace(a.ws, inst);
+    pb.xrow = lds + PB::LDS_SLOTS * a.npad;
+    solve_chain_instance<METHOD, PB, M>(a, pb, L, lane, inst, t_start, lds);
+}
+
+/// method = pantr with speculation (SpecBox): two wavefronts per instance.  Wavefront 0 is the solver
+/// of pantr_solve_kernel<M, 0>; wavefront 1 serves its requests with its own LDS vectors, exchange
+/// row and trajectory rows.  Dynamic LDS: two blocks of (LDS_SLOTS n_pad + XS_DOUBLES) doubles.
+template <class M>
+__global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs a) {
+    extern __shared__ double lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+    const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if (inst >= a.B)
+        return;
+    const long long t_start = wall_clock64();
+    typename M::Lane L(lane);
+
+    __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
+    __shared__ SpecBox box;
+    using PB = WaveProblem<M, true, true>;
+    double *my = lds + (size_t)wave * (PB::LDS_SLOTS * a.npad + PB::XS_DOUBLES);
+    PB pb{L, a.prm.box, my, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
+    pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
+    pb.bind_workspace(a.ws, inst);
+    pb.xrow = my + PB::LDS_SLOTS * a.npad;
+    pb.spec = &box;
+    pb.spec_tick_s = a.prm.tick_s;
+    if (threadIdx.x == 0) {
+        box.req_seq = 0;
+        box.done_seq = 0;
+        box.cmd = 0;
+    }
+    __syncthreads(); // the only workgroup barrier: the mailbox exists before either wavefront reads it
+    if (wave == 1) {
+        for (int i = lane; i < PB::LDS_SLOTS * a.npad; i += WAVE)
+            my[i] = 0.0;
+        wave_sync();
+        pb.X = pb.X2;
+        pb.spec_serve(a.prm, t_start);
+        return;
+    }
+    // where a SIMD holds a helper of one instance and the solver of another, the solver issues first
+    __builtin_amdgcn_s_setprio(3);
+    solve_chain_instance<0, PB, M>(a, pb, L, lane, inst, t_start, my);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -174,6 +174,11 @@ struct ALMParams {
 /// Everything one solver instance is configured by.
 struct SolverOptions {
     Method method = Method::PANTR;
+    /// `speculation=auto|on|off` (an option of this implementation, spelled like `method=`): hanging chain,
+    /// method=pantr: a second wavefront per instance evaluates the successor of a rejected candidate
+    /// during the CG loop (csrc/pantr_kernel.hip.h: SpecBox).  Same results either way; auto = on for
+    /// batches small enough to leave the GPU's SIMDs idle otherwise.  -1 auto, 0 off, 1 on.
+    int32_t speculation = -1;
     PANTRParams solver;
     NewtonTRDirectionParams dir;
     SteihaugCGParams accel;
@@ -401,6 +406,15 @@ inline SetResult set_option(SolverOptions &o, std::string_view kv, std::string &
         err = "Unknown solver '" + std::string(v) + "' (available: pantr, panoc, strucpanoc)";
         return SetResult::BadValue;
     }
+    if (kv.substr(0, 12) == "speculation=") {
+        std::string_view v = kv.substr(12);
+        if (v == "auto" || v == "on" || v == "off" || v == "1" || v == "0") {
+            o.speculation = v == "auto" ? -1 : (v == "on" || v == "1") ? 1 : 0;
+            return SetResult::Ok;
+        }
+        err = "Invalid value '" + std::string(v) + "' for 'speculation' (auto, on, off)";
+        return SetResult::BadValue;
+    }
     auto eq = kv.find('=');
     if (eq == std::string_view::npos) {
         auto dot = kv.find('.');
@@ -439,6 +453,10 @@ inline SetResult set_option(SolverOptions &o, std::string_view kv, std::string &
 inline bool get_option(const SolverOptions &o, std::string_view key, double &out) {
     if (key == "method") {
         out = static_cast<int>(o.method);
+        return true;
+    }
+    if (key == "speculation") {
+        out = o.speculation;
         return true;
     }
     FieldRef ref{};

@@ -328,3 +328,30 @@ def test_idle_row_of_the_lane_layout_stays_zero(rng):
         # the stage-0 row is the initial state itself: lane 16c+p holds component c of point p
         assert np.array_equal(lanes[0, active, 0], x0[inst][[3 * p + c for c in range(3) for p in range(10)]])
     b.close()
+
+
+def test_speculation_changes_nothing_but_time():
+    """`speculation=on|off` (two wavefronts per instance: the successor of a rejected candidate is
+    evaluated by the second one during the CG loop) - same solutions, same counters, bit for bit; the
+    batch has accepted and rejected candidates, and quadratic-upper-bound backtracks the helper must
+    decline."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_hanging_chain_N60_warm300.npz"))
+    idx = np.arange(0, 300, 25)
+    x0 = np.vstack([d["x0"][idx], d["x0"][idx]])
+    u0 = np.vstack([d["guess"][idx], np.zeros_like(d["guess"][idx])])
+    res = {}
+    for mode in ("off", "on", "auto"):
+        b = pa.PantrBatch("hanging_chain", 60, len(x0), opts=tuple(pa.DODO_PANTR_OPTS) + (f"speculation={mode}",))
+        res[mode] = b.solve(x0, u0)
+        b.close()
+    u_off, st_off = res["off"]
+    assert np.all(st_off["status"] == 1) and st_off["rejected"].sum() > 0 and st_off["accepted"].sum() > 0
+    for mode in ("on", "auto"):
+        u, st = res[mode]
+        assert np.array_equal(u, u_off)
+        for k in ("status", "iterations", "cg_iterations", "accepted", "rejected", "qub_backtracks", "n_psi",
+                  "n_psi_grad_psi", "n_grad_L", "n_hess_psi_prod", "n_prox_grad_step", "eps", "final_psi", "final_fbe",
+                  "final_gamma", "final_radius"):
+            assert np.array_equal(st[k], st_off[k]), (mode, k)
+    with pytest.raises(pa.PantrError, match="speculation"):
+        pa.PantrBatch("hanging_chain", 5, 1, opts=("speculation=maybe",))
