@@ -268,8 +268,14 @@ int set_option(SolverOptions &o, const char *kv) {
 /// wherever the doubled LDS fits a CU; auto: while the batch leaves SIMDs idle - at most three
 /// instances per CU (their six wavefronts on its four SIMDs: the helpers sleep most of the time) and
 /// all of them resident at once.
+/// LDS of a workgroup of the two-wavefront kernel: dynamic (both wavefronts' vectors and exchange rows),
+/// and with the static part (four landing buffers, the mailbox).
+size_t spec_lds_bytes(const pantr_batch &b) { return spec_lds_doubles<ChainModel>(b.npad) * sizeof(double); }
+size_t spec_lds_total(const pantr_batch &b) {
+    return spec_lds_bytes(b) + 2 * WaveProblem<ChainModel>::tape_lds_bytes() + sizeof(SpecBox);
+}
 bool use_speculation(const pantr_batch *b, int32_t B) {
-    const size_t wg_lds = 2 * b->lds_bytes_pantr + WaveProblem<ChainModel>::tape_lds_bytes() + sizeof(SpecBox);
+    const size_t wg_lds = spec_lds_total(*b);
     if (b->opts.speculation == 0 || wg_lds > 160 * 1024)
         return false;
     if (b->opts.speculation == 1)
@@ -341,7 +347,7 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
         return fail(PANTR_ERR_OUT_OF_RANGE, "horizon too long for method=panoc|strucpanoc: their vectors do not fit the 160 KiB LDS");
     HIP_TRY(hipEventRecord(b->ev_start, stream));
     if (method == 0 && use_speculation(b, B))
-        hipLaunchKernelGGL(pantr_solve_spec_kernel<ChainModel>, dim3(B), dim3(2 * WAVE), 2 * b->lds_bytes_pantr, stream, a);
+        hipLaunchKernelGGL(pantr_solve_spec_kernel<ChainModel>, dim3(B), dim3(2 * WAVE), spec_lds_bytes(*b), stream, a);
     else if (method == 0)
         hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 0>), dim3(B), dim3(WAVE), b->lds_bytes_pantr, stream, a);
     else if (method == 1)
@@ -613,8 +619,8 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
     } else {
         if (int rc = raise_dynamic_lds((const void *)&pantr_solve_kernel<ChainModel, 0>, b->lds_bytes_pantr))
             return rc;
-        if (2 * b->lds_bytes_pantr + static_lds + sizeof(SpecBox) <= 160 * 1024)
-            if (int rc = raise_dynamic_lds((const void *)&pantr_solve_spec_kernel<ChainModel>, 2 * b->lds_bytes_pantr))
+        if (spec_lds_total(*b) <= 160 * 1024)
+            if (int rc = raise_dynamic_lds((const void *)&pantr_solve_spec_kernel<ChainModel>, spec_lds_bytes(*b)))
                 return rc;
         if (b->lds_bytes + static_lds <= 160 * 1024) // else the comparators are refused at launch
             for (const void *k : {(const void *)&pantr_solve_kernel<ChainModel, 1>,

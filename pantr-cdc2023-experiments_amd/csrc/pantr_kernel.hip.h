@@ -145,8 +145,14 @@ struct SpecBox {
     int ok;                ///< response: the quadratic upper bound held (no backtracking: the result is usable)
     double psi_x, gradTp, pTp, L, qub_factor, L_max; ///< request: what the quadratic-upper-bound test needs
     double psi_xh;         ///< response: psi(xhat)
+    // SPEC_MODEL: the model value m(p) = p'r_J + 1/2 p'H_JJ p of the finished CG's step - the one product
+    // of an iteration nothing waits for until the ratio test: the main wavefront evaluates the
+    // candidate meanwhile
+    int p_off, rj_off;     ///< request: offsets (doubles, from the workgroup's dynamic LDS) of p and r_J
+    unsigned mask[WAVE];   ///< request: the inactive set, one bit per owned element and lane
+    double mval;           ///< response
 };
-enum : int { SPEC_EVAL = 1, SPEC_EXIT = 2 };
+enum : int { SPEC_EVAL = 1, SPEC_EXIT = 2, SPEC_MODEL = 3 };
 
 // ---------------------------------------------------------------------------------------
 // Wave-cooperative problem functions of the single-shooting problem
@@ -172,8 +178,12 @@ struct WaveProblem {
     double *giter = nullptr; ///< ITER_GLOBAL: this instance's NUM_ITER_VEC iterate vectors in the HBM workspace
     // speculation (see SpecBox): nullptr / unused in one-wavefront workgroups
     SpecBox *spec = nullptr;   ///< LDS mailbox
-    double4 *tape0 = nullptr, *tape1 = nullptr; ///< the two tape buffers; `tape` is the one the products read
-    double *X2 = nullptr, *G2 = nullptr;    ///< the helper's trajectory rows and its gradient (HBM)
+    // (the two tape buffers and the helper's rows are addressed from the instance's workspace base when
+    // they are needed - tape_buf(), helper_*() below - rather than held in registers through the solve)
+    double *wg_lds = nullptr;               ///< base of the workgroup's dynamic LDS (both wavefronts' vectors)
+    double *ws0    = nullptr;               ///< base of this instance's HBM workspace
+    mutable bool spec_stashed = false, spec_stash_ok = false; ///< result of a finished SPEC_EVAL kept while the mailbox
+    mutable double spec_stash_psi = 0.0;                      ///< carries a SPEC_MODEL request
     mutable int tape_cur = 0;               ///< which of the two `tape` is
     mutable bool spec_pending = false;      ///< a request is out whose result has been neither taken nor dropped
     mutable bool spec_dead = false;         ///< the helper missed a deadline: no further requests
@@ -195,6 +205,9 @@ struct WaveProblem {
     /// by the next stage's read of its prefetched state).  The slot of the CG residual r: dead outside
     /// the CG loop like z.
     static constexpr int S_GSTAGE  = CG_BASE + 4;
+    /// LDS vector slots of a helper wavefront (SpecBox): slots 0..S_GSTAGE, of which it uses the product
+    /// output (CG_BASE + 1) and the two staging slots
+    static constexpr int HELPER_SLOTS = S_GSTAGE + 1;
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
     /// Exchange row of the component gather: XS_DOUBLES doubles of dynamic LDS behind the kernel's vectors.
     static constexpr int XS_DOUBLES = 32;
@@ -228,19 +241,32 @@ struct WaveProblem {
         const size_t npad_ = (size_t)((M::nu * N + WAVE - 1) / WAVE) * WAVE;
         return (size_t)(N + 1) * (M::TRAJ_DOUBLES + M::XT_DOUBLES) +
                (size_t)N * (M::TAPE_D4_PER_STAGE + M::ST_D4_PER_STAGE) * 4 + NUM_ITER_VEC * npad_ +
-               // speculation: second tape, the helper's trajectory rows and gradient
-               (size_t)N * M::TAPE_D4_PER_STAGE * 4 + (size_t)(N + 1) * M::TRAJ_DOUBLES + npad_;
+               // speculation: second tape, the helper's trajectory rows, gradient, tangent rows and tangent tape
+               (size_t)N * M::TAPE_D4_PER_STAGE * 4 + (size_t)(N + 1) * M::TRAJ_DOUBLES + npad_ +
+               (size_t)(N + 1) * M::XT_DOUBLES + (size_t)N * M::ST_D4_PER_STAGE * 4;
     }
     __device__ __forceinline__ void bind_workspace(double *ws, int inst) {
         X     = ws + (size_t)inst * workspace_doubles(N);
+        ws0   = X;
         Xt    = X + (size_t)(N + 1) * M::TRAJ_DOUBLES;
         tape  = reinterpret_cast<double4 *>(Xt + (size_t)(N + 1) * M::XT_DOUBLES);
         st    = tape + (size_t)N * M::TAPE_D4_PER_STAGE;
         giter = reinterpret_cast<double *>(st + (size_t)N * M::ST_D4_PER_STAGE);
-        tape0    = tape;
-        tape1    = reinterpret_cast<double4 *>(giter + (size_t)NUM_ITER_VEC * npad);
-        X2       = reinterpret_cast<double *>(tape1 + (size_t)N * M::TAPE_D4_PER_STAGE);
-        G2       = X2 + (size_t)(N + 1) * M::TRAJ_DOUBLES;
+    }
+    /// Tape buffer 0 | 1 (`tape` is one of them).
+    __device__ __forceinline__ double4 *tape_buf(int which) const {
+        double *t0 = ws0 + (size_t)(N + 1) * (M::TRAJ_DOUBLES + M::XT_DOUBLES);
+        double *t1 = t0 + (size_t)N * (M::TAPE_D4_PER_STAGE + M::ST_D4_PER_STAGE) * 4 + (size_t)NUM_ITER_VEC * npad;
+        return reinterpret_cast<double4 *>(which ? t1 : t0);
+    }
+    /// The helper's trajectory rows, gradient, tangent rows and tangent tape (behind tape buffer 1).
+    __device__ __forceinline__ double *helper_X() const {
+        return reinterpret_cast<double *>(tape_buf(1) + (size_t)N * M::TAPE_D4_PER_STAGE);
+    }
+    __device__ __forceinline__ double *helper_G() const { return helper_X() + (size_t)(N + 1) * M::TRAJ_DOUBLES; }
+    __device__ __forceinline__ double *helper_Xt() const { return helper_G() + npad; }
+    __device__ __forceinline__ double4 *helper_st() const {
+        return reinterpret_cast<double4 *>(helper_Xt() + (size_t)(N + 1) * M::XT_DOUBLES);
     }
 
     // ---- speculation: the main wavefront's side (no-ops without a mailbox) ---------------------
@@ -279,10 +305,15 @@ struct WaveProblem {
     __device__ __forceinline__ void spec_drop() const {
         if (spec && spec_pending)
             spec_wait();
-        spec_pending = false;
+        spec_pending = spec_stashed = false;
     }
     /// The candidate was rejected: the value of psi(xhat) if the helper's result is usable.
     __device__ __forceinline__ bool spec_take(double &psi_xh) const {
+        if (spec_stashed) { // taken out of the mailbox when the SPEC_MODEL request went in
+            spec_stashed = false;
+            psi_xh       = spec_stash_psi;
+            return spec_stash_ok;
+        }
         if (!spec || !spec_pending)
             return false;
         const bool done = spec_wait();
@@ -292,16 +323,48 @@ struct WaveProblem {
             psi_xh = uniform(spec->psi_xh);
         return ok;
     }
+    /// Ask the helper for the model value of p (an LDS vector of this wavefront) with r_J and the
+    /// inactive set `mask`.  false: no helper, or it is still busy with the SPEC_EVAL request (a short
+    /// CG loop) - the caller evaluates the product itself.
+    __device__ __forceinline__ bool spec_post_model(const double *p, const double *rJ, unsigned mask) const {
+        if (!spec || spec_dead)
+            return false;
+        if (spec_pending) {
+            const int want = __hip_atomic_load(&spec->req_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__hip_atomic_load(&spec->done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want)
+                return false;
+            spec_stash_ok  = uniform(spec->ok) != 0;
+            spec_stash_psi = uniform(spec->psi_xh);
+            spec_stashed   = true;
+            spec_pending   = false;
+        }
+        spec->mask[L.l] = mask;
+        wave_sync(); // p, r_J and the mask are written
+        if (L.l == 0) {
+            spec->cmd = SPEC_MODEL; spec->tape_sel = tape_cur;
+            spec->p_off = (int)(p - wg_lds); spec->rj_off = (int)(rJ - wg_lds);
+            __hip_atomic_store(&spec->req_seq, spec->req_seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return true;
+    }
+    /// The model value asked for; false if the helper did not deliver (the caller evaluates it itself).
+    __device__ __forceinline__ bool spec_take_model(double &mval) const {
+        if (!spec_wait())
+            return false;
+        mval = uniform(spec->mval);
+        return true;
+    }
     /// The gradient and the tape that go with a taken value: grad <- the helper's, tape <- the one it recorded.
     __device__ __forceinline__ void spec_adopt(double *grad) const {
         wave_sync();
+        const double *Gh = helper_G();
         for (int j = 0; j < nj; ++j) {
             int i = j * WAVE + L.l;
             if (i < n)
-                grad[i] = G2[i];
+                grad[i] = Gh[i];
         }
         tape_cur = 1 - tape_cur;
-        const_cast<WaveProblem *>(this)->tape = tape_cur ? tape1 : tape0;
+        const_cast<WaveProblem *>(this)->tape = tape_buf(tape_cur);
         primed = false;
     }
     __device__ __forceinline__ void spec_exit() const {
@@ -315,7 +378,7 @@ struct WaveProblem {
     }
     /// The helper wavefront: serves requests until SPEC_EXIT (or until the instance's time is up: a
     /// helper never outlives max_time by more than one request).  `this` is the helper's own problem
-    /// object: its own LDS vectors and exchange row, X = X2, the same iterate vectors and tapes.
+    /// object: its own LDS vectors and exchange row, X = helper_X(), the same iterate vectors and tapes.
     __device__ __forceinline__ void spec_serve(const KernelParams &P, long long t_start) {
         int seen = 0;
         while (true) {
@@ -326,10 +389,26 @@ struct WaveProblem {
                     return;
             }
             seen = r;
-            if (uniform(spec->cmd) == SPEC_EXIT)
+            const int cmd = uniform(spec->cmd);
+            if (cmd == SPEC_EXIT)
                 return;
+            if (cmd == SPEC_MODEL) {
+                const double *p = wg_lds + uniform(spec->p_off), *rJ = wg_lds + uniform(spec->rj_off);
+                const unsigned mask = spec->mask[L.l];
+                double *Hp = vec(CG_BASE + 1);
+                tape   = tape_buf(uniform(spec->tape_sel));
+                primed = false;
+                hess_prod_tape(p, Hp);
+                wait_vmem(); // the rows the product left in flight for a successor (there is none here)
+                const double mval = dot(p, rJ) + 0.5 * dot_masked(p, Hp, mask);
+                if (L.l == 0) {
+                    spec->mval = mval;
+                    __hip_atomic_store(&spec->done_seq, seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                continue;
+            }
             const double *xh = ivec(uniform(spec->xh_slot));
-            tape             = uniform(spec->tape_sel) ? tape1 : tape0;
+            tape             = tape_buf(uniform(spec->tape_sel));
             const double psi_xh = psi_forward<true>(xh);
             const double psi_x = uniform(spec->psi_x), gradTp = uniform(spec->gradTp), pTp = uniform(spec->pTp),
                          Lip = uniform(spec->L);
@@ -337,8 +416,8 @@ struct WaveProblem {
             const bool violated = psi_xh > ((psi_x + gradTp) + (0.5 * Lip) * pTp) + margin;
             const bool ok       = !(Lip < uniform(spec->L_max) && violated);
             if (ok)
-                grad_reverse<true>(xh, G2);
-            wave_sync(); // G2 and the tape rows are written (and acknowledged) before the result is announced
+                grad_reverse<true>(xh, helper_G());
+            wave_sync(); // the gradient and the tape rows are written (and acknowledged) before the result is announced
             if (L.l == 0) {
                 spec->psi_xh = psi_xh;
                 spec->ok     = ok ? 1 : 0;
@@ -784,7 +863,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                 pb.spec_request(prox.base + 1, prox.psi_x, prox.gradTp, prox.pTp, prox.L, P);
 
         // ---- Newton trust-region direction at xbar (Steihaug-Toint CG on the inactive set) ----
-        bool accept    = false;
+        bool accept    = false, model_deferred = false;
         double rho     = __builtin_nan(""), q_model = __builtin_nan("");
         int nJ = 0, cg_its = 0;
         if (!P.disable_acceleration) {
@@ -807,6 +886,15 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
             // iterations in ten of the hanging-chain benchmark): the product is exactly zero
             const bool skip_kterm = __builtin_amdgcn_readfirstlane(__all(qK_zero ? 1 : 0)) != 0;
             enum { KTERM, CGSTART, CG, EVAL_A, EVAL_B, EVAL_STEP };
+            // PB::HAS_SPEC: the model value of the CG's step is the one product of an iteration whose
+            // result nothing needs before the ratio test - the helper wavefront evaluates it
+            // (spec_post_model) while this one goes on to the candidate; `model_deferred`: q_model is
+            // still on its way
+            auto defer_model = [&]() {
+                if constexpr (PB::HAS_SPEC)
+                    return pb.spec_post_model(step, rJ, mask);
+                return false;
+            };
             int state = (P.hessian_vec_factor != 0 && nJ < n && !skip_kterm) ? KTERM : CGSTART;
             const double *vin = q;
             double r_sq = 0, tolerance = 0, qa = 0;
@@ -912,12 +1000,20 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                                 if (i < n)
                                     step[i] = z[i] + tb * d[i];
                             }
+                            if ((model_deferred = defer_model())) {
+                                ++st.n_hess_psi_prod;
+                                break;
+                            }
                             state = EVAL_STEP;
                             vin   = step;
                         }
                         continue;
                     }
                     if (__builtin_sqrt(r_next_sq) < tolerance || cg_i > cg_max) {
+                        if ((model_deferred = defer_model())) {
+                            ++st.n_hess_psi_prod;
+                            break;
+                        }
                         state = EVAL_STEP;
                         vin   = step;
                         continue;
@@ -967,18 +1063,34 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                 }
             }
             bool q_finite = __builtin_amdgcn_readfirstlane(__all(fin ? 1 : 0)) != 0;
-            if (q_finite && q_model < 0) {
+            // the model value, if it is still with the helper (the candidate below is then evaluated on
+            // the expectation q_model < 0 and discarded - iterate `cand` is scratch - should it not hold)
+            auto settle_model = [&]() {
+                if constexpr (PB::HAS_SPEC) {
+                    if (model_deferred && !pb.spec_take_model(q_model)) { // not delivered: evaluate it here
+                        pb.hess_prod(X_(prox), step, work);
+                        q_model = pb.dot(step, rJ) + 0.5 * pb.dot_masked(step, work, mask);
+                    }
+                }
+                model_deferred = false;
+            };
+            if (!q_finite)
+                settle_model();
+            if (q_finite && (model_deferred || q_model < 0)) {
                 for (int j = 0; j < nj; ++j) {
                     int i = j * WAVE + lane;
                     if (i < n)
                         X_(cand)[i] = X_(prox)[i] + q[i];
                 }
                 PANTR_PHASE(PH_PSI_GRAD, cand.psi_x = pb.eval_psi_grad(X_(cand), G_(cand)));
-                ++st.n_psi_grad_psi;
                 cand.gamma = prox.gamma;
                 cand.L     = prox.L;
                 pb.prox_grad_step(cand.gamma, X_(cand), G_(cand), XH_(cand), P_(cand), cand.pTp,
                                   cand.gradTp);
+                settle_model();
+            }
+            if (q_finite && q_model < 0) {
+                ++st.n_psi_grad_psi;
                 ++st.n_prox_grad_step;
                 double phi_k = prox.fbe(), phi_n = cand.fbe();
                 double tr_eps = (1.0 + fabs(phi_k)) * P.TR_tolerance_factor;
@@ -1110,8 +1222,14 @@ __global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // 
 }
 
 /// method = pantr with speculation (SpecBox): two wavefronts per instance.  Wavefront 0 is the solver
-/// of pantr_solve_kernel<M, 0>; wavefront 1 serves its requests with its own LDS vectors, exchange
-/// row and trajectory rows.  Dynamic LDS: two blocks of (LDS_SLOTS n_pad + XS_DOUBLES) doubles.
+/// of pantr_solve_kernel<M, 0>; wavefront 1 serves its requests with its own LDS vectors (slots 0..4:
+/// it uses the product output, the sweeps' staging copy and the gradient staging), exchange row,
+/// landing buffers, trajectory and tangent rows.  Dynamic LDS: spec_lds_doubles(npad) doubles.
+template <class M>
+__host__ __device__ constexpr size_t spec_lds_doubles(size_t npad) {
+    using PB = WaveProblem<M, true, true>;
+    return (PB::LDS_SLOTS + PB::HELPER_SLOTS) * npad + 2 * PB::XS_DOUBLES;
+}
 template <class M>
 __global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs a) {
     extern __shared__ double lds[];
@@ -1124,14 +1242,18 @@ __global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs
 
     __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
     __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char helper_buf0[M::LDS_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char helper_buf1[M::LDS_STAGE_BYTES];
     __shared__ SpecBox box;
     using PB = WaveProblem<M, true, true>;
-    double *my = lds + (size_t)wave * (PB::LDS_SLOTS * a.npad + PB::XS_DOUBLES);
-    PB pb{L, a.prm.box, my, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
+    double *my = lds + (wave ? PB::LDS_SLOTS * a.npad + PB::XS_DOUBLES : 0);
+    PB pb{L, a.prm.box, my, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr,
+          wave ? helper_buf0 : tape_buf0, wave ? helper_buf1 : tape_buf1};
     pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
-    pb.xrow = my + PB::LDS_SLOTS * a.npad;
-    pb.spec = &box;
+    pb.xrow   = my + (wave ? PB::HELPER_SLOTS : PB::LDS_SLOTS) * a.npad;
+    pb.wg_lds = lds;
+    pb.spec   = &box;
     pb.spec_tick_s = a.prm.tick_s;
     if (threadIdx.x == 0) {
         box.req_seq = 0;
@@ -1140,10 +1262,12 @@ __global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs
     }
     __syncthreads(); // the only workgroup barrier: the mailbox exists before either wavefront reads it
     if (wave == 1) {
-        for (int i = lane; i < PB::LDS_SLOTS * a.npad; i += WAVE)
+        for (int i = lane; i < PB::HELPER_SLOTS * a.npad; i += WAVE)
             my[i] = 0.0;
         wave_sync();
-        pb.X = pb.X2;
+        pb.X  = pb.helper_X();
+        pb.Xt = pb.helper_Xt();
+        pb.st = pb.helper_st();
         pb.spec_serve(a.prm, t_start);
         return;
     }
