@@ -44,7 +44,7 @@ METRIC = "MPC-steps solved/sec, hanging_chain N=60 cold+warm, 1/2/4/8 MI355X"
 HORIZON = 60
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FIXTURE = os.path.join(ROOT, "tests", "golden", "mpc_hanging_chain_N60_warm300.npz")
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 # PMC summary of the headline command (scripts/profile.sh + scripts/summarize_profiles.py)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_summary.json")
 # published mean solver time per MPC step, alpaqa PANTR, unstated CPU, 1 thread
@@ -67,7 +67,7 @@ def measured_traffic(instances):
         if d.get("csrc_sha256") != src["csrc_sha256"]:
             src["refused"] = "the kernels changed since the PMC passes were taken"
             return None, src
-        if int(d["pmc_per_launch"]["SQ_WAVES"]) != instances:
+        if int(d["pmc_per_launch"]["SQ_WAVES"]) != instances * int(d.get("wavefronts_per_instance", 1)):
             src["refused"] = "the PMC passes were taken on another batch size"
             return None, src
         if "valu_issue" in d:  # what binds instead of HBM: VALU issue of lone wavefronts (same PMC passes)
@@ -111,6 +111,10 @@ class Resident:
 
     def kernel_ms(self):
         return self.batch.last_kernel_ms() if self.B else 0.0
+
+    def kernel_name(self):
+        """The device kernel this batch's solve launches (the library decides: method, speculation, batch size)."""
+        return self.batch.kernel_name(max(self.B, 1))
 
     def stats(self):
         raw = self.stats_t.cpu().numpy().tobytes()
@@ -243,7 +247,7 @@ def extra_configs(torch, pa, dev, local_rank, cores, peak_measured, with_cpu):
     from pantr_amd import workloads
     out = {}
 
-    def one(name, ws, kernel, description, cpu_sample=None):
+    def one(name, ws, description, cpu_sample=None):
         rs = [Resident(w, torch, pa, dev, local_rank) for w in ws]
         wall, kms = time_group(rs, torch)
         for r in rs:
@@ -252,7 +256,7 @@ def extra_configs(torch, pa, dev, local_rank, cores, peak_measured, with_cpu):
         dom = int(np.argmax(kms))                      # the launch that decides the wall time
         cfg = {"workload": description, "instances": total, "launches_per_pass": len(rs),
                "value": total / wall, "unit": "steps/s", "ms_per_pass": wall * 1e3,
-               "roofline": roofline_obj(rs[dom].alg_bytes(), kms[dom], kernel, peak_measured),
+               "roofline": roofline_obj(rs[dom].alg_bytes(), kms[dom], rs[dom].kernel_name(), peak_measured),
                "all_launches": {"algorithmic_bytes": int(sum(r.alg_bytes() for r in rs)),
                                 "achieved_GBps": sum(r.alg_bytes() for r in rs) / wall / 1e9,
                                 "kernel_ms": kms}}
@@ -272,21 +276,18 @@ def extra_configs(torch, pa, dev, local_rank, cores, peak_measured, with_cpu):
 
     # configs[3]: six horizons x {cold, warm} x 60 steps = 720 instances, one launch per horizon, concurrent
     one("sweep", [workloads.closed_loop_batch("hanging_chain", N, device=local_rank) for N in workloads.HORIZONS],
-        "pantr_solve_kernel<ChainModel, 0>",
         "BASELINE.json configs[3]: hanging_chain horizons 10..60 x {warm, cold} x 60 MPC time steps = 720 replay "
         "instances, one launch per horizon on six concurrent HIP streams (dodo.py:69-95)")
     # configs[2]
     one("realistic_quadcopter", [workloads.closed_loop_batch("realistic_quadcopter", 60, device=local_rank)],
-        "pantr_alm_kernel<QuadModelT<true>, 0>",
         "BASELINE.json configs[2]: realistic_quadcopter N=60 (n=240, m=244), all 60 warm + 60 cold time steps as one "
         "batch of 120 ALM solves (dodo.py:96-105)")
     # configs[0]: the reference's CPU-runnable case, here as the replay of its one warm run
     one("quadcopter_N12", [workloads.closed_loop_batch("quadcopter", 12, starts=(True,), device=local_rank)],
-        "pantr_alm_kernel<QuadModelT<false>, 0>",
         "BASELINE.json configs[0]: quadcopter N=12 (n=48, m=52), the 60 time steps of one warm-started MPC run "
         "(num_sim=60 warm=true num_dist=0 solver.max_iter=250) as one batch")
     # configs[4] on ONE GPU: all 1024
-    one("stress_N120", [workloads.stress_batch(1024, device=local_rank)], "pantr_solve_kernel<ChainModel, 0>",
+    one("stress_N120", [workloads.stress_batch(1024, device=local_rank)],
         "BASELINE.json configs[4] on one GPU: hanging_chain N=120 (n=360), 1024 synthetic cold instances in one launch",
         cpu_sample=np.arange(0, 1024, 8))
     return out
@@ -366,7 +367,7 @@ def strong_mode(args, torch, pa, dev, local_rank, rank, world, distributed, rehe
             "config": {"workload": desc, "instances": len(where), "instances_rank0": int(len(mine)),
                        "partition": "longest-processing-time-first by (horizon, start) cost (pantr_amd/sharding.py)",
                        "gathered_equals_unsharded": same, "rehearsal_shared_gpu": rehearsal},
-            "roofline": dict(roofline_obj(rs[dom].alg_bytes(), kms[dom], "pantr_solve_kernel<ChainModel, 0>"),
+            "roofline": dict(roofline_obj(rs[dom].alg_bytes(), kms[dom], rs[dom].kernel_name()),
                              rank0_all_launches_algorithmic_bytes=int(alg), rank0_kernel_ms=kms),
         }), flush=True)
     for r in rs:
@@ -443,6 +444,8 @@ def main():
                 raise SystemExit(f"bench.py: the device closed loop deviates from tests/golden by {fixture_dev:.3e}")
     B, n = w["u0"].shape
     S = max(1, args.streams)
+    if S > 1:  # several passes in flight fill the SIMDs by themselves: one wavefront per instance
+        w = dict(w, opts=tuple(w["opts"]) + ("speculation=off",))
     rs = [Resident(w, torch, pa, dev, local_rank) for _ in range(S)]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
 
@@ -497,7 +500,7 @@ def main():
                                        "another machine and another code base: not a baseline for this metric",
                 "parity": "unpinned (oracle = this project's restatement of un-vendored alpaqa)",
             },
-            "roofline": roofline_obj(alg_bytes, k_ms, "pantr_solve_kernel<ChainModel, 0>", peak_measured, traffic,
+            "roofline": roofline_obj(alg_bytes, k_ms, rs[0].kernel_name(), peak_measured, traffic,
                                      traffic_src),
         }
         if extras:
@@ -509,13 +512,15 @@ def main():
                 r.check(key)
                 line[key] = {"value": r.B / wall, "unit": "steps/s", "instances": r.B, "ms_per_pass": wall * 1e3,
                              "mean_iterations": float(r.stats()["iterations"].mean()),
-                             "roofline": roofline_obj(r.alg_bytes(), kms[0], "pantr_solve_kernel<ChainModel, 0>",
+                             "roofline": roofline_obj(r.alg_bytes(), kms[0], r.kernel_name(),
                                                       peak_measured)}
                 r.close()
             # throughput mode: four independent passes in flight, every stream issuing its next pass as soon
             # as its previous one is queued (one pass fills 600 of the chip's wavefront slots and ends on
             # its slowest instance; overlapping passes fill the tail)
-            four = rs + [Resident(w, torch, pa, dev, local_rank) for _ in range(4 - len(rs))]
+            # (speculation off: its second wavefront per instance uses SIMDs that four concurrent passes fill anyway)
+            w_thr = dict(w, opts=tuple(w["opts"]) + ("speculation=off",))
+            four = [Resident(w_thr, torch, pa, dev, local_rank) for _ in range(4)]
             four_streams = [torch.cuda.Stream(dev) for _ in four]
             rounds = 3
             for r, st4 in zip(four, four_streams):
@@ -532,9 +537,11 @@ def main():
             line["throughput_mode"] = {"passes_in_flight": 4, "passes": 4 * rounds, "value": 4 * rounds * B / wall,
                                        "unit": "steps/s", "ms_total": wall * 1e3,
                                        "last_kernel_ms": [r.kernel_ms() for r in four],
+                                       "kernel": four[0].kernel_name(),
                                        "note": "same batch, four independent solver handles on four HIP streams, each "
-                                               "running its passes back to back; the headline stays one pass at a time"}
-            for r in four[len(rs):]:
+                                               "running its passes back to back (speculation=off: one wavefront per "
+                                               "instance); the headline stays one pass at a time"}
+            for r in four:
                 r.close()
             with_cpu = not args.no_cpu_baseline
             if with_cpu:

@@ -874,14 +874,33 @@ int pantr_batch_get_param(const pantr_batch_t *b, const char *key, double *value
 int pantr_batch_footprint(const pantr_batch_t *b, int64_t *lds_bytes, int64_t *ws_bytes_per_instance) {
     if (!b)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
-    if (lds_bytes) { // of the solve kernel the handle's current method selects
+    if (lds_bytes) { // of the solve kernel the handle's current method selects, for a batch of its maximum size
         const bool pantr_chain = !b->al() && b->opts.method == host::Method::PANTR;
         const bool cmp_scalar = b->al() && b->opts.method != host::Method::PANTR;
-        *lds_bytes = (int64_t)((pantr_chain ? b->lds_bytes_pantr : cmp_scalar ? b->lds_bytes_cmp : b->lds_bytes) +
-                               (b->al() ? 0 : WaveProblem<ChainModel>::tape_lds_bytes()));
+        if (pantr_chain && use_speculation(b, b->maxB))
+            *lds_bytes = (int64_t)spec_lds_total(*b);
+        else
+            *lds_bytes = (int64_t)((pantr_chain ? b->lds_bytes_pantr : cmp_scalar ? b->lds_bytes_cmp : b->lds_bytes) +
+                                   (b->al() ? 0 : WaveProblem<ChainModel>::tape_lds_bytes()));
     }
     if (ws_bytes_per_instance) *ws_bytes_per_instance = (int64_t)(b->ws_per_instance * sizeof(double));
     return PANTR_OK;
+}
+
+const char *pantr_batch_kernel_name(const pantr_batch_t *b, int32_t B) {
+    if (!b)
+        return "";
+    const int method = static_cast<int>(b->opts.method);
+    if (b->al()) {
+        const bool realistic = b->problem == ProblemId::RealisticQuadcopter;
+        static const char *names[2][3] = {
+            {"pantr_alm_kernel<QuadModelT<false>, 0>", "pantr_alm_kernel<QuadModelT<false>, 1>", "pantr_alm_kernel<QuadModelT<false>, 2>"},
+            {"pantr_alm_kernel<QuadModelT<true>, 0>", "pantr_alm_kernel<QuadModelT<true>, 1>", "pantr_alm_kernel<QuadModelT<true>, 2>"}};
+        return names[realistic ? 1 : 0][method];
+    }
+    if (method == 0)
+        return use_speculation(b, B) ? "pantr_solve_spec_kernel<ChainModel>" : "pantr_solve_kernel<ChainModel, 0>";
+    return method == 1 ? "pantr_solve_kernel<ChainModel, 1>" : "pantr_solve_kernel<ChainModel, 2>";
 }
 
 // ---- the hot path ------------------------------------------------------------------------

@@ -94,6 +94,7 @@ EXPORTS = (
     "pantr_batch_get_penalty_alm_split", "pantr_problem_data_load", "pantr_problem_data_destroy",
     "pantr_problem_data_get", "pantr_problem_dims", "pantr_problem_defaults", "pantr_batch_eval_g",
     "pantr_batch_mpc_record", "pantr_device_copy_bandwidth", "pantr_source_hash", "pantr_stats_size",
+    "pantr_batch_kernel_name",
 )
 
 
@@ -344,6 +345,12 @@ class PantrBatch:
         v = _i32()
         _check(lib().pantr_batch_get_penalty_alm_split(self._h, C.byref(v)))
         return v.value
+
+    def kernel_name(self, B=None):
+        """Device kernel a solve of B instances (default: the handle's maximum) launches, as rocprofv3 names it."""
+        f = lib().pantr_batch_kernel_name
+        f.restype, f.argtypes = C.c_char_p, [C.c_void_p, _i32]
+        return f(self._h, self.max_instances if B is None else int(B)).decode()
 
     def footprint(self):
         a, b = C.c_int64(), C.c_int64()

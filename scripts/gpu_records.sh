@@ -8,7 +8,7 @@
 set -e
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 timeout -k 10 400 bash scripts/profile.sh > $OUT/profile.log 2>&1

@@ -16,15 +16,26 @@ def newest(pattern):
     return max(files, key=os.path.getmtime) if files else None
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERNEL = "pantr_solve_kernel"
-GRID = 600 * 64  # the timed launches: 600 instances, one 64-wide workgroup each
+KERNEL = "pantr_solve_"  # pantr_solve_kernel<ChainModel, 0> (one wavefront per instance) | pantr_solve_spec_kernel<ChainModel> (two)
+INSTANCES = 600           # the timed launches: 600 instances, one workgroup each
 
+
+def timed_grid():
+    """Grid size (threads) of the timed launches: 600 workgroups of 64 or - with speculation - 128 threads."""
+    t = newest(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
+    for r in csv.DictReader(open(t)):
+        if KERNEL in r["Kernel_Name"] and int(r["Grid_Size_X"]) in (INSTANCES * 64, INSTANCES * 128):
+            return int(r["Grid_Size_X"]), r["Kernel_Name"]
+    raise SystemExit("no timed launch of the solve kernel in the trace")
+
+
+GRID, KERNEL_FULL = timed_grid()
 summary = {"tag": tag, "command": "python3 bench.py --steps 3 --warmup 1 --headline-only",
-           "kernel": "pantr::pantr_solve_kernel<pantr::ChainModel, 0>",
+           "kernel": KERNEL_FULL, "wavefronts_per_instance": GRID // (INSTANCES * 64),
            # the code these numbers describe: bench.py prints roofline.traffic only while csrc/ still hashes to this
            "csrc_sha256": pa.source_hash()}
 stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
