@@ -65,7 +65,6 @@ struct ChainModel {
         int e[DIM];     ///< upper-triangle indices of row c of a symmetric 3x3
         bool active, mass, end, first, lead, grav;
         double inv_m_l; ///< 1/m on the masses' lanes, 0 elsewhere (keeps idle lanes' derivatives at 0)
-        double xref;       ///< reference position of this component of the end point (1,0,0)
         __device__ explicit Lane(int lane) {
             l      = lane;
             p      = lane & 15;
@@ -82,7 +81,6 @@ struct ChainModel {
             int cc = c < DIM ? c : 0;
             for (int k = 0; k < DIM; ++k)
                 e[k] = sym(cc, k);
-            xref = c == 0 ? 1.0 : 0.0;
         }
     };
 
@@ -464,7 +462,7 @@ struct ChainModel {
     /// to acc.x, the masses' lanes add beta v^2 to acc.v.
     __device__ static __forceinline__ void cost_accumulate(const Lane &L, const State &s, double uc, bool has_u,
                                                            State &acc) {
-        double t  = s.x - L.xref;
+        double t  = s.x - (L.c == 0 ? 1.0 : 0.0); // reference position of the end point: (1, 0, 0)
         double a1 = alpha * (t * t);
         double b1 = beta * (s.v * s.v);
         acc.x     = L.end ? acc.x + a1 : acc.x;
@@ -485,7 +483,7 @@ struct ChainModel {
     }
     /// lam + d(l or l_N)/dx.
     __device__ static __forceinline__ void cost_grad_x_add(const Lane &L, const State &s, State &lam) {
-        double ge = c2a * (s.x - L.xref);
+        double ge = c2a * (s.x - (L.c == 0 ? 1.0 : 0.0));
         double gv = c2b * s.v;
         lam.x     = L.end ? lam.x + ge : lam.x;
         lam.v     = L.mass ? lam.v + gv : lam.v;
