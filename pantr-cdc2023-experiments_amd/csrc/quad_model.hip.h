@@ -140,7 +140,7 @@ struct QuadModelT {
             da[2] = u[3];
         } else { // Omega [a b c]' = omega, Omega = [[c1,0,-c0 s1],[0,1,s0],[s1,0,c0 c1]], det = c0
             T a   = (t.c1 * u[1]) + (t.s1 * u[3]);
-            T cc  = ((t.c1 * u[3]) - (t.s1 * u[1])) / t.c0;
+            T cc  = qdiv((t.c1 * u[3]) - (t.s1 * u[1]), t.c0);
             T b   = u[2] - (t.s0 * cc);
             da[0] = a;
             da[1] = b;
@@ -213,7 +213,7 @@ struct QuadModelT {
         // a = c1 u1 + s1 u3 ; cc = (c1 u3 - s1 u1)/c0 ; b = u2 - s0 cc
         RateAdjCoef<T> k;
         k.num      = (t.c1 * u[3]) - (t.s1 * u[1]);
-        k.ic       = 1.0 / t.c0; // one reciprocal serves the three quotients by cos(phi)
+        k.ic       = qrecip(t.c0); // one reciprocal serves the three quotients by cos(phi)
         const T cc = k.num * k.ic;
         k.x        = (cc * t.s0) * k.ic; // d cc / d phi = num s0 / c0^2
         k.y        = t.c0 * cc;          // -d b / d phi at fixed cc

@@ -11,6 +11,37 @@ namespace pantr {
 
 constexpr int WAVE = 64;
 
+/// sqrt and division for operands well inside the normal range (no zeros, infinities, subnormals;
+/// exponents far from the ends): the compiler's correctly rounded fp64 expansions (v_rsq_f64 /
+/// v_rcp_f64 seeds, Goldschmidt / Newton steps in fma) without their range handling - the
+/// v_ldexp scaling and class test around the square root (8 of 18 instructions), v_div_scale,
+/// v_div_fmas and v_div_fixup around the division (4 of 11).  On such operands the dropped
+/// instructions are identities, so the results are the correctly rounded ones, bit for bit those of
+/// __builtin_sqrt and '/' (and of the oracle's).  Outside that range (the idle lanes of the chain
+/// sweeps divide by zero) the result is NaN or infinity; the callers never use those lanes.
+__device__ __forceinline__ double sqrt_inrange(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    double r = __builtin_fma(-h, g, 0.5);
+    g        = __builtin_fma(g, r, g);
+    h        = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g        = __builtin_fma(d, h, g);
+    d        = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ double div_inrange(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y        = __builtin_fma(y, e, y);
+    e        = __builtin_fma(-b, y, 1.0);
+    y        = __builtin_fma(y, e, y);
+    double q = a * y;
+    double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+
 // ---- first-order dual number (value, tangent) -------------------------------------------
 struct dual {
     double v, t;
@@ -27,15 +58,21 @@ __device__ __forceinline__ dual operator-(double c, dual a) { return {c - a.v, 0
 /// c / b = q with tangent b.t * k, k = (-q) / b.v: divisions act on primal values only, which
 /// is what lets the tape path record (q, k) once and replay tangents without dividing.
 __device__ __forceinline__ dual operator/(double c, dual b) {
-    double q = c / b.v;
-    double k = (-q) / b.v;
+    double q = div_inrange(c, b.v);
+    double k = div_inrange(-q, b.v);
     return {q, b.t * k};
 }
 /// a / b = q with tangent (a.t - q b.t) / b.v
 __device__ __forceinline__ dual operator/(dual a, dual b) {
-    double q = a.v / b.v;
-    return {q, (a.t - q * b.t) / b.v};
+    double q = div_inrange(a.v, b.v);
+    return {q, div_inrange(a.t - q * b.t, b.v)};
 }
+/// a / b of the models' stage functions: the in-range division (same results; its reciprocal
+/// iterations do not wait for the numerator, which shortens the dependent chain of the attitude integration)
+__device__ __forceinline__ double qdiv(double a, double b) { return div_inrange(a, b); }
+__device__ __forceinline__ dual qdiv(dual a, dual b) { return a / b; }
+__device__ __forceinline__ double qrecip(double b) { return div_inrange(1.0, b); }
+__device__ __forceinline__ dual qrecip(dual b) { return 1.0 / b; }
 __device__ __forceinline__ dual operator-(dual a) { return {-a.v, -a.t}; }
 /// c k + s in one rounding (the Runge-Kutta combinations of the scalar models)
 __device__ __forceinline__ double madd(double c, double k, double s) { return __builtin_fma(c, k, s); }
@@ -91,37 +128,6 @@ __device__ __forceinline__ dual wsqrt(dual a) {
     return {r, a.t * h};
 }
 __device__ __forceinline__ double wsqrt(double a) { return __builtin_sqrt(a); }
-
-/// sqrt and division for operands well inside the normal range (no zeros, infinities, subnormals;
-/// exponents far from the ends): the compiler's correctly rounded fp64 expansions (v_rsq_f64 /
-/// v_rcp_f64 seeds, Goldschmidt / Newton steps in fma) without their range handling - the
-/// v_ldexp scaling and class test around the square root (8 of 18 instructions), v_div_scale,
-/// v_div_fmas and v_div_fixup around the division (4 of 11).  On such operands the dropped
-/// instructions are identities, so the results are the correctly rounded ones, bit for bit those of
-/// __builtin_sqrt and '/' (and of the oracle's).  Outside that range (the idle lanes of the chain
-/// sweeps divide by zero) the result is NaN or infinity; the callers never use those lanes.
-__device__ __forceinline__ double sqrt_inrange(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    double h = y * 0.5;
-    double r = __builtin_fma(-h, g, 0.5);
-    g        = __builtin_fma(g, r, g);
-    h        = __builtin_fma(h, r, h);
-    double d = __builtin_fma(-g, g, x);
-    g        = __builtin_fma(d, h, g);
-    d        = __builtin_fma(-g, g, x);
-    return __builtin_fma(d, h, g);
-}
-__device__ __forceinline__ double div_inrange(double a, double b) {
-    double y = __builtin_amdgcn_rcp(b);
-    double e = __builtin_fma(-b, y, 1.0);
-    y        = __builtin_fma(y, e, y);
-    e        = __builtin_fma(-b, y, 1.0);
-    y        = __builtin_fma(y, e, y);
-    double q = a * y;
-    double r = __builtin_fma(-b, q, a);
-    return __builtin_fma(r, y, q);
-}
 
 template <class T>
 __device__ __forceinline__ T make_const(double c);
