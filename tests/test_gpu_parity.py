@@ -355,3 +355,27 @@ def test_speculation_changes_nothing_but_time():
             assert np.array_equal(st[k], st_off[k]), (mode, k)
     with pytest.raises(pa.PantrError, match="speculation"):
         pa.PantrBatch("hanging_chain", 5, 1, opts=("speculation=maybe",))
+
+
+def test_kernel_name_follows_method_speculation_and_batch_size():
+    """pantr_batch_kernel_name: what measurement code names its dominant kernel with."""
+    b = pa.PantrBatch("hanging_chain", 60, 1024, opts=pa.DODO_PANTR_OPTS)
+    assert b.kernel_name(600) == "pantr_solve_spec_kernel<ChainModel>"      # auto: small batches speculate
+    assert b.kernel_name(1024) == "pantr_solve_kernel<ChainModel, 0>"       # auto: large ones do not
+    lds_auto, ws = b.footprint()
+    b.close()
+    b = pa.PantrBatch("hanging_chain", 60, 600, opts=tuple(pa.DODO_PANTR_OPTS) + ("speculation=off",))
+    assert b.kernel_name() == "pantr_solve_kernel<ChainModel, 0>"
+    lds_off, _ = b.footprint()
+    b.close()
+    b = pa.PantrBatch("hanging_chain", 60, 600, opts=tuple(pa.DODO_PANTR_OPTS) + ("speculation=on",))
+    assert b.kernel_name() == "pantr_solve_spec_kernel<ChainModel>"
+    lds_on, _ = b.footprint()
+    b.close()
+    assert lds_off == lds_auto < lds_on <= 160 * 1024 // 4   # (1024 instances: one wavefront each; four two-wavefront workgroups fit a CU)
+    b = pa.PantrBatch("hanging_chain", 60, 8, opts=pa.DODO_OPTS["panoc"])
+    assert b.kernel_name() == "pantr_solve_kernel<ChainModel, 1>"
+    b.close()
+    b = pa.PantrBatch("realistic_quadcopter", 12, 2)
+    assert b.kernel_name() == "pantr_alm_kernel<QuadModelT<true>, 0>"
+    b.close()
