@@ -58,6 +58,11 @@ struct ChainModel {
 
     /// A tape row is 64 doubles: ten springs x six entries and four unused slots; nobody reads the last one.
     static constexpr int TAPE_ROW_DUMP = 63;
+    /// First slot of spring p's six entries in a row: 6p, with one slot left free before spring 8.  A
+    /// 16-lane row of the wavefront reads entry e of its ten springs in one LDS access over 32 banks of
+    /// 4 bytes: at a stride of 48 bytes springs 8 and 9 would fall on the banks of springs 0 and 1 (a
+    /// two-way conflict in every read of K and M); shifted by 8 bytes they fall on free ones.
+    __host__ __device__ static constexpr int spring_base(int p) { return 6 * p + (p >= 8 ? 1 : 0); }
     /// Per-lane role.
     struct Lane {
         int l, p, c, q; ///< lane, point, component, compact slot 3p+c
@@ -247,7 +252,7 @@ struct ChainModel {
     // ---- the tape ------------------------------------------------------------------------------
     // Per substage j and spring p: the upper triangles of K = c I + w d d^T and of
     // M = w [ lF d^T + d lF^T + dt (I - (3/n2) d d^T) ] (both symmetric), six doubles each in the
-    // order (0,0) (0,1) (0,2) (1,1) (1,2) (2,2): spring p's block at doubles [6p, 6p+6) of a
+    // order (0,0) (0,1) (0,2) (1,1) (1,2) (2,2): spring p's block at doubles [spring_base(p), +6) of a
     // 512-byte row.  Stage layout in HBM (4 KiB): [K rows of j = 0..3] (2 KiB: all the forward sweep
     // needs) then [M rows of j = 0..3].  Lane (p,c) reads row c of the full matrices from LDS.
     // The forward sweep of each product writes its tangent spring vectors d_t to a second tape
@@ -283,7 +288,7 @@ struct ChainModel {
             double M  = ax.w * m;
             // slot of entry (c, c2): recomputed here (three integer operations) rather than kept in the
             // lane's registers for the whole solve
-            const int slot = (L.active && L.c <= c2) ? 6 * L.p + sym(L.c, c2) : TAPE_ROW_DUMP;
+            const int slot = (L.active && L.c <= c2) ? spring_base(L.p) + sym(L.c, c2) : TAPE_ROW_DUMP;
             Krow[slot] = K;
             Mrow[slot] = M;
         }
@@ -311,12 +316,12 @@ struct ChainModel {
         double K[DIM], M[DIM], D[DIM]; ///< D = d_t of this lane's point (from the tangent tape)
     };
     __device__ static __forceinline__ TapeK tape_fwd(const Lane &L, const char *buf, int j) {
-        const double *K = reinterpret_cast<const double *>(buf + j * 512) + 6 * L.pc;
+        const double *K = reinterpret_cast<const double *>(buf + j * 512) + spring_base(L.pc);
         return {{K[L.e[0]], K[L.e[1]], K[L.e[2]]}};
     }
     __device__ static __forceinline__ TapeKM tape_rev(const Lane &L, const char *buf, int j) {
-        const double *K  = reinterpret_cast<const double *>(buf + j * 512) + 6 * L.pc;
-        const double *M  = reinterpret_cast<const double *>(buf + 2048 + j * 512) + 6 * L.pc;
+        const double *K  = reinterpret_cast<const double *>(buf + j * 512) + spring_base(L.pc);
+        const double *M  = reinterpret_cast<const double *>(buf + 2048 + j * 512) + spring_base(L.pc);
         const double *st = reinterpret_cast<const double *>(buf + TAPE_STAGE_BYTES + j * 256) + DIM * L.pc;
         return {{K[L.e[0]], K[L.e[1]], K[L.e[2]]}, {M[L.e[0]], M[L.e[1]], M[L.e[2]]}, {st[0], st[1], st[2]}};
     }
