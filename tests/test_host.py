@@ -83,6 +83,14 @@ def test_option_grammar():
         assert e.value.code == -1
     with pytest.raises(pa.PantrError):
         p.get("solver.no_such_key")
+    # speculation=auto|on|off: an option of this implementation, spelled like method=
+    assert p.get("speculation") == -1
+    for text, value in (("speculation=on", 1), ("speculation=off", 0), ("speculation=auto", -1)):
+        p.set(text)
+        assert p.get("speculation") == value
+    with pytest.raises(pa.PantrError) as e:
+        p.set("speculation=maybe")
+    assert e.value.code == -1 and "speculation" in str(e.value)
 
 
 def test_no_cpu_fallback():
