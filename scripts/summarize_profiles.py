@@ -57,7 +57,7 @@ for r in csv.DictReader(open(trace)):
                                                   "SGPR_Count") if k in r}
         break
 pmc = {}
-for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     f = newest(os.path.join(src, name, "*", "*_counter_collection.csv"))
     if not f:
         continue
@@ -86,5 +86,14 @@ if "SQ_INSTS_VALU" in pmc and "SQ_WAVE_CYCLES" in pmc and summary.get("kernel_tr
         "cycles_per_valu_instruction_of_a_wavefront": wave_cycles / pmc["SQ_INSTS_VALU"],
         "mean_wavefront_ms": wave_cycles / pmc["SQ_WAVES"] / 2.4e9 * 1e3,
         "note": "one wavefront per instance: the pass lasts as long as its slowest instance, so most SIMD cycles idle"}
+if "SQ_LDS_IDX_ACTIVE" in pmc and summary.get("kernel_trace_timed_launches", {}).get("avg_ms"):
+    ms = summary["kernel_trace_timed_launches"]["avg_ms"]
+    cu_cycles = 256 * ms * 1e-3 * 2.4e9
+    summary["lds"] = {
+        "lds_busy_frac_of_cu_cycles": pmc["SQ_LDS_IDX_ACTIVE"] / cu_cycles,
+        "bank_conflict_frac_of_lds_cycles": pmc.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(pmc["SQ_LDS_IDX_ACTIVE"], 1.0),
+        "lds_instructions_per_launch": pmc.get("SQ_INSTS_LDS"),
+        "note": "SQ_LDS_IDX_ACTIVE / (256 CUs x kernel time x 2.4 GHz): averaged over the whole pass, including its "
+                "tail when few instances are left; while all 600 run the fraction is about pass / mean-solve-time higher"}
 json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
