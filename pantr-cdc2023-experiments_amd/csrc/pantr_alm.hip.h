@@ -51,10 +51,10 @@ struct AlmSolveArgs {
 };
 
 /// Wave-cooperative single-shooting problem with an augmented-Lagrangian term, scalar model M.
-template <class M>
+template <class M, bool SPEC = false>
 struct ScalarALProblem {
     static constexpr int nx = M::nx, nu = M::nu, nc = M::nc;
-    static constexpr bool HAS_SPEC = false; ///< no helper wavefront (pantr_kernel.hip.h: SpecBox)
+    static constexpr bool HAS_SPEC = SPEC; ///< a helper wavefront evaluates ahead (pantr_alm_spec_kernel; SpecBox)
     int lane;
     const BoxData *box; ///< bounds of u (box C) and of the constraints (box D), kernel argument
     double *lds; ///< n-vectors: NUM_VEC slots of npad doubles
@@ -1109,6 +1109,126 @@ struct ScalarALProblem {
         }
         wave_sync();
     }
+    // ---- speculation on a rejected candidate (SPEC: two-wavefront workgroups, pantr_alm_spec_kernel) ----
+    // As for the chain (pantr_kernel.hip.h, SpecBox): while the solver wavefront runs the CG loop and
+    // evaluates the candidate, the helper evaluates what a rejection needs next - psi(xhat) of the prox
+    // iterate with its multiplier estimates, the quadratic-upper-bound test, grad_L(xhat) and the tape
+    // there - on its own trajectory, trig store, scratch and tape buffer.  It reads xhat from the solver's
+    // iterate vectors and y, Sigma, y/Sigma from the shared m-vectors (all constant meanwhile) and writes
+    // yhat to the m-vector slot of the prox iterate (which nothing else touches meanwhile), the gradient
+    // to a vector of its own.  No model-value requests here: a request keeps the helper busy until the
+    // ratio test.
+    SpecBox *spec = nullptr;
+    double *hG    = nullptr; ///< LDS: the helper's gradient vector
+    double *tape0 = nullptr; ///< HBM: the first of this instance's two tape buffers
+    int tape_cur  = 0;       ///< which of them `tape` is
+    bool spec_pending = false, spec_dead = false;
+    double spec_tick_s = 1e-8, spec_patience_s = 1.0;
+
+    __device__ __forceinline__ void spec_request(int xh_slot, double psi_x, double gradTp, double pTp, double Lip,
+                                                 const KernelParams &P, int yh_slot) {
+        if (!spec || spec_dead)
+            return;
+        wave_sync(); // xhat is written
+        if (lane == 0) {
+            spec->cmd = SPEC_EVAL; spec->xh_slot = xh_slot; spec->yh_slot = yh_slot; spec->tape_sel = 1 - tape_cur;
+            spec->psi_x = psi_x; spec->gradTp = gradTp; spec->pTp = pTp; spec->L = Lip;
+            spec->qub_factor = P.quadratic_upperbound_tolerance_factor; spec->L_max = P.L_max;
+            __hip_atomic_store(&spec->req_seq, spec->req_seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        spec_pending = true;
+    }
+    /// Wait for the posted request (bounded work; the wait is bounded too: false = nothing of it is used).
+    __device__ __forceinline__ bool spec_wait() {
+        const int want = __hip_atomic_load(&spec->req_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(&spec->done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((double)(wall_clock64() - t0) * spec_tick_s > spec_patience_s) {
+                spec_dead = true;
+                return false;
+            }
+        }
+        return true;
+    }
+    __device__ __forceinline__ void spec_drop() {
+        if (spec && spec_pending)
+            spec_wait();
+        spec_pending = false;
+    }
+    __device__ __forceinline__ bool spec_take(double &psi_xh) {
+        if (!spec || !spec_pending)
+            return false;
+        const bool done = spec_wait();
+        spec_pending    = false;
+        const bool ok   = done && uniform(spec->ok) != 0;
+        if (ok)
+            psi_xh = uniform(spec->psi_xh);
+        return ok;
+    }
+    __device__ __forceinline__ bool spec_post_model(const double *, const double *, unsigned) { return false; }
+    __device__ __forceinline__ bool spec_take_model(double &) { return false; }
+    /// grad <- the helper's gradient, tape <- the buffer it recorded into (yhat is in the iterate's slot already).
+    __device__ __forceinline__ void spec_adopt(double *grad) {
+        wave_sync();
+        for (int i = lane; i < n; i += WAVE)
+            grad[i] = hG[i];
+        tape_cur = 1 - tape_cur;
+        tape     = tape0 + (size_t)tape_cur * workspace_doubles(N);
+        wave_sync();
+    }
+    /// End of an inner solve: the helper idles until the next one (set_al / update_multipliers write the
+    /// m-vectors it reads).
+    __device__ __forceinline__ void spec_exit() { spec_drop(); }
+    /// End of the instance.
+    __device__ __forceinline__ void spec_shutdown() {
+        if (!spec)
+            return;
+        spec_drop();
+        if (lane == 0) {
+            spec->cmd = SPEC_EXIT;
+            __hip_atomic_store(&spec->req_seq, spec->req_seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    /// The helper wavefront (`this`: its own X, Xt, TG, scr, coef; the solver's vectors and m-vectors).
+    __device__ __forceinline__ void spec_serve(long long t_start, double tick_s, double give_up_s) {
+        int seen = 0;
+        while (true) {
+            int r;
+            while ((r = __hip_atomic_load(&spec->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == seen) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((double)(wall_clock64() - t_start) * tick_s > give_up_s)
+                    return;
+            }
+            seen = r;
+            if (uniform(spec->cmd) == SPEC_EXIT)
+                return;
+            const double *xh = ivec(uniform(spec->xh_slot));
+            const int yh     = uniform(spec->yh_slot);
+            tape             = tape0 + (size_t)uniform(spec->tape_sel) * workspace_doubles(N);
+            const double psi_xh = eval_psi_xhat(xh, yh);
+            const double psi_x = uniform(spec->psi_x), gradTp = uniform(spec->gradTp), pTp = uniform(spec->pTp),
+                         Lip = uniform(spec->L);
+            const double margin = (1.0 + fabs(psi_x)) * uniform(spec->qub_factor);
+            const bool violated = psi_xh > ((psi_x + gradTp) + (0.5 * Lip) * pTp) + margin;
+            const bool ok       = !(Lip < uniform(spec->L_max) && violated);
+            if (ok)
+                eval_grad_xhat(xh, hG, yh);
+            wave_sync(); // gradient, yhat and (acknowledged) tape are written before the result is announced
+            if (lane == 0) {
+                spec->psi_xh = psi_xh;
+                spec->ok     = ok ? 1 : 0;
+                __hip_atomic_store(&spec->done_seq, seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    /// LDS doubles of the helper: trajectory, adjoint rows, trig store, rate-adjoint coefficients, sweep
+    /// scratch of its own (the solver's is lent from its CG vectors, which are busy meanwhile), gradient.
+    __host__ __device__ static size_t helper_lds_doubles(int N, int npad) {
+        return (size_t)2 * (N + 1) * nx + (size_t)(N + 1) * M::TRIG_DOUBLES_PER_STAGE + coef_doubles(N) +
+               scratch_doubles(N) + (size_t)npad;
+    }
+
     /// y / Sigma for the sweeps; call whenever y or Sigma changed (they are fixed during an inner solve).
     __device__ __forceinline__ void set_al() const {
         wave_sync();
@@ -1211,41 +1331,14 @@ struct ScalarALProblem {
     }
 };
 
-/// ALM outer loop (m > 0) around the inner solver METHOD names, one wavefront per instance.
-template <class M, int METHOD>
-__global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-    if (inst >= a.B)
-        return;
-    const long long t_start = wall_clock64();
+/// One instance, start to finish, on the calling wavefront: the body of both ALM kernels.
+template <class M, int METHOD, class PB>
+__device__ __forceinline__ void alm_solve_instance(const AlmSolveArgs &a, PB &pb, int lane, int inst, long long t_start) {
     const KernelParams &P    = a.prm;
     const AlmKernelParams &A = a.alm;
-    using PB = ScalarALProblem<M>;
-    PB pb;
-    pb.lane = lane; pb.box = &a.prm.box; pb.lds = lds; pb.N = a.N; pb.n = a.n; pb.npad = a.npad; pb.nj = a.nj;
-    pb.m = a.m; pb.mpad = a.mpad; pb.mj = a.mj;
-    pb.mv = lds + (size_t)NUM_VEC * a.npad;
-    pb.X  = pb.mv + (size_t)PB::MV_COUNT * a.mpad;
-    pb.Xt = pb.X + (size_t)(a.N + 1) * M::nx;
-    pb.TG = reinterpret_cast<double2 *>(pb.Xt + (size_t)(a.N + 1) * M::nx);
-    pb.tape = a.ws + (size_t)inst * PB::workspace_doubles(a.N);
     const int n = a.n, m = a.m;
-    const size_t total = PB::lds_doubles(a.N, a.npad, a.mpad, METHOD != 0);
-    for (size_t i = lane; i < total; i += WAVE)
-        lds[i] = 0.0;
-    wave_sync();
-    {
-        double *x0_lds = reinterpret_cast<double *>(pb.TG + 12 * (a.N + 1)); // after the trig store
-        if (lane < M::nx)
-            x0_lds[lane] = a.x0[(size_t)inst * M::nx + lane];
-        pb.x0 = x0_lds;
-        // scratch of the cascade sweeps: PANTR lends the five vector slots from z on (dead outside the
-        // direction computation); the comparators keep L-BFGS scalars in the CG block and get LDS of their own
-        pb.coef = x0_lds + PB::X0_DOUBLES;
-        pb.scr  = METHOD == 0 ? pb.vec(PB::CG_BASE + 3) : pb.coef + PB::coef_doubles(a.N);
-    }
+    if (lane < M::nx)
+        const_cast<double *>(pb.x0)[lane] = a.x0[(size_t)inst * M::nx + lane];
     double *x_io = pb.vec(S_XIO), *y = pb.mvec(PB::MV_Y), *Sig = pb.mvec(PB::MV_SIG), *e1 = pb.mvec(PB::MV_E1),
            *e2 = pb.mvec(PB::MV_E2);
     for (int i = lane; i < n; i += WAVE)
@@ -1341,6 +1434,90 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
         st.penalty_norm               = __builtin_sqrt(sq / m);
         write_stats(a.stats + inst, st);
     }
+    if constexpr (PB::HAS_SPEC)
+        pb.spec_shutdown();
+}
+
+/// The solver wavefront's problem object on the workgroup's dynamic LDS (layout: lds_doubles()).
+template <class M, int METHOD, class PB>
+__device__ __forceinline__ void alm_bind(PB &pb, const AlmSolveArgs &a, double *lds, int lane, int inst) {
+    pb.lane = lane; pb.box = &a.prm.box; pb.lds = lds; pb.N = a.N; pb.n = a.n; pb.npad = a.npad; pb.nj = a.nj;
+    pb.m = a.m; pb.mpad = a.mpad; pb.mj = a.mj;
+    pb.mv = lds + (size_t)NUM_VEC * a.npad;
+    pb.X  = pb.mv + (size_t)PB::MV_COUNT * a.mpad;
+    pb.Xt = pb.X + (size_t)(a.N + 1) * M::nx;
+    pb.TG = reinterpret_cast<double2 *>(pb.Xt + (size_t)(a.N + 1) * M::nx);
+    double *x0_lds = reinterpret_cast<double *>(pb.TG + 12 * (a.N + 1)); // after the trig store
+    pb.x0 = x0_lds;
+    // scratch of the cascade sweeps: PANTR lends the five vector slots from z on (dead outside the
+    // direction computation); the comparators keep L-BFGS scalars in the CG block and get LDS of their own
+    pb.coef = x0_lds + PB::X0_DOUBLES;
+    pb.scr  = METHOD == 0 ? pb.vec(PB::CG_BASE + 3) : pb.coef + PB::coef_doubles(a.N);
+}
+
+/// ALM outer loop (m > 0) around the inner solver METHOD names, one wavefront per instance.
+template <class M, int METHOD>
+__global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if (inst >= a.B)
+        return;
+    const long long t_start = wall_clock64();
+    using PB = ScalarALProblem<M>;
+    PB pb;
+    alm_bind<M, METHOD>(pb, a, lds, lane, inst);
+    pb.tape = a.ws + (size_t)inst * PB::workspace_doubles(a.N);
+    const size_t total = PB::lds_doubles(a.N, a.npad, a.mpad, METHOD != 0);
+    for (size_t i = lane; i < total; i += WAVE)
+        lds[i] = 0.0;
+    wave_sync();
+    alm_solve_instance<M, METHOD>(a, pb, lane, inst, t_start);
+}
+
+/// method = pantr with a helper wavefront per instance (ScalarALProblem: speculation).  Wavefront 0 is
+/// the solver of pantr_alm_kernel<M, 0>; wavefront 1 serves its requests on LDS of its own behind the
+/// solver's (helper_lds_doubles) and on the instance's second tape buffer.
+template <class M>
+__global__ __launch_bounds__(2 * WAVE) void pantr_alm_spec_kernel(AlmSolveArgs a) {
+    extern __shared__ double lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+    const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if (inst >= a.B)
+        return;
+    const long long t_start = wall_clock64();
+    __shared__ SpecBox box;
+    using PB = ScalarALProblem<M, true>;
+    PB pb;
+    alm_bind<M, 0>(pb, a, lds, lane, inst);
+    const size_t solver_doubles = PB::lds_doubles(a.N, a.npad, a.mpad, false);
+    const size_t total          = solver_doubles + PB::helper_lds_doubles(a.N, a.npad);
+    for (size_t i = threadIdx.x; i < total; i += 2 * WAVE)
+        lds[i] = 0.0;
+    if (threadIdx.x == 0) {
+        box.req_seq  = 0;
+        box.done_seq = 0;
+        box.cmd      = 0;
+    }
+    __syncthreads(); // the only workgroup barrier: LDS is cleared and the mailbox exists
+    pb.spec        = &box;
+    pb.spec_tick_s = a.prm.tick_s;
+    pb.tape0       = a.ws + (size_t)inst * 2 * PB::workspace_doubles(a.N);
+    pb.tape        = pb.tape0;
+    double *h      = lds + solver_doubles; // the helper's LDS
+    pb.hG          = h + (size_t)2 * (a.N + 1) * M::nx + (size_t)(a.N + 1) * M::TRIG_DOUBLES_PER_STAGE +
+            PB::coef_doubles(a.N) + PB::scratch_doubles(a.N);
+    if (wave == 1) {
+        pb.X    = h; // (the solver writes the initial state to LDS before its first request)
+        pb.Xt   = pb.X + (size_t)(a.N + 1) * M::nx;
+        pb.TG   = reinterpret_cast<double2 *>(pb.Xt + (size_t)(a.N + 1) * M::nx);
+        pb.coef = reinterpret_cast<double *>(pb.TG + 12 * (a.N + 1));
+        pb.scr  = pb.coef + PB::coef_doubles(a.N);
+        pb.spec_serve(t_start, a.prm.tick_s, 2.0 * a.alm.max_time_s + 1.0);
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    alm_solve_instance<M, 0>(a, pb, lane, inst, t_start);
 }
 
 } // namespace pantr

@@ -274,7 +274,25 @@ size_t spec_lds_bytes(const pantr_batch &b) { return spec_lds_doubles<ChainModel
 size_t spec_lds_total(const pantr_batch &b) {
     return spec_lds_bytes(b) + 2 * WaveProblem<ChainModel>::tape_lds_bytes() + sizeof(SpecBox);
 }
+/// The same question for the quadcopter family (pantr_alm_spec_kernel): dynamic LDS of the two-wavefront
+/// workgroup; auto: every instance resident at once, at most one workgroup per pair of SIMDs.
+size_t alm_spec_lds_bytes(const pantr_batch &b) {
+    const bool realistic = b.problem == ProblemId::RealisticQuadcopter;
+    return b.lds_bytes + sizeof(double) * (realistic ? ScalarALProblem<QuadModelT<true>>::helper_lds_doubles(b.N, b.npad)
+                                                     : ScalarALProblem<QuadModelT<false>>::helper_lds_doubles(b.N, b.npad));
+}
+bool use_alm_speculation(const pantr_batch *b, int32_t B) {
+    const size_t wg_lds = alm_spec_lds_bytes(*b) + sizeof(SpecBox);
+    if (b->opts.method != host::Method::PANTR || b->opts.speculation == 0 || wg_lds > 160 * 1024)
+        return false;
+    if (b->opts.speculation == 1)
+        return true;
+    const size_t per_cu = std::min<size_t>(2, (160 * 1024) / wg_lds);
+    return (size_t)B <= per_cu * (size_t)b->num_cus;
+}
 bool use_speculation(const pantr_batch *b, int32_t B) {
+    if (b->al())
+        return use_alm_speculation(b, B);
     const size_t wg_lds = spec_lds_total(*b);
     if (b->opts.speculation == 0 || wg_lds > 160 * 1024)
         return false;
@@ -323,7 +341,9 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
         HIP_TRY(hipEventRecord(b->ev_start, stream));
         with_quad_model(b, [&](auto model) {
             using M = decltype(model);
-            if (method == 0)
+            if (method == 0 && use_alm_speculation(b, B))
+                hipLaunchKernelGGL(pantr_alm_spec_kernel<M>, dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
+            else if (method == 0)
                 hipLaunchKernelGGL((pantr_alm_kernel<M, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
             else if (method == 1)
                 hipLaunchKernelGGL((pantr_alm_kernel<M, 1>), dim3(B), dim3(WAVE), b->lds_bytes_cmp, stream, a);
@@ -582,7 +602,7 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
     size_t static_lds = 0;
     if (b->al()) {
         // trajectories and multipliers live in LDS; the second-order tape streams from HBM
-        b->ws_per_instance = ScalarALProblem<QuadModelT<false>>::workspace_doubles(b->N);
+        b->ws_per_instance = 2 * ScalarALProblem<QuadModelT<false>>::workspace_doubles(b->N); // two tape buffers (speculation)
         auto lds_of = [&](bool dedicated_scratch) {
             return (id == ProblemId::RealisticQuadcopter
                         ? ScalarALProblem<QuadModelT<true>>::lds_doubles(b->N, b->npad, b->mpad, dedicated_scratch)
@@ -609,6 +629,11 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
                               (const void *)&pantr_alm_eval_kernel<QuadModelT<true>>})
             if (int rc = raise_dynamic_lds(k, b->lds_bytes))
                 return rc;
+        if (alm_spec_lds_bytes(*b) + sizeof(SpecBox) <= 160 * 1024)
+            for (const void *k : {(const void *)&pantr_alm_spec_kernel<QuadModelT<false>>,
+                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<true>>})
+                if (int rc = raise_dynamic_lds(k, alm_spec_lds_bytes(*b)))
+                    return rc;
         if (b->lds_bytes_cmp <= 160 * 1024) // else the comparators are refused at launch
             for (const void *k : {(const void *)&pantr_alm_kernel<QuadModelT<false>, 1>,
                                   (const void *)&pantr_alm_kernel<QuadModelT<false>, 2>,
@@ -879,6 +904,8 @@ int pantr_batch_footprint(const pantr_batch_t *b, int64_t *lds_bytes, int64_t *w
         const bool cmp_scalar = b->al() && b->opts.method != host::Method::PANTR;
         if (pantr_chain && use_speculation(b, b->maxB))
             *lds_bytes = (int64_t)spec_lds_total(*b);
+        else if (b->al() && use_alm_speculation(b, b->maxB))
+            *lds_bytes = (int64_t)(alm_spec_lds_bytes(*b) + sizeof(SpecBox));
         else
             *lds_bytes = (int64_t)((pantr_chain ? b->lds_bytes_pantr : cmp_scalar ? b->lds_bytes_cmp : b->lds_bytes) +
                                    (b->al() ? 0 : WaveProblem<ChainModel>::tape_lds_bytes()));
@@ -896,6 +923,8 @@ const char *pantr_batch_kernel_name(const pantr_batch_t *b, int32_t B) {
         static const char *names[2][3] = {
             {"pantr_alm_kernel<QuadModelT<false>, 0>", "pantr_alm_kernel<QuadModelT<false>, 1>", "pantr_alm_kernel<QuadModelT<false>, 2>"},
             {"pantr_alm_kernel<QuadModelT<true>, 0>", "pantr_alm_kernel<QuadModelT<true>, 1>", "pantr_alm_kernel<QuadModelT<true>, 2>"}};
+        if (use_alm_speculation(b, B))
+            return realistic ? "pantr_alm_spec_kernel<QuadModelT<true>>" : "pantr_alm_spec_kernel<QuadModelT<false>>";
         return names[realistic ? 1 : 0][method];
     }
     if (method == 0)

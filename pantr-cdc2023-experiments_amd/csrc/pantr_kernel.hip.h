@@ -141,6 +141,7 @@ struct SpecBox {
     int req_seq, done_seq; ///< main: requests posted; helper: requests finished
     int cmd;               ///< SPEC_EVAL | SPEC_EXIT
     int xh_slot;           ///< iterate vector (pb.ivec index) holding the point to evaluate: xhat of the prox iterate
+    int yh_slot;           ///< problems with general constraints: the m-vector that receives yhat there
     int tape_sel;          ///< tape buffer (0 | 1) the helper records into
     int ok;                ///< response: the quadratic upper bound held (no backtracking: the result is usable)
     double psi_x, gradTp, pTp, L, qub_factor, L_max; ///< request: what the quadratic-upper-bound test needs
@@ -274,7 +275,7 @@ struct WaveProblem {
     static_assert(!SPEC || ITER_GLOBAL, "speculation needs the iterates in HBM");
     /// Post "evaluate psi, the bound test and grad_L + tape at ivec(xh_slot)"; the helper starts at once.
     __device__ __forceinline__ void spec_request(int xh_slot, double psi_x, double gradTp, double pTp, double Lip,
-                                                 const KernelParams &P) const {
+                                                 const KernelParams &P, int /*yh_slot*/) const {
         if (!spec || spec_dead)
             return;
         wave_sync(); // the iterate vectors the helper will read are written (and, in HBM, acknowledged)
@@ -860,7 +861,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
         ++st.n_prox_grad_step;
         if constexpr (PB::HAS_SPEC)
             if (!P.disable_acceleration) // should the candidate be rejected: xbar's own next steps, meanwhile
-                pb.spec_request(prox.base + 1, prox.psi_x, prox.gradTp, prox.pTp, prox.L, P);
+                pb.spec_request(prox.base + 1, prox.psi_x, prox.gradTp, prox.pTp, prox.L, P, prox.yh);
 
         // ---- Newton trust-region direction at xbar (Steihaug-Toint CG on the inactive set) ----
         bool accept    = false, model_deferred = false;

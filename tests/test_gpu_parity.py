@@ -377,5 +377,8 @@ def test_kernel_name_follows_method_speculation_and_batch_size():
     assert b.kernel_name() == "pantr_solve_kernel<ChainModel, 1>"
     b.close()
     b = pa.PantrBatch("realistic_quadcopter", 12, 2)
+    assert b.kernel_name() == "pantr_alm_spec_kernel<QuadModelT<true>>"          # auto, a small batch
+    b.close()
+    b = pa.PantrBatch("realistic_quadcopter", 12, 2, opts=tuple(pa.DODO_PANTR_OPTS) + ("speculation=off",))
     assert b.kernel_name() == "pantr_alm_kernel<QuadModelT<true>, 0>"
     b.close()

@@ -82,6 +82,33 @@ def test_alm_solve_matches_oracle(rng, problem, N):
         assert st["eps"][i] <= 1e-8 and st["delta"][i] <= 1e-8
 
 
+@pytest.mark.parametrize("problem,N", [("quadcopter", 12), ("realistic_quadcopter", 20), ("realistic_quadcopter", 60)])
+def test_speculation_changes_nothing_but_time(rng, problem, N):
+    """Two wavefronts per instance (pantr_alm_spec_kernel: the helper evaluates the successor of a rejected
+    candidate during the CG loop and the candidate's evaluation) against one: solutions, multipliers and
+    every counter equal.  The other tests of this file run whatever `speculation=auto` selects - the
+    two-wavefront kernel at these batch sizes - against the oracle."""
+    B = 4
+    x0 = np.vstack([ob.quad_initial_state(), ob.quad_initial_state() + 0.02 * rng.standard_normal((B - 1, 9))])
+    u0 = np.tile(ob.quad_initial_guess(N), (B, 1))
+    res = {}
+    for mode in ("on", "off"):
+        b = pa.PantrBatch(problem, N, B, opts=quad_opts(problem) + [f"speculation={mode}"])
+        assert ("spec" in b.kernel_name()) == (mode == "on")
+        res[mode] = b.solve_al(x0, u0)
+        b.close()
+    (u1, y1, s1), (u0_, y0_, s0) = res["on"], res["off"]
+    assert np.array_equal(u1, u0_) and np.array_equal(y1, y0_)
+    for key in s1.dtype.names:
+        if key not in ("elapsed_s", "phase_s"):
+            assert np.array_equal(s1[key], s0[key]), key
+    assert np.all(s1["status"] == 1) and s1["rejected"].sum() > 0   # (rejections happened: results were taken)
+    b = pa.PantrBatch(problem, N, 4096, opts=quad_opts(problem))
+    assert "spec" not in b.kernel_name()                             # auto: large batches keep one wavefront
+    assert "spec" in b.kernel_name(B)
+    b.close()
+
+
 @pytest.mark.parametrize("warm", [True, False])
 def test_closed_loop_with_multipliers(warm):
     """mpc-driver.cpp:123-210 incl. the multiplier shift (:173-175), on the device."""
