@@ -246,9 +246,8 @@ int pantr_device_count(void);
  * GB/s.  The measured yardstick bench.py reports next to the 8 TB/s spec peak. */
 int pantr_device_copy_bandwidth(int32_t device, int64_t bytes, int32_t reps, double *gb_per_s);
 /* Name of the device kernel a solve of B instances on this handle launches (as rocprofv3 prints it, without
- * the namespace): which one depends on the problem, on `method=` and - hanging chain, method=pantr - on
- * `speculation=` and B (one or two wavefronts per instance).  Measurement code names its dominant kernel
- * with it. */
+ * the namespace): which one depends on the problem, on `method=` and - method=pantr - on `speculation=`
+ * and B (one or two wavefronts per instance).  Measurement code names its dominant kernel with it. */
 const char *pantr_batch_kernel_name(const pantr_batch_t *b, int32_t B);
 /* Bytes of LDS per workgroup and of HBM workspace per instance for this handle. */
 int pantr_batch_footprint(const pantr_batch_t *b, int64_t *lds_bytes, int64_t *ws_bytes_per_instance);

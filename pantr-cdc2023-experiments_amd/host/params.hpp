@@ -174,10 +174,11 @@ struct ALMParams {
 /// Everything one solver instance is configured by.
 struct SolverOptions {
     Method method = Method::PANTR;
-    /// `speculation=auto|on|off` (an option of this implementation, spelled like `method=`): hanging chain,
-    /// method=pantr: a second wavefront per instance evaluates the successor of a rejected candidate
-    /// during the CG loop (csrc/pantr_kernel.hip.h: SpecBox).  Same results either way; auto = on for
-    /// batches small enough to leave the GPU's SIMDs idle otherwise.  -1 auto, 0 off, 1 on.
+    /// `speculation=auto|on|off` (an option of this implementation, spelled like `method=`), method=pantr:
+    /// a second wavefront per instance evaluates the successor of a rejected candidate while the solver
+    /// works on the trust-region subproblem (csrc/pantr_kernel.hip.h: SpecBox; csrc/pantr_alm.hip.h for the
+    /// quadcopter family).  Same results either way; auto = on for batches small enough to leave the GPU's
+    /// SIMDs idle otherwise.  -1 auto, 0 off, 1 on.
     int32_t speculation = -1;
     PANTRParams solver;
     NewtonTRDirectionParams dir;
