@@ -52,6 +52,11 @@ __device__ __forceinline__ InnerResult panoc_inner(PB &pb, const KernelParams &P
                                                    double *lbfgs_ws) {
     const int lane = threadIdx.x;
     const int n = pb.n, nj = pb.nj;
+#ifdef PANTR_REST_TIMING // (development build of pantr_inner's bookkeeping timing: unused here)
+    double rest_bucket_[4] = {0, 0, 0, 0};
+    long long rest_last_ = 0;
+    int rest_cur_ = 0;
+#endif
     enum { S_IT0 = 0, S_IT1 = 4, S_Q = 8, S_WORK = 9, S_RA = 10 }; // S_RA: slots 10..18, rho | alpha
     IterateRef curr{S_IT0, 0}, next{S_IT1, 1};
     auto X_  = [&](const IterateRef &it) { return pb.vec(it.base + 0); };

@@ -674,7 +674,27 @@ __device__ __forceinline__ bool is_finite(double v) { return fabs(v) < __builtin
 // Profiling build (-DPANTR_PHASE_TIMING; `make phase` builds it as a separate library, never over
 // the product): stats.phase_s[] receives the seconds spent per phase (scripts/phase_timing.sh);
 // all documented stats fields keep their meaning and pantr_version() reports the build.
-#ifdef PANTR_PHASE_TIMING
+#if defined(PANTR_REST_TIMING)
+// Second profiling variant (`make phase EXTRA_HIPFLAGS=-DPANTR_REST_TIMING`, scripts/rest_timing.py;
+// pantr_version() says "+rest-timing"): where a PANTR iteration's time OUTSIDE the evaluations goes.
+// phase_s[] then means: [0] all evaluations, [1] from the end of the CG loop to the stop criterion of the
+// next iteration, [2] prox iterate .. start of the CG loop, [3] the CG loop without its products.
+#define PANTR_REGION(k)                                                                            \
+    do {                                                                                           \
+        long long t_ = wall_clock64();                                                             \
+        rest_bucket_[rest_cur_] += (double)(t_ - rest_last_) * P.tick_s;                           \
+        rest_last_ = t_;                                                                           \
+        rest_cur_  = (k);                                                                          \
+    } while (0)
+#define PANTR_PHASE(idx, ...)                                                                      \
+    do {                                                                                           \
+        const int keep_ = rest_cur_;                                                               \
+        PANTR_REGION(0);                                                                           \
+        __VA_ARGS__;                                                                               \
+        PANTR_REGION(keep_);                                                                       \
+    } while (0)
+#elif defined(PANTR_PHASE_TIMING)
+#define PANTR_REGION(k) do {} while (0)
 #define PANTR_PHASE(idx, ...)                                                                      \
     do {                                                                                           \
         long long t0_ = wall_clock64();                                                            \
@@ -682,6 +702,7 @@ __device__ __forceinline__ bool is_finite(double v) { return fabs(v) < __builtin
         st.phase_s[idx] += (double)(wall_clock64() - t0_) * P.tick_s;                              \
     } while (0)
 #else
+#define PANTR_REGION(k) do {} while (0)
 #define PANTR_PHASE(idx, ...)                                                                    \
     do {                                                                                           \
         __VA_ARGS__;                                                                               \
@@ -768,6 +789,11 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
     // `which` names the iterate whose psi(xhat) and quadratic-upper-bound backtracking are
     // pending: 0 = the initial iterate, 1 = the accepted candidate, 2 = the prox iterate.
     int which = 0;
+#ifdef PANTR_REST_TIMING
+    double rest_bucket_[4] = {0, 0, 0, 0};
+    long long rest_last_ = wall_clock64();
+    int rest_cur_ = 1;
+#endif
     while (status == Busy) {
         // speculation (PB::HAS_SPEC, two-wavefront workgroups): psi(xhat), the bound test, grad_L(xhat)
         // and the tape of a rejected candidate's successor were evaluated by the helper wavefront
@@ -839,6 +865,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
         if (status != Busy)
             break;
 
+        PANTR_REGION(2);
         // ---- forward-backward step: prox iterate xbar = xhat_k, grad via grad_L(xhat) ----
         for (int j = 0; j < nj; ++j) {
             int i = j * WAVE + lane;
@@ -901,6 +928,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
             double r_sq = 0, tolerance = 0, qa = 0;
             int cg_i = 0;
             const int cg_max = (int)lround((double)nJ * P.max_iter_factor);
+            PANTR_REGION(3);
             while (true) {
                 if (state == CGSTART) {
                     // all 64 nj slots: the CG passes below run without bounds checks, the padding of
@@ -1052,6 +1080,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                 q_model = mval; // EVAL_STEP
                 break;
             }
+            PANTR_REGION(1);
             st.cg_iterations += cg_its;
             // full step: Newton part on J, prox step on the active set
             bool fin = true;
@@ -1123,6 +1152,11 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
 
     if constexpr (PB::HAS_SPEC)
         pb.spec_exit();
+#ifdef PANTR_REST_TIMING
+    PANTR_REGION(1);
+    for (int i = 0; i < 4; ++i)
+        st.phase_s[i] += rest_bucket_[i];
+#endif
     // ---- results ----
     if ((status == Converged || status == Interrupted || P.always_overwrite_results) && is_finite(curr.L)) {
         pb.update_multipliers(curr.yh); // err_z = Sigma^{-1} (yhat - y), y <- yhat  (m > 0)
