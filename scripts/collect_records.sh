@@ -1,0 +1,22 @@
+#!/usr/bin/env bash
+# After scripts/gpu_records.sh <tag> ran on the GPU box (gpurun merges its output into gpurun_out/):
+# copies what a round commits into profiles/<tag>_* and digests the profile passes.
+#   scripts/collect_records.sh r03
+set -e
+cd "$(dirname "$0")/.."
+TAG=${1:-r03}
+R=gpurun_out/$TAG
+for f in bench bench_streams4; do
+    [ -s $R/$f.json ] && tail -1 $R/$f.json > profiles/${TAG}_$f.json
+done
+[ -s $R/gpu_tests.log ] && tail -3 $R/gpu_tests.log > profiles/${TAG}_gpu_tests.log
+[ -s $R/phase_timing.txt ] && grep -v amdgpu.ids $R/phase_timing.txt > profiles/${TAG}_phase_timing.txt
+for w in strong_stress strong_sweep weak; do
+    grep '^{' $R/rehearsal_$w.log | tail -1 > profiles/${TAG}_rehearsal_2ranks_$w.json
+done
+grep -v amdgpu.ids $R/saturation.txt > profiles/${TAG}_saturation.txt
+grep -v 'amdgpu.ids\|rocprofv3\|Opened result\|HSA version' $R/rows_workload.txt > profiles/${TAG}_rows_f1_f4_workload.txt
+cp "$(ls -t gpurun_out/prof_rows/*/*_kernel_stats.csv | head -1)" profiles/${TAG}_rows_f1_f4_kernel_stats.csv
+python scripts/summarize_profiles.py $TAG > /dev/null
+python scripts/kernel_resources.py > profiles/${TAG}_kernel_resources.txt 2> /dev/null || true
+ls -la profiles/ | grep ${TAG}_
