@@ -1333,12 +1333,13 @@ struct ScalarALProblem {
 
 /// One instance, start to finish, on the calling wavefront: the body of both ALM kernels.
 template <class M, int METHOD, class PB>
-__device__ __forceinline__ void alm_solve_instance(const AlmSolveArgs &a, PB &pb, int lane, int inst, long long t_start) {
+__device__ __forceinline__ void alm_solve_instance(const AlmSolveArgs &a, PB &pb, int lane, int inst, long long t_start,
+                                                   double *x0_lds) {
     const KernelParams &P    = a.prm;
     const AlmKernelParams &A = a.alm;
     const int n = a.n, m = a.m;
-    if (lane < M::nx)
-        const_cast<double *>(pb.x0)[lane] = a.x0[(size_t)inst * M::nx + lane];
+    if (lane < M::nx) // the problem parameter of this instance (pb.x0 reads it)
+        x0_lds[lane] = a.x0[(size_t)inst * M::nx + lane];
     double *x_io = pb.vec(S_XIO), *y = pb.mvec(PB::MV_Y), *Sig = pb.mvec(PB::MV_SIG), *e1 = pb.mvec(PB::MV_E1),
            *e2 = pb.mvec(PB::MV_E2);
     for (int i = lane; i < n; i += WAVE)
@@ -1438,9 +1439,10 @@ __device__ __forceinline__ void alm_solve_instance(const AlmSolveArgs &a, PB &pb
         pb.spec_shutdown();
 }
 
-/// The solver wavefront's problem object on the workgroup's dynamic LDS (layout: lds_doubles()).
+/// The solver wavefront's problem object on the workgroup's dynamic LDS (layout: lds_doubles()).  Returns
+/// where the instance's initial state goes.
 template <class M, int METHOD, class PB>
-__device__ __forceinline__ void alm_bind(PB &pb, const AlmSolveArgs &a, double *lds, int lane, int inst) {
+__device__ __forceinline__ double *alm_bind(PB &pb, const AlmSolveArgs &a, double *lds, int lane, int inst) {
     pb.lane = lane; pb.box = &a.prm.box; pb.lds = lds; pb.N = a.N; pb.n = a.n; pb.npad = a.npad; pb.nj = a.nj;
     pb.m = a.m; pb.mpad = a.mpad; pb.mj = a.mj;
     pb.mv = lds + (size_t)NUM_VEC * a.npad;
@@ -1453,6 +1455,7 @@ __device__ __forceinline__ void alm_bind(PB &pb, const AlmSolveArgs &a, double *
     // direction computation); the comparators keep L-BFGS scalars in the CG block and get LDS of their own
     pb.coef = x0_lds + PB::X0_DOUBLES;
     pb.scr  = METHOD == 0 ? pb.vec(PB::CG_BASE + 3) : pb.coef + PB::coef_doubles(a.N);
+    return x0_lds;
 }
 
 /// ALM outer loop (m > 0) around the inner solver METHOD names, one wavefront per instance.
@@ -1466,13 +1469,13 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
     const long long t_start = wall_clock64();
     using PB = ScalarALProblem<M>;
     PB pb;
-    alm_bind<M, METHOD>(pb, a, lds, lane, inst);
+    double *x0_lds = alm_bind<M, METHOD>(pb, a, lds, lane, inst);
     pb.tape = a.ws + (size_t)inst * PB::workspace_doubles(a.N);
     const size_t total = PB::lds_doubles(a.N, a.npad, a.mpad, METHOD != 0);
     for (size_t i = lane; i < total; i += WAVE)
         lds[i] = 0.0;
     wave_sync();
-    alm_solve_instance<M, METHOD>(a, pb, lane, inst, t_start);
+    alm_solve_instance<M, METHOD>(a, pb, lane, inst, t_start, x0_lds);
 }
 
 /// method = pantr with a helper wavefront per instance (ScalarALProblem: speculation).  Wavefront 0 is
@@ -1489,7 +1492,7 @@ __global__ __launch_bounds__(2 * WAVE) void pantr_alm_spec_kernel(AlmSolveArgs a
     __shared__ SpecBox box;
     using PB = ScalarALProblem<M, true>;
     PB pb;
-    alm_bind<M, 0>(pb, a, lds, lane, inst);
+    double *x0_lds = alm_bind<M, 0>(pb, a, lds, lane, inst);
     const size_t solver_doubles = PB::lds_doubles(a.N, a.npad, a.mpad, false);
     const size_t total          = solver_doubles + PB::helper_lds_doubles(a.N, a.npad);
     for (size_t i = threadIdx.x; i < total; i += 2 * WAVE)
@@ -1517,7 +1520,7 @@ __global__ __launch_bounds__(2 * WAVE) void pantr_alm_spec_kernel(AlmSolveArgs a
         return;
     }
     __builtin_amdgcn_s_setprio(3);
-    alm_solve_instance<M, 0>(a, pb, lane, inst, t_start);
+    alm_solve_instance<M, 0>(a, pb, lane, inst, t_start, x0_lds);
 }
 
 } // namespace pantr

@@ -11,6 +11,7 @@ from pantr_amd import workloads
 if "+rest-timing" not in pa.version():
     raise SystemExit(f"{pa.LIB_PATH} is not the rest-timing build ({pa.version()})")
 
+N = int(os.environ.get("HORIZON", "60"))
 for problem in sys.argv[1:] or ["quadcopter", "realistic_quadcopter", "hanging_chain"]:
     if problem == "hanging_chain":
         d = np.load(os.path.join(ROOT, "tests/golden/mpc_hanging_chain_N60_warm300.npz"))
@@ -18,12 +19,12 @@ for problem in sys.argv[1:] or ["quadcopter", "realistic_quadcopter", "hanging_c
         b = pa.PantrBatch(problem, 60, 600, opts=pa.DODO_PANTR_OPTS + ("alm.max_time=3s",))
         st = b.solve(x0, u0)[-1].ravel()
     else:
-        w = workloads.closed_loop_batch(problem, 60)
-        b = pa.PantrBatch(problem, 60, len(w["x0"]), opts=w["opts"])
+        w = workloads.closed_loop_batch(problem, N)
+        b = pa.PantrBatch(problem, N, len(w["x0"]), opts=w["opts"])
         st = b.solve_al(w["x0"], w["u0"], w["y0"])[-1].ravel()
     i = int(np.argmax(st["elapsed_s"])); s = st[i]; it = int(s["iterations"])
     ph = s["phase_s"]
-    print(f"{problem} ({b.kernel_name()}): slowest instance {i}: {s['elapsed_s']*1e3:.1f} ms, {it} iterations, {s['cg_iterations']} CG iterations")
+    print(f"{problem} N={60 if problem == 'hanging_chain' else N} ({b.kernel_name()}), pass {b.last_kernel_ms():.2f} ms: slowest instance {i}: {s['elapsed_s']*1e3:.1f} ms, {it} iterations, {s['cg_iterations']} CG iterations")
     print(f"   per iteration, us: evaluations {ph[0]/it*1e6:.1f} | end of the CG loop .. stop criterion {ph[1]/it*1e6:.1f} | prox iterate .. CG start {ph[2]/it*1e6:.1f} "
           f"| CG algebra {ph[3]/it*1e6:.1f} ({ph[3]/max(int(s['cg_iterations']),1)*1e6:.2f} per CG iteration, two clock reads included)")
     b.close()
