@@ -112,6 +112,39 @@ def test_solve_iterates_match_oracle(rng, N):
         assert st["final_psi"][b] == st_o["final_psi"]
 
 
+@pytest.mark.parametrize("N", [1, 2, 3])
+@pytest.mark.parametrize("spec", ["on", "off"])
+def test_smallest_horizons_solve_like_the_oracle(rng, N, spec):
+    """The stage loops are unrolled by two and prefetch a stage ahead: horizons of one, two and three stages
+    through both solve kernels (one and two wavefronts per instance)."""
+    B = 3
+    x0s = np.vstack([disturbed_state()[None, :], random_states(rng, B - 1, 0.02)])
+    u0s = np.vstack([np.zeros((1, NU * N)), random_inputs(rng, B - 1, N, -0.3, 0.3)])
+    b = pa.PantrBatch("hanging_chain", N, B, opts=tuple(pa.DODO_PANTR_OPTS) + (f"speculation={spec}",))
+    assert ("spec" in b.kernel_name()) == (spec == "on")
+    u, st = b.solve(x0s, u0s)
+    b.close()
+    prm = ob.dodo_params()
+    for i in range(B):
+        u_o, st_o, _ = ob.solve(N, x0s[i], u0s[i], prm)
+        assert st["status"][i] == st_o["status"]
+        for key in ("iterations", "cg_iterations", "accepted", "rejected", "n_psi", "n_psi_grad_psi", "n_grad_L",
+                    "n_hess_psi_prod"):
+            assert st[key][i] == st_o[key], key
+        assert np.array_equal(u[i], u_o) and st["eps"][i] == st_o["eps"]
+
+
+def test_sizes_outside_the_limits_are_refused():
+    """n = nu N <= 2048 (32 elements per lane); 1 <= B <= max_instances."""
+    with pytest.raises(pa.PantrError, match="horizon too long"):
+        pa.PantrBatch("hanging_chain", 683, 1)                  # n = 2049
+    b = pa.PantrBatch("hanging_chain", 5, 2)
+    for B in (0, 3):
+        with pytest.raises(pa.PantrError, match="batch size"):
+            b.solve(np.zeros((B, NX)), np.zeros((B, 15)))
+    b.close()
+
+
 def test_solve_status_codes(rng):
     """max_iter exhaustion gives MaxIter (negative runtime in the reference, mpc-driver.cpp:219-221)."""
     N = 22

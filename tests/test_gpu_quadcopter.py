@@ -82,6 +82,24 @@ def test_alm_solve_matches_oracle(rng, problem, N):
         assert st["eps"][i] <= 1e-8 and st["delta"][i] <= 1e-8
 
 
+@pytest.mark.parametrize("problem", ["quadcopter", "realistic_quadcopter"])
+@pytest.mark.parametrize("N", [1, 2])
+def test_smallest_horizons_solve_like_the_oracle(rng, problem, N):
+    """One- and two-stage horizons through the ALM kernel `speculation=auto` selects (two wavefronts)."""
+    B = 2
+    b = pa.PantrBatch(problem, N, B, opts=quad_opts(problem))
+    x0 = np.vstack([ob.quad_initial_state(), ob.quad_initial_state() + 0.02 * rng.standard_normal((B - 1, 9))])
+    u0 = np.tile(ob.quad_initial_guess(N), (B, 1))
+    u, y, st = b.solve_al(x0, u0)
+    b.close()
+    for i in range(B):
+        u_o, y_o, st_o = ob.quad_solve(problem, N, x0[i], u0[i])
+        assert st["status"][i] == st_o["status"]
+        for key in ("outer_iterations", "iterations", "cg_iterations", "n_hess_psi_prod", "n_psi", "n_grad_L"):
+            assert st[key][i] == st_o[key], key
+        assert np.array_equal(u[i], u_o) and np.array_equal(y[i], y_o)
+
+
 @pytest.mark.parametrize("problem,N", [("quadcopter", 12), ("realistic_quadcopter", 20), ("realistic_quadcopter", 60)])
 def test_speculation_changes_nothing_but_time(rng, problem, N):
     """Two wavefronts per instance (pantr_alm_spec_kernel: the helper evaluates the successor of a rejected
