@@ -42,7 +42,7 @@ def test_problem_data(problem):
 
 
 @pytest.mark.parametrize("problem", ["quadcopter", "realistic_quadcopter"])
-@pytest.mark.parametrize("N", [1, 7, 30, 64, 70])  # 64 | 70: one full block of stages per wavefront scan | a carry into a second
+@pytest.mark.parametrize("N", [1, 7, 30, 64, 70, 110])  # 64 | 70: one full block of stages per wavefront scan | a carry into a second; 110: 155 KiB of the 160 KiB LDS (realistic_quadcopter)
 def test_psi_grad_hess_prod_match_oracle(rng, problem, N):
     B, n, m = 3, 4 * N, 4 * N + 4
     b = pa.PantrBatch(problem, N, B)
