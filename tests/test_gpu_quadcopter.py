@@ -82,6 +82,22 @@ def test_alm_solve_matches_oracle(rng, problem, N):
         assert st["eps"][i] <= 1e-8 and st["delta"][i] <= 1e-8
 
 
+def test_longest_realistic_quadcopter_horizon_solves_like_the_oracle():
+    """N = 110: 155 KiB of the CU's 160 KiB LDS (the two-wavefront kernel does not fit: one wavefront), two
+    blocks of 64 stages in every scan; one cold ALM solve - thousands of PANTR iterations - bit for bit."""
+    problem, N = "realistic_quadcopter", 110
+    b = pa.PantrBatch(problem, N, 1, opts=quad_opts(problem))
+    assert "spec" not in b.kernel_name()
+    x0, u0 = ob.quad_initial_state()[None, :], ob.quad_initial_guess(N)[None, :]
+    u, y, st = b.solve_al(x0, u0)
+    b.close()
+    u_o, y_o, st_o = ob.quad_solve(problem, N, x0[0], u0[0])
+    assert st["status"][0] == st_o["status"] == 1
+    for key in ("outer_iterations", "iterations", "cg_iterations", "n_hess_psi_prod", "n_psi", "n_grad_L"):
+        assert st[key][0] == st_o[key], key
+    assert np.array_equal(u[0], u_o) and np.array_equal(y[0], y_o)
+
+
 @pytest.mark.parametrize("problem", ["quadcopter", "realistic_quadcopter"])
 @pytest.mark.parametrize("N", [1, 2])
 def test_smallest_horizons_solve_like_the_oracle(rng, problem, N):
