@@ -56,6 +56,14 @@ typedef struct pantr_stats {
     int32_t n_psi, n_grad_psi, n_psi_grad_psi, n_grad_L, n_hess_psi_prod, n_prox_grad_step;
     int32_t outer_iterations;           /* ALM iterations (1 when m = 0) */
     int32_t inner_convergence_failures; /* inner solves that did not reach their tolerance */
+    /* n_hess_psi_prod counts the Hessian-vector products EVALUATED (what the byte model of the roofline
+     * uses).  n_hess_psi_prod_calls is what alpaqa's EvalCounter would show (drivers/results.hpp:63-87,
+     * summed by new-benchmarks-paper/benchmark_util.py:12-27): it also counts the products with q_K = 0
+     * that the direction skips because their result is exactly zero. */
+    int32_t n_hess_psi_prod_calls;
+    /* two-wavefront kernels (speculation): requests whose result the solver wavefront stopped waiting for
+     * (it evaluates the step itself and posts no further requests); 0 in a healthy run */
+    int32_t spec_timeouts;
     double delta;                       /* ||Sigma^{-1}(yhat - y)||_inf at exit (0 when m = 0) */
     double penalty_norm;                /* ||Sigma||_2 / sqrt(m) at exit */
     /* method=panoc, strucpanoc (alpaqa::PANOCStats; qub_backtracks above = stepsize_backtracks) */

@@ -70,6 +70,9 @@ struct Stats {
     int iterations = 0, cg_iterations = 0, accepted = 0, rejected = 0, qub_backtracks = 0;
     long n_psi = 0, n_grad_psi = 0, n_psi_grad_psi = 0, n_grad_L = 0, n_hess_psi_prod = 0,
          n_prox_grad_step = 0;
+    /// n_hess_psi_prod + the products with q_K = 0 the direction skips: what alpaqa's EvalCounter would show
+    /// (drivers/results.hpp:63-87 writes it, benchmark_util.py:12-27 sums it)
+    long n_hess_psi_prod_calls = 0;
     double eps = NaN, final_gamma = NaN, final_psi = NaN, final_fbe = NaN, final_radius = NaN;
     double elapsed_s = 0;
     // ALM
@@ -201,6 +204,7 @@ struct PANTRSolver {
         problem.set_al(y, Sigma);
         Stats s;
         const EvalCounters c0 = problem.cnt;
+        long skipped_products = 0; // H q_K with q_K = 0: alpaqa would call the function (n_hess_psi_prod_calls)
         Iterate it0(n, m), it1(n, m), it2(n, m);
         Iterate *curr = &it0, *prox = &it1, *cand = &it2;
         std::vector<double> q(n), work(n), work2(n), rJ(n), wz(n), wr(n), wd(n), wBd(n), wev(n),
@@ -246,6 +250,7 @@ struct PANTRSolver {
             s.n_psi_grad_psi   = c.psi_grad_psi - c0.psi_grad_psi;
             s.n_grad_L         = c.grad_L - c0.grad_L;
             s.n_hess_psi_prod  = c.hess_psi_prod - c0.hess_psi_prod;
+            s.n_hess_psi_prod_calls = s.n_hess_psi_prod + skipped_products;
             s.n_prox_grad_step = c.prox_grad_step - c0.prox_grad_step;
             s.elapsed_s        = std::chrono::duration<double>(clk::now() - t0).count();
             return s;
@@ -341,6 +346,8 @@ struct PANTRSolver {
                 bool qK_zero = true;
                 for (int i = 0; i < n; ++i)
                     qK_zero = qK_zero && q[i] == 0.0;
+                if (dir_params.hessian_vec_factor != 0 && any_K && qK_zero)
+                    ++skipped_products;
                 if (dir_params.hessian_vec_factor != 0 && any_K && !qK_zero) {
                     problem.eval_hess_psi_prod(prox->x.data(), q.data(), work.data());
                     for (int i = 0; i < n; ++i)
@@ -456,6 +463,7 @@ Stats alm_solve(const ALMParams &alm, const Inner &inner, Problem &problem, doub
         total.qub_backtracks += ps.qub_backtracks;
         total.n_psi += ps.n_psi; total.n_grad_psi += ps.n_grad_psi; total.n_psi_grad_psi += ps.n_psi_grad_psi;
         total.n_grad_L += ps.n_grad_L; total.n_hess_psi_prod += ps.n_hess_psi_prod;
+        total.n_hess_psi_prod_calls += ps.n_hess_psi_prod_calls;
         total.n_prox_grad_step += ps.n_prox_grad_step;
         total.linesearch_failures += ps.linesearch_failures; total.linesearch_backtracks += ps.linesearch_backtracks;
         total.lbfgs_failures += ps.lbfgs_failures; total.lbfgs_rejected += ps.lbfgs_rejected;

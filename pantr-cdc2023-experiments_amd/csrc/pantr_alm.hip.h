@@ -1123,6 +1123,7 @@ struct ScalarALProblem {
     double *tape0 = nullptr; ///< HBM: the first of this instance's two tape buffers
     int tape_cur  = 0;       ///< which of them `tape` is
     bool spec_pending = false, spec_dead = false;
+    int spec_timeouts = 0; ///< results this wavefront stopped waiting for (stats.spec_timeouts)
     double spec_tick_s = 1e-8, spec_patience_s = 1.0;
 
     __device__ __forceinline__ void spec_request(int xh_slot, double psi_x, double gradTp, double pTp, double Lip,
@@ -1142,10 +1143,16 @@ struct ScalarALProblem {
     __device__ __forceinline__ bool spec_wait() {
         const int want = __hip_atomic_load(&spec->req_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const long long t0 = wall_clock64();
-        while (__hip_atomic_load(&spec->done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) {
+        // (spec_patience = 0: the first result asked for counts as late whether it is there or not - how the tests
+        // reach this path; the helper is normally done long before the solver asks)
+        while (!(spec_patience_s > 0) ||
+               __hip_atomic_load(&spec->done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) {
             __builtin_amdgcn_s_sleep(2);
             if ((double)(wall_clock64() - t0) * spec_tick_s > spec_patience_s) {
-                spec_dead = true;
+                spec_dead = true; // no further requests; the helper ends at its next look at the flag
+                ++spec_timeouts;
+                if (lane == 0)
+                    __hip_atomic_store(&spec->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return false;
             }
         }
@@ -1193,15 +1200,18 @@ struct ScalarALProblem {
     /// The helper wavefront (`this`: its own X, Xt, TG, scr, coef; the solver's vectors and m-vectors).
     __device__ __forceinline__ void spec_serve(long long t_start, double tick_s, double give_up_s) {
         int seen = 0;
+        auto aborted = [&]() {
+            return uniform(__hip_atomic_load(&spec->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0;
+        };
         while (true) {
             int r;
             while ((r = __hip_atomic_load(&spec->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == seen) {
                 __builtin_amdgcn_s_sleep(8);
-                if ((double)(wall_clock64() - t_start) * tick_s > give_up_s)
+                if (aborted() || (double)(wall_clock64() - t_start) * tick_s > give_up_s)
                     return;
             }
             seen = r;
-            if (uniform(spec->cmd) == SPEC_EXIT)
+            if (uniform(spec->cmd) == SPEC_EXIT || aborted())
                 return;
             const double *xh = ivec(uniform(spec->xh_slot));
             const int yh     = uniform(spec->yh_slot);
@@ -1212,6 +1222,8 @@ struct ScalarALProblem {
             const double margin = (1.0 + fabs(psi_x)) * uniform(spec->qub_factor);
             const bool violated = psi_xh > ((psi_x + gradTp) + (0.5 * Lip) * pTp) + margin;
             const bool ok       = !(Lip < uniform(spec->L_max) && violated);
+            if (aborted()) // the solver stopped waiting (and evaluates this itself): nothing of the result is used
+                return;
             if (ok)
                 eval_grad_xhat(xh, hG, yh);
             wave_sync(); // gradient, yhat and (acknowledged) tape are written before the result is announced
@@ -1433,6 +1445,8 @@ __device__ __forceinline__ void alm_solve_instance(const AlmSolveArgs &a, PB &pb
         st.inner_convergence_failures = failures;
         st.delta                      = norm_e2;
         st.penalty_norm               = __builtin_sqrt(sq / m);
+        if constexpr (PB::HAS_SPEC)
+            st.spec_timeouts = pb.spec_timeouts;
         write_stats(a.stats + inst, st);
     }
     if constexpr (PB::HAS_SPEC)
@@ -1461,7 +1475,7 @@ __device__ __forceinline__ double *alm_bind(PB &pb, const AlmSolveArgs &a, doubl
 /// ALM outer loop (m > 0) around the inner solver METHOD names, one wavefront per instance.
 template <class M, int METHOD>
 __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     if (inst >= a.B)
@@ -1483,7 +1497,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
 /// solver's (helper_lds_doubles) and on the instance's second tape buffer.
 template <class M>
 __global__ __launch_bounds__(2 * WAVE) void pantr_alm_spec_kernel(AlmSolveArgs a) {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
     const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     if (inst >= a.B)
@@ -1501,10 +1515,12 @@ __global__ __launch_bounds__(2 * WAVE) void pantr_alm_spec_kernel(AlmSolveArgs a
         box.req_seq  = 0;
         box.done_seq = 0;
         box.cmd      = 0;
+        box.abort    = 0;
     }
     __syncthreads(); // the only workgroup barrier: LDS is cleared and the mailbox exists
     pb.spec        = &box;
     pb.spec_tick_s = a.prm.tick_s;
+    pb.spec_patience_s = a.prm.spec_patience_s;
     pb.tape0       = a.ws + (size_t)inst * 2 * PB::workspace_doubles(a.N);
     pb.tape        = pb.tape0;
     double *h      = lds + solver_doubles; // the helper's LDS
@@ -1551,7 +1567,7 @@ struct AlmEvalArgs {
 
 template <class M>
 __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x, inst = blockIdx.x;
     if (inst >= a.B)
         return;

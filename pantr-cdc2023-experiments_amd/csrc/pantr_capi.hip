@@ -202,6 +202,7 @@ KernelParams to_kernel_params(const SolverOptions &o, double tick_s, const BoxDa
     KernelParams k{};
     k.tick_s = tick_s;
     k.solver_max_time_s = o.solver.max_time;
+    k.spec_patience_s   = o.spec_patience;
     const auto &s = o.solver;
     k.L_0 = s.Lipschitz.L_0; k.lip_eps = s.Lipschitz.epsilon; k.lip_delta = s.Lipschitz.delta;
     k.Lgamma_factor = s.Lipschitz.Lgamma_factor;
@@ -302,6 +303,18 @@ bool use_speculation(const pantr_batch *b, int32_t B) {
     return (size_t)B <= per_cu * (size_t)b->num_cus;
 }
 
+/// `residency=k`: the dynamic LDS a launch asks for so that at most k workgroups fit the 160 KiB of a
+/// compute unit (never less than the kernel needs; k = 0: exactly what it needs).
+size_t residency_lds(const pantr_batch *b, size_t dyn_bytes, size_t static_bytes) {
+    const int k = b->opts.residency;
+    if (k <= 0)
+        return dyn_bytes;
+    const size_t cu = 160 * 1024, gran = 1280; // allocation granularity of the LDS (bytes), rounded up generously
+    const size_t per_wg = cu / (size_t)(k + 1) + gran; // k + 1 of these no longer fit
+    const size_t want = per_wg > static_bytes ? per_wg - static_bytes : 0;
+    return std::min(std::max(dyn_bytes, want), cu - static_bytes);
+}
+
 int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, double *d_y,
                  DeviceStats *d_stats, hipStream_t stream) {
     if (int rc = check_supported(b->opts))
@@ -366,11 +379,19 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
     if (method != 0 && b->lds_bytes + WaveProblem<ChainModel>::tape_lds_bytes() > 160 * 1024)
         return fail(PANTR_ERR_OUT_OF_RANGE, "horizon too long for method=panoc|strucpanoc: their vectors do not fit the 160 KiB LDS");
     HIP_TRY(hipEventRecord(b->ev_start, stream));
-    if (method == 0 && use_speculation(b, B))
-        hipLaunchKernelGGL(pantr_solve_spec_kernel<ChainModel>, dim3(B), dim3(2 * WAVE), spec_lds_bytes(*b), stream, a);
-    else if (method == 0)
-        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 0>), dim3(B), dim3(WAVE), b->lds_bytes_pantr, stream, a);
-    else if (method == 1)
+    if (method == 0 && use_speculation(b, B)) {
+        const size_t lds = residency_lds(b, spec_lds_bytes(*b), 2 * WaveProblem<ChainModel>::tape_lds_bytes() + sizeof(SpecBox));
+        if (b->opts.residency > 0)
+            if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(&pantr_solve_spec_kernel<ChainModel>), lds))
+                return rc;
+        hipLaunchKernelGGL(pantr_solve_spec_kernel<ChainModel>, dim3(B), dim3(2 * WAVE), lds, stream, a);
+    } else if (method == 0) {
+        const size_t lds = residency_lds(b, b->lds_bytes_pantr, WaveProblem<ChainModel>::tape_lds_bytes());
+        if (b->opts.residency > 0)
+            if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(&pantr_solve_kernel<ChainModel, 0>), lds))
+                return rc;
+        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 0>), dim3(B), dim3(WAVE), lds, stream, a);
+    } else if (method == 1)
         hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 1>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
     else
         hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 2>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);

@@ -53,6 +53,7 @@ struct KernelParams {
     double initial_radius, min_radius;
     double hessian_vec_factor, tol_scale, tol_scale_root, tol_max, max_iter_factor;
     double tolerance;
+    double spec_patience_s;   ///< speculation: how long the solver wavefront waits for a result (`spec_patience=`)
     double solver_max_time_s; ///< solver.max_time alone (max_time_s above = min(solver.max_time, alm.max_time))
     double tick_s;            ///< seconds per wall_clock64() tick (hipDeviceAttributeWallClockRate)
     // PANOC line search and L-BFGS (method = panoc, strucpanoc; panoc_kernel.hip.h)
@@ -69,6 +70,8 @@ struct DeviceStats {
     int32_t status, iterations, cg_iterations, accepted, rejected, qub_backtracks;
     int32_t n_psi, n_grad_psi, n_psi_grad_psi, n_grad_L, n_hess_psi_prod, n_prox_grad_step;
     int32_t outer_iterations, inner_convergence_failures; ///< ALM
+    int32_t n_hess_psi_prod_calls; ///< n_hess_psi_prod + the zero products the direction skips (alpaqa's count)
+    int32_t spec_timeouts;         ///< speculation: results the solver wavefront stopped waiting for
     double delta, penalty_norm;                           ///< ||Sigma^{-1}(yhat - y)||_inf, ||Sigma|| / sqrt(m)
     int32_t linesearch_failures, linesearch_backtracks, lbfgs_failures, lbfgs_rejected, tau_1_accepted,
         count_tau; ///< PANOC
@@ -88,6 +91,7 @@ __device__ __forceinline__ void write_stats(DeviceStats *o, const DeviceStats &s
     o->n_psi = s.n_psi; o->n_grad_psi = s.n_grad_psi; o->n_psi_grad_psi = s.n_psi_grad_psi;
     o->n_grad_L = s.n_grad_L; o->n_hess_psi_prod = s.n_hess_psi_prod; o->n_prox_grad_step = s.n_prox_grad_step;
     o->outer_iterations = s.outer_iterations; o->inner_convergence_failures = s.inner_convergence_failures;
+    o->n_hess_psi_prod_calls = s.n_hess_psi_prod_calls; o->spec_timeouts = s.spec_timeouts;
     o->delta = s.delta; o->penalty_norm = s.penalty_norm;
     o->linesearch_failures = s.linesearch_failures; o->linesearch_backtracks = s.linesearch_backtracks;
     o->lbfgs_failures = s.lbfgs_failures; o->lbfgs_rejected = s.lbfgs_rejected;
@@ -137,8 +141,9 @@ struct SolveArgs {
 // dropped.  Both wavefronts run the same device functions on the same inputs, so a taken result has
 // the bits the main wavefront would have produced.  Mailbox in LDS; sequence numbers written with
 // release, read with acquire semantics at workgroup scope.
-struct SpecBox {
+struct alignas(16) SpecBox { // a multiple of 16 bytes: the dynamic LDS behind it stays 16-byte aligned
     int req_seq, done_seq; ///< main: requests posted; helper: requests finished
+    int abort;             ///< main: it stopped waiting for a result - the helper ends at its next check
     int cmd;               ///< SPEC_EVAL | SPEC_EXIT
     int xh_slot;           ///< iterate vector (pb.ivec index) holding the point to evaluate: xhat of the prox iterate
     int yh_slot;           ///< problems with general constraints: the m-vector that receives yhat there
@@ -188,6 +193,7 @@ struct WaveProblem {
     mutable int tape_cur = 0;               ///< which of the two `tape` is
     mutable bool spec_pending = false;      ///< a request is out whose result has been neither taken nor dropped
     mutable bool spec_dead = false;         ///< the helper missed a deadline: no further requests
+    mutable int spec_timeouts = 0;          ///< how often that happened (stats.spec_timeouts)
     double spec_tick_s = 1e-8, spec_patience_s = 1.0; ///< clock period; how long the main wavefront waits for a result
 #ifdef PANTR_PHASE_TIMING
     mutable long long fwd_cycles = 0; ///< profiling build: shader cycles spent in the forward half of the products
@@ -293,10 +299,16 @@ struct WaveProblem {
     __device__ __forceinline__ bool spec_wait() const {
         const int want = __hip_atomic_load(&spec->req_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const long long t0 = wall_clock64();
-        while (__hip_atomic_load(&spec->done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) {
+        // (spec_patience = 0: the first result asked for counts as late whether it is there or not - how the tests
+        // reach this path; the helper is normally done long before the solver asks)
+        while (!(spec_patience_s > 0) ||
+               __hip_atomic_load(&spec->done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) {
             __builtin_amdgcn_s_sleep(2);
             if ((double)(wall_clock64() - t0) * spec_tick_s > spec_patience_s) {
-                spec_dead = true; // no further requests (the helper ends on SPEC_EXIT or on its own clock)
+                spec_dead = true; // no further requests; the helper ends at its next look at the flag
+                ++spec_timeouts;
+                if (L.l == 0)
+                    __hip_atomic_store(&spec->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return false;
             }
         }
@@ -382,16 +394,19 @@ struct WaveProblem {
     /// object: its own LDS vectors and exchange row, X = helper_X(), the same iterate vectors and tapes.
     __device__ __forceinline__ void spec_serve(const KernelParams &P, long long t_start) {
         int seen = 0;
+        auto aborted = [&]() {
+            return uniform(__hip_atomic_load(&spec->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0;
+        };
         while (true) {
             int r;
             while ((r = __hip_atomic_load(&spec->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == seen) {
                 __builtin_amdgcn_s_sleep(8);
-                if ((double)(wall_clock64() - t_start) * P.tick_s > 2.0 * P.max_time_s + 1.0)
+                if (aborted() || (double)(wall_clock64() - t_start) * P.tick_s > 2.0 * P.max_time_s + 1.0)
                     return;
             }
             seen = r;
             const int cmd = uniform(spec->cmd);
-            if (cmd == SPEC_EXIT)
+            if (cmd == SPEC_EXIT || aborted())
                 return;
             if (cmd == SPEC_MODEL) {
                 const double *p = wg_lds + uniform(spec->p_off), *rJ = wg_lds + uniform(spec->rj_off);
@@ -416,6 +431,8 @@ struct WaveProblem {
             const double margin = (1.0 + fabs(psi_x)) * uniform(spec->qub_factor);
             const bool violated = psi_xh > ((psi_x + gradTp) + (0.5 * Lip) * pTp) + margin;
             const bool ok       = !(Lip < uniform(spec->L_max) && violated);
+            if (aborted()) // the solver stopped waiting (and evaluates this itself): nothing of the result is used
+                return;
             if (ok)
                 grad_reverse<true>(xh, helper_G());
             wave_sync(); // the gradient and the tape rows are written (and acknowledged) before the result is announced
@@ -924,6 +941,8 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                 return false;
             };
             int state = (P.hessian_vec_factor != 0 && nJ < n && !skip_kterm) ? KTERM : CGSTART;
+            if (P.hessian_vec_factor != 0 && nJ < n && skip_kterm)
+                ++st.n_hess_psi_prod_calls; // alpaqa would call hess_psi_prod here (and get zero)
             const double *vin = q;
             double r_sq = 0, tolerance = 0, qa = 0;
             int cg_i = 0;
@@ -960,6 +979,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                 // the one Hessian-vector product site: work = H(xbar) * vin (tape replay)
                 PANTR_PHASE(PH_DIRECTION, pb.hess_prod(X_(prox), vin, work));
                 ++st.n_hess_psi_prod;
+                ++st.n_hess_psi_prod_calls;
                 if (state == KTERM) {
                     for (int j = 0; j < nj; ++j) {
                         int i = j * WAVE + lane;
@@ -1031,6 +1051,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                             }
                             if ((model_deferred = defer_model())) {
                                 ++st.n_hess_psi_prod;
+                                ++st.n_hess_psi_prod_calls;
                                 break;
                             }
                             state = EVAL_STEP;
@@ -1041,6 +1062,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                     if (__builtin_sqrt(r_next_sq) < tolerance || cg_i > cg_max) {
                         if ((model_deferred = defer_model())) {
                             ++st.n_hess_psi_prod;
+                            ++st.n_hess_psi_prod_calls;
                             break;
                         }
                         state = EVAL_STEP;
@@ -1232,13 +1254,14 @@ __device__ __forceinline__ void solve_chain_instance(const SolveArgs &a, PB &pb,
         st.elapsed_s    = (double)(wall_clock64() - t_start) * P.tick_s;
         st.outer_iterations = 1;
         st.inner_convergence_failures = r.status == Converged ? 0 : 1;
+        st.spec_timeouts = pb.spec_timeouts;
         write_stats(a.stats + inst, st);
     }
 }
 
 template <class M, int METHOD>
 __global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // <= 256 VGPRs: two wavefronts per SIMD (uncapped it would take 260)
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     if (inst >= a.B)
@@ -1267,7 +1290,7 @@ __host__ __device__ constexpr size_t spec_lds_doubles(size_t npad) {
 }
 template <class M>
 __global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs a) {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
     const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     if (inst >= a.B)
@@ -1290,10 +1313,12 @@ __global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs
     pb.wg_lds = lds;
     pb.spec   = &box;
     pb.spec_tick_s = a.prm.tick_s;
+    pb.spec_patience_s = a.prm.spec_patience_s;
     if (threadIdx.x == 0) {
         box.req_seq = 0;
         box.done_seq = 0;
         box.cmd = 0;
+        box.abort = 0;
     }
     __syncthreads(); // the only workgroup barrier: the mailbox exists before either wavefront reads it
     if (wave == 1) {
@@ -1332,7 +1357,7 @@ struct EvalArgs {
 
 template <class M>
 __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x, inst = blockIdx.x;
     if (inst >= a.B)
         return;

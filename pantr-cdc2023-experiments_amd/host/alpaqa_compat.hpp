@@ -70,11 +70,14 @@ struct EvalCounter {
              f_grad_f = 0, f_g = 0, grad_f_grad_g_prod = 0, g = 0, grad_g_prod = 0, grad_gi = 0,
              grad_L = 0, hess_L_prod = 0, hess_L = 0, hess_psi_prod = 0, hess_psi = 0, psi = 0,
              grad_psi = 0, psi_grad_psi = 0;
+    /// not an alpaqa field: the products the device evaluated (pantr_stats_t::n_hess_psi_prod)
+    unsigned hess_psi_prod_evaluated = 0;
     void reset() { *this = {}; }
     void add(const pantr_stats_t &s) {
         prox_grad_step += s.n_prox_grad_step;
         grad_L += s.n_grad_L;
-        hess_psi_prod += s.n_hess_psi_prod;
+        hess_psi_prod += s.n_hess_psi_prod_calls; // alpaqa counts the call, also where the product is known to be zero
+        hess_psi_prod_evaluated += s.n_hess_psi_prod;
         psi += s.n_psi;
         grad_psi += s.n_grad_psi;
         psi_grad_psi += s.n_psi_grad_psi;

@@ -180,6 +180,15 @@ struct SolverOptions {
     /// quadcopter family).  Same results either way; auto = on for batches small enough to leave the GPU's
     /// SIMDs idle otherwise.  -1 auto, 0 off, 1 on.
     int32_t speculation = -1;
+    /// `residency=auto|<k>` (an option of this implementation): at most k workgroups of a solve kernel resident
+    /// per compute unit (the launch asks for as much LDS as leaves room for k).  Large batches stream their
+    /// second-order tapes; fewer instances in flight keep that working set inside the 256 MiB Infinity Cache.
+    /// 0 = auto (what the LDS of the kernel allows).  Same results either way.
+    int32_t residency = 0;
+    /// `spec_patience=<duration>` (an option of this implementation): how long a solver wavefront waits for a
+    /// result of its helper before it evaluates the step itself, tells the helper to stop and posts no further
+    /// requests (pantr_stats_t::spec_timeouts counts these).  Same results either way.
+    double spec_patience = 1.0;
     PANTRParams solver;
     NewtonTRDirectionParams dir;
     SteihaugCGParams accel;
@@ -416,6 +425,22 @@ inline SetResult set_option(SolverOptions &o, std::string_view kv, std::string &
         err = "Invalid value '" + std::string(v) + "' for 'speculation' (auto, on, off)";
         return SetResult::BadValue;
     }
+    if (kv.substr(0, 14) == "spec_patience=") {
+        if (parse_duration(kv.substr(14), o.spec_patience) && o.spec_patience >= 0)
+            return SetResult::Ok;
+        err = "Invalid value '" + std::string(kv.substr(14)) + "' for 'spec_patience' (a duration, e.g. 500ms)";
+        return SetResult::BadValue;
+    }
+    if (kv.substr(0, 10) == "residency=") {
+        std::string_view v = kv.substr(10);
+        int32_t k = 0;
+        if (v == "auto" || (parse_int(v, k) && k >= 0 && k <= 32)) {
+            o.residency = v == "auto" ? 0 : k;
+            return SetResult::Ok;
+        }
+        err = "Invalid value '" + std::string(v) + "' for 'residency' (auto, or workgroups per compute unit 1..32)";
+        return SetResult::BadValue;
+    }
     auto eq = kv.find('=');
     if (eq == std::string_view::npos) {
         auto dot = kv.find('.');
@@ -458,6 +483,14 @@ inline bool get_option(const SolverOptions &o, std::string_view key, double &out
     }
     if (key == "speculation") {
         out = o.speculation;
+        return true;
+    }
+    if (key == "residency") {
+        out = o.residency;
+        return true;
+    }
+    if (key == "spec_patience") {
+        out = o.spec_patience;
         return true;
     }
     FieldRef ref{};

@@ -84,7 +84,8 @@ inline void write_evaluations(std::ostream &os, const alpaqa::EvalCounter &e) {
     dict_elem(os, "grad_L", e.grad_L);
     dict_elem(os, "hess_L_prod", e.hess_L_prod);
     dict_elem(os, "hess_L", e.hess_L);
-    dict_elem(os, "hess_ψ_prod", e.hess_psi_prod);
+    dict_elem(os, "hess_ψ_prod", e.hess_psi_prod); // alpaqa's convention: calls (pantr_stats_t::n_hess_psi_prod_calls)
+    dict_elem(os, "hess_ψ_prod_evaluated", e.hess_psi_prod_evaluated); // not an alpaqa key: products the device evaluated
     dict_elem(os, "hess_ψ", e.hess_psi);
     dict_elem(os, "ψ", e.psi);
     dict_elem(os, "grad_ψ", e.grad_psi);

@@ -58,7 +58,8 @@ class PantrStats(C.Structure):
                                     "rejected", "qub_backtracks", "n_psi", "n_grad_psi",
                                     "n_psi_grad_psi", "n_grad_L", "n_hess_psi_prod",
                                     "n_prox_grad_step", "outer_iterations",
-                                    "inner_convergence_failures")] + \
+                                    "inner_convergence_failures", "n_hess_psi_prod_calls",
+                                    "spec_timeouts")] + \
                [(k, _dbl) for k in ("delta", "penalty_norm")] + \
                [(k, _i32) for k in ("linesearch_failures", "linesearch_backtracks", "lbfgs_failures",
                                     "lbfgs_rejected", "tau_1_accepted", "count_tau")] + \
@@ -71,7 +72,8 @@ STATS_DTYPE = np.dtype([(k, np.float64) for k in ("eps", "final_gamma", "final_p
                                                 "accepted", "rejected", "qub_backtracks", "n_psi",
                                                 "n_grad_psi", "n_psi_grad_psi", "n_grad_L",
                                                 "n_hess_psi_prod", "n_prox_grad_step",
-                                                "outer_iterations", "inner_convergence_failures")] +
+                                                "outer_iterations", "inner_convergence_failures",
+                                                "n_hess_psi_prod_calls", "spec_timeouts")] +
                        [(k, np.float64) for k in ("delta", "penalty_norm")] +
                        [(k, np.int32) for k in ("linesearch_failures", "linesearch_backtracks",
                                                 "lbfgs_failures", "lbfgs_rejected", "tau_1_accepted",

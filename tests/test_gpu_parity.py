@@ -98,7 +98,7 @@ def test_solve_iterates_match_oracle(rng, N):
         u_o, st_o, tr_o = ob.solve(N, x0s[b], u0s[b], prm, trace_cap=400)
         assert st["status"][b] == st_o["status"] == 1
         for key in ("iterations", "cg_iterations", "accepted", "rejected", "qub_backtracks",
-                    "n_psi", "n_grad_psi", "n_psi_grad_psi", "n_grad_L", "n_hess_psi_prod",
+                    "n_psi", "n_grad_psi", "n_psi_grad_psi", "n_grad_L", "n_hess_psi_prod", "n_hess_psi_prod_calls",
                     "n_prox_grad_step"):
             assert st[key][b] == st_o[key], key
         k = st_o["iterations"]
@@ -129,7 +129,7 @@ def test_smallest_horizons_solve_like_the_oracle(rng, N, spec):
         u_o, st_o, _ = ob.solve(N, x0s[i], u0s[i], prm)
         assert st["status"][i] == st_o["status"]
         for key in ("iterations", "cg_iterations", "accepted", "rejected", "n_psi", "n_psi_grad_psi", "n_grad_L",
-                    "n_hess_psi_prod"):
+                    "n_hess_psi_prod", "n_hess_psi_prod_calls"):
             assert st[key][i] == st_o[key], key
         assert np.array_equal(u[i], u_o) and st["eps"][i] == st_o["eps"]
 
@@ -144,7 +144,7 @@ def test_longest_horizon_through_the_solve_kernel(rng):
     b.close()
     u_o, st_o, _ = ob.solve(N, x0s[0], u0s[0], ob.dodo_params(max_iter=2))
     assert st["status"][0] == st_o["status"] == 3 and st["iterations"][0] == st_o["iterations"] == 2
-    for key in ("cg_iterations", "n_hess_psi_prod", "n_psi", "n_psi_grad_psi", "n_grad_L"):
+    for key in ("cg_iterations", "n_hess_psi_prod", "n_hess_psi_prod_calls", "n_psi", "n_psi_grad_psi", "n_grad_L"):
         assert st[key][0] == st_o[key], key
     assert np.array_equal(u[0], u_o) and st["eps"][0] == st_o["eps"]
 
@@ -224,7 +224,7 @@ def test_config5_stress_horizon_120():
         res = list(ex.map(oracle, pick))
     for b, (xo, u_o, st_o) in zip(pick, res):
         assert np.array_equal(xo, x0[b]) and np.array_equal(u[b], u_o)
-        for key in ("iterations", "cg_iterations", "n_hess_psi_prod", "n_psi", "n_psi_grad_psi", "n_grad_L"):
+        for key in ("iterations", "cg_iterations", "n_hess_psi_prod", "n_hess_psi_prod_calls", "n_psi", "n_psi_grad_psi", "n_grad_L"):
             assert st[key][b] == st_o[key], key
 
 
@@ -260,7 +260,7 @@ def test_config4_horizon_sweep():
         u, st = batch.solve(np.vstack(x0s), np.vstack(guesses))
         batch.close()
         assert np.array_equal(u, np.vstack(sols)), N
-        for key in ("iterations", "cg_iterations", "n_hess_psi_prod", "n_psi", "n_psi_grad_psi", "n_grad_L", "status"):
+        for key in ("iterations", "cg_iterations", "n_hess_psi_prod", "n_hess_psi_prod_calls", "n_psi", "n_psi_grad_psi", "n_grad_L", "status"):
             assert st[key].tolist() == [s[key] for s in stats_o], (N, key)
         total += len(u)
     assert total == 720
@@ -281,7 +281,7 @@ def test_bench_workload_matches_oracle_at_full_occupancy():
     assert np.array_equal(u[:300], d["sol"])  # the recorded closed loop (committed fixture)
     u_o, st_o = ob.solve_batch(60, x0, u0, ob.dodo_params(), nthreads=min(16, os.cpu_count() or 1))
     assert np.array_equal(u, u_o)
-    for key in ("iterations", "n_hess_psi_prod", "cg_iterations", "status"):
+    for key in ("iterations", "n_hess_psi_prod", "n_hess_psi_prod_calls", "cg_iterations", "status"):
         assert np.array_equal(st[key], np.array([s[key] for s in st_o])), key
 
 
@@ -398,11 +398,54 @@ def test_speculation_changes_nothing_but_time():
         u, st = res[mode]
         assert np.array_equal(u, u_off)
         for k in ("status", "iterations", "cg_iterations", "accepted", "rejected", "qub_backtracks", "n_psi",
-                  "n_psi_grad_psi", "n_grad_L", "n_hess_psi_prod", "n_prox_grad_step", "eps", "final_psi", "final_fbe",
+                  "n_psi_grad_psi", "n_grad_L", "n_hess_psi_prod", "n_hess_psi_prod_calls", "n_prox_grad_step", "eps", "final_psi", "final_fbe",
                   "final_gamma", "final_radius"):
             assert np.array_equal(st[k], st_off[k]), (mode, k)
     with pytest.raises(pa.PantrError, match="speculation"):
         pa.PantrBatch("hanging_chain", 5, 1, opts=("speculation=maybe",))
+
+
+def test_a_helper_that_misses_its_deadline_costs_time_only():
+    """`spec_patience=0`: the first result the solver wavefront asks its helper for counts as late (normally the
+    helper is done long before): the solver tells the helper to stop (SpecBox::abort), evaluates the step itself
+    and posts no further requests; stats.spec_timeouts reports it.  Same solutions and counters as without a
+    helper; the workgroup ends (the helper sees the flag), so the launch returns."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_hanging_chain_N60_warm300.npz"))
+    idx = np.arange(0, 300, 30)
+    x0 = np.vstack([d["x0"][idx], d["x0"][idx]])
+    u0 = np.vstack([d["guess"][idx], np.zeros_like(d["guess"][idx])])
+    res = {}
+    for opts in (("speculation=off",), ("speculation=on",), ("speculation=on", "spec_patience=0")):
+        b = pa.PantrBatch("hanging_chain", 60, len(x0), opts=tuple(pa.DODO_PANTR_OPTS) + opts)
+        res[opts] = b.solve(x0, u0)
+        b.close()
+    u_off, st_off = res[("speculation=off",)]
+    assert np.all(st_off["spec_timeouts"] == 0) and np.all(res[("speculation=on",)][1]["spec_timeouts"] == 0)
+    u, st = res[("speculation=on", "spec_patience=0")]
+    # the first wait of every instance that asks at all (and a second one if a request was still out); none after
+    assert np.all(st["spec_timeouts"] <= 2) and np.sum(st["spec_timeouts"] >= 1) >= len(x0) - 2
+    assert np.array_equal(u, u_off)
+    for k in ("status", "iterations", "cg_iterations", "accepted", "rejected", "n_psi", "n_psi_grad_psi", "n_grad_L",
+              "n_hess_psi_prod", "n_hess_psi_prod_calls", "eps", "final_psi"):
+        assert np.array_equal(st[k], st_off[k]), k
+
+
+def test_residency_caps_workgroups_per_cu_and_changes_nothing_else():
+    """`residency=k` (at most k workgroups per compute unit, through the LDS the launch asks for): same
+    solutions and counters, for the one- and the two-wavefront kernel."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_hanging_chain_N60_warm300.npz"))
+    idx = np.arange(0, 300, 20)
+    x0 = np.vstack([d["x0"][idx], d["x0"][idx]])
+    u0 = np.vstack([d["guess"][idx], np.zeros_like(d["guess"][idx])])
+    ref = None
+    for opts in ((), ("residency=1",), ("residency=2", "speculation=off"), ("residency=5", "speculation=off")):
+        b = pa.PantrBatch("hanging_chain", 60, len(x0), opts=tuple(pa.DODO_PANTR_OPTS) + opts)
+        u, st = b.solve(x0, u0)
+        b.close()
+        if ref is None:
+            ref = (u, st)
+        assert np.array_equal(u, ref[0]) and np.array_equal(st["n_hess_psi_prod"], ref[1]["n_hess_psi_prod"]), opts
+        assert np.all(st["status"] == 1)
 
 
 def test_kernel_name_follows_method_speculation_and_batch_size():

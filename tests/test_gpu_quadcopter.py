@@ -74,7 +74,7 @@ def test_alm_solve_matches_oracle(rng, problem, N):
     for i in range(B):
         u_o, y_o, st_o = ob.quad_solve(problem, N, x0[i], u0[i])
         assert st["status"][i] == st_o["status"] == 1
-        for key in ("outer_iterations", "iterations", "cg_iterations", "n_hess_psi_prod", "n_psi",
+        for key in ("outer_iterations", "iterations", "cg_iterations", "n_hess_psi_prod", "n_hess_psi_prod_calls", "n_psi",
                     "n_psi_grad_psi", "n_grad_L", "inner_convergence_failures"):
             assert st[key][i] == st_o[key], key
         assert rel(u[i], u_o) <= RTOL and np.array_equal(u[i], u_o) and np.array_equal(y[i], y_o)
@@ -93,7 +93,7 @@ def test_longest_realistic_quadcopter_horizon_solves_like_the_oracle():
     b.close()
     u_o, y_o, st_o = ob.quad_solve(problem, N, x0[0], u0[0])
     assert st["status"][0] == st_o["status"] == 1
-    for key in ("outer_iterations", "iterations", "cg_iterations", "n_hess_psi_prod", "n_psi", "n_grad_L"):
+    for key in ("outer_iterations", "iterations", "cg_iterations", "n_hess_psi_prod", "n_hess_psi_prod_calls", "n_psi", "n_grad_L"):
         assert st[key][0] == st_o[key], key
     assert np.array_equal(u[0], u_o) and np.array_equal(y[0], y_o)
 
@@ -111,7 +111,7 @@ def test_smallest_horizons_solve_like_the_oracle(rng, problem, N):
     for i in range(B):
         u_o, y_o, st_o = ob.quad_solve(problem, N, x0[i], u0[i])
         assert st["status"][i] == st_o["status"]
-        for key in ("outer_iterations", "iterations", "cg_iterations", "n_hess_psi_prod", "n_psi", "n_grad_L"):
+        for key in ("outer_iterations", "iterations", "cg_iterations", "n_hess_psi_prod", "n_hess_psi_prod_calls", "n_psi", "n_grad_L"):
             assert st[key][i] == st_o[key], key
         assert np.array_equal(u[i], u_o) and np.array_equal(y[i], y_o)
 
@@ -126,9 +126,10 @@ def test_speculation_changes_nothing_but_time(rng, problem, N):
     x0 = np.vstack([ob.quad_initial_state(), ob.quad_initial_state() + 0.02 * rng.standard_normal((B - 1, 9))])
     u0 = np.tile(ob.quad_initial_guess(N), (B, 1))
     res = {}
-    for mode in ("on", "off"):
-        b = pa.PantrBatch(problem, N, B, opts=quad_opts(problem) + [f"speculation={mode}"])
-        assert ("spec" in b.kernel_name()) == (mode == "on")
+    for mode in ("on", "off", "late"):
+        extra = ["speculation=on", "spec_patience=0"] if mode == "late" else [f"speculation={mode}"]
+        b = pa.PantrBatch(problem, N, B, opts=quad_opts(problem) + extra)
+        assert ("spec" in b.kernel_name()) == (mode != "off")
         res[mode] = b.solve_al(x0, u0)
         b.close()
     (u1, y1, s1), (u0_, y0_, s0) = res["on"], res["off"]
@@ -136,6 +137,13 @@ def test_speculation_changes_nothing_but_time(rng, problem, N):
     for key in s1.dtype.names:
         if key not in ("elapsed_s", "phase_s"):
             assert np.array_equal(s1[key], s0[key]), key
+    # a helper declared late (spec_patience=0: the first result asked for): the solver stops waiting, tells it to
+    # stop and goes on alone - same results, the timeout reported, the launch returns
+    u2, y2, s2 = res["late"]
+    assert np.array_equal(u2, u0_) and np.array_equal(y2, y0_)
+    assert np.all(s2["spec_timeouts"] >= 1) and np.all(s2["spec_timeouts"] <= 2) and np.all(s1["spec_timeouts"] == 0)
+    for key in ("status", "iterations", "outer_iterations", "cg_iterations", "n_hess_psi_prod", "n_psi", "n_grad_L", "eps"):
+        assert np.array_equal(s2[key], s0[key]), key
     assert np.all(s1["status"] == 1) and s1["rejected"].sum() > 0   # (rejections happened: results were taken)
     b = pa.PantrBatch(problem, N, 4096, opts=quad_opts(problem))
     assert "spec" not in b.kernel_name()                             # auto: large batches keep one wavefront
@@ -162,7 +170,7 @@ def test_config3_realistic_quadcopter_horizon_60():
     form bench.py measures) reproduce u, y and every counter of the oracle."""
     from concurrent.futures import ThreadPoolExecutor
     problem, N, num_sim = "realistic_quadcopter", 60, 60
-    keys = ("iterations", "outer_iterations", "cg_iterations", "n_hess_psi_prod", "n_psi", "n_psi_grad_psi",
+    keys = ("iterations", "outer_iterations", "cg_iterations", "n_hess_psi_prod", "n_hess_psi_prod_calls", "n_psi", "n_psi_grad_psi",
             "n_grad_L", "inner_convergence_failures")
     with ThreadPoolExecutor(2) as ex:   # the oracle's two closed loops run beside the device's
         fut = {w: ex.submit(ob.quad_mpc_full, problem, N, num_sim, w) for w in (True, False)}

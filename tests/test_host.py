@@ -40,7 +40,7 @@ def test_stats_struct_layout():
             names += [x.strip() for x in decl.split(None, 1)[1].split(",")]
     names = [x.split('[')[0] for x in names]   # phase_s[4]
     assert tuple(names) == pa.STATS_DTYPE.names
-    assert pa.STATS_DTYPE.itemsize == 6 * 8 + 14 * 4 + 2 * 8 + 6 * 4 + 8 + 4 * 8
+    assert pa.STATS_DTYPE.itemsize == 6 * 8 + 16 * 4 + 2 * 8 + 6 * 4 + 8 + 4 * 8
 
 
 def test_driver_defaults_and_dodo_options():
@@ -91,6 +91,16 @@ def test_option_grammar():
     with pytest.raises(pa.PantrError) as e:
         p.set("speculation=maybe")
     assert e.value.code == -1 and "speculation" in str(e.value)
+    # residency=auto|<k>, spec_patience=<duration>: options of this implementation as well
+    assert p.get("residency") == 0 and p.get("spec_patience") == 1.0
+    for text, key, value in (("residency=3", "residency", 3), ("residency=auto", "residency", 0),
+                             ("spec_patience=250ms", "spec_patience", 0.25), ("spec_patience=0", "spec_patience", 0.0)):
+        p.set(text)
+        assert p.get(key) == value
+    for bad in ("residency=-1", "residency=many", "spec_patience=soon", "spec_patience=-1s"):
+        with pytest.raises(pa.PantrError) as e:
+            p.set(bad)
+        assert e.value.code == -1 and bad.split("=")[0] in str(e.value)
 
 
 def test_no_cpu_fallback():
