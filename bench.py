@@ -43,6 +43,7 @@ sys.path.insert(0, os.path.join(ROOT, "pantr-cdc2023-experiments_amd"))
 METRIC = "MPC-steps solved/sec, hanging_chain N=60 cold+warm, 1/2/4/8 MI355X"
 HORIZON = 60
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_COPY_GUIDE_GBS = 6290.0  # MI355X_MICROARCH.md:36: 6.29 TB/s measured with a float4 copy (79 % of the spec peak)
 FIXTURE = os.path.join(ROOT, "tests", "golden", "mpc_hanging_chain_N60_warm300.npz")
 PROFILE_TAG = "r03"
 # PMC summary of the headline command (scripts/profile.sh + scripts/summarize_profiles.py)
@@ -95,6 +96,7 @@ class Resident:
         self.stats_t = torch.zeros(max(self.B, 1) * pa.STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
         self.batch = pa.PantrBatch(w["problem"], w["horizon"], max(self.B, 1), device=local_rank, opts=w["opts"])
         self.launched = False
+        self.last_dev = None  # max |u - recorded closed loop| measured by the last check()
 
     def launch(self, stream=None):
         if self.B == 0:
@@ -125,6 +127,7 @@ class Resident:
 
     def check(self, what):
         """Every instance converged, and the replay reproduces the recorded closed loop bit for bit."""
+        self.last_dev = None
         if self.B == 0:
             return 0.0
         st = self.stats()
@@ -136,6 +139,7 @@ class Resident:
             have = self.idx < len(self.w["sol"])
             if np.any(have):
                 dev = float(np.max(np.abs(self.solutions()[have] - self.w["sol"][self.idx[have]])))
+                self.last_dev = dev
                 if dev != 0.0:
                     raise SystemExit(f"bench.py: '{what}' replay deviates from the recorded closed loop by "
                                      f"{dev:.3e} - refusing to report")
@@ -155,8 +159,9 @@ def roofline_obj(alg_bytes, kernel_ms, kernel, peak_measured=None, traffic=None,
          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel, "kernel_ms": kernel_ms,
          "algorithmic_bytes_per_launch": int(alg_bytes)}
     if peak_measured:
-        r["peak_measured"] = peak_measured
+        r["peak_measured"] = peak_measured  # best 16-B-per-lane device copy of this library on this device, GB/s
         r["frac_of_measured_peak"] = achieved / peak_measured
+        r["peak_measured_guide"] = HBM_COPY_GUIDE_GBS
     if traffic_source is not None:
         r["traffic_source"] = traffic_source
     return r
@@ -305,7 +310,12 @@ def strong_mode(args, torch, pa, dev, local_rank, rank, world, distributed, rehe
         desc = "BASELINE.json configs[4]: hanging_chain N=120, 1024 synthetic cold instances"
     # global instance list: (workload k, row i); the same deterministic partition on every rank
     where = [(k, i) for k, w in enumerate(ws) for i in range(len(w["x0"]))]
-    costs = [workloads.expected_cost(ws[k]["horizon"], bool(ws[k]["warm"][i])) for k, i in where]
+    # what an instance costs: the Hessian-vector products its own recorded solve needed, times the horizon (a
+    # product sweeps the horizon twice), where the replay batch holds that record; N^2.7 otherwise
+    costs = [float(ws[k]["cost"][i]) if ws[k].get("cost") is not None
+             else workloads.expected_cost(ws[k]["horizon"], bool(ws[k]["warm"][i])) for k, i in where]
+    cost_source = ("recorded n_hess_psi_prod x horizon of every instance" if all(w.get("cost") is not None for w in ws)
+                   else "horizon^2.7 x (cold: 2.5) - this batch has no recorded solves")
     mine = sharding.shard_indices(len(where), rank, world, costs)
     rs = []
     for k, w in enumerate(ws):
@@ -342,6 +352,10 @@ def strong_mode(args, torch, pa, dev, local_rank, rank, world, distributed, rehe
     gathered = sharding.gather_rows(local, local_idx, len(where), None if rehearsal else dev)
     kms = [r.kernel_ms() for r in rs]
     alg = sum(r.alg_bytes() for r in rs if r.B)
+    # what bounds a pass: the slowest instance's in-kernel time (over all ranks), and how full this rank's GPU is
+    slowest_local = max((float(r.stats()["elapsed_s"].max()) for r in rs if r.B), default=0.0)
+    slowest = sharding.max_over_ranks(slowest_local, cdev)
+    cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
     failure, same = None, None
     if rank == 0:
         full = [Resident(w, torch, pa, dev, local_rank) for w in ws]
@@ -365,13 +379,58 @@ def strong_mode(args, torch, pa, dev, local_rank, rank, world, distributed, rehe
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "instances": len(where), "instances_rank0": int(len(mine)),
-                       "partition": "longest-processing-time-first by (horizon, start) cost (pantr_amd/sharding.py)",
+                       "partition": "longest-processing-time-first (pantr_amd/sharding.py); cost = " + cost_source,
                        "gathered_equals_unsharded": same, "rehearsal_shared_gpu": rehearsal},
+            "bound": {"slowest_instance_in_kernel_ms": slowest * 1e3, "ms_per_pass": elapsed / args.steps * 1e3,
+                      "instances_per_cu_rank0": len(mine) / cus, "compute_units": cus,
+                      "note": "a pass cannot be shorter than its slowest instance: sharding shortens a pass only while "
+                              "the GPU is full (many instances per CU)"},
             "roofline": dict(roofline_obj(rs[dom].alg_bytes(), kms[dom], rs[dom].kernel_name()),
                              rank0_all_launches_algorithmic_bytes=int(alg), rank0_kernel_ms=kms),
         }), flush=True)
     for r in rs:
         r.close()
+
+
+def spawn_ranks(n):
+    """`bench.py --gpus N` started bare (no WORLD_SIZE in the environment): start N fresh rank processes - before
+    this process has made any torch.cuda / HIP call; it never makes one - with the environment torch.distributed.run
+    would give them, relay rank 0's line (its stdout is this process's stdout), and leave with a failure if any
+    rank failed.  Children are ended by their exact PIDs if one of them fails while the others still run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = None if r == 0 else subprocess.DEVNULL  # rank 0 prints the JSON line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            try:
+                code = p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.remove(p)
+            if code != 0:
+                rc = rc or code
+        if rc and pending:  # a rank failed: its peers would wait for it in the next collective
+            time.sleep(5.0)  # (sharding.raise_together normally ends them by themselves)
+            for p in pending:
+                if p.poll() is None:
+                    p.terminate()
+            for p in pending:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+    return rc
 
 
 def main():
@@ -388,6 +447,9 @@ def main():
     ap.add_argument("--workload", choices=("headline", "sweep", "stress"), default="headline")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare: this process becomes the launcher (no GPU call before or after this point)
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import pantr_amd as pa
@@ -493,7 +555,8 @@ def main():
                 "workload_source": source,
                 "instances_per_gpu": B, "horizon": HORIZON, "n": n, "streams": S,
                 "converged": int(np.sum(stats["status"] == 1)),
-                "max_abs_dev_from_recorded_closed_loop": 0.0, "max_abs_dev_from_tests_golden": fixture_dev,
+                # measured by Resident.check() on this run's solutions (a nonzero value refuses to report)
+                "max_abs_dev_from_recorded_closed_loop": rs[0].last_dev, "max_abs_dev_from_tests_golden": fixture_dev,
                 "scaling_note": "weak = every rank solves its own 600-instance batch (replicas, no exchange step); "
                                 "`--workload sweep|stress --scaling strong` shards one batch over the ranks",
                 "published_reference": "BASELINE.md 1.1: 4.21 steps/s (alpaqa PANTR cold+warm, unstated CPU, 1 thread) - "
@@ -504,7 +567,8 @@ def main():
                                      traffic_src),
         }
         if extras:
-            cores = min(16, len(os.sched_getaffinity(0)))  # the GPU box's CPU share for one GPU
+            affinity = len(os.sched_getaffinity(0))
+            cores = min(16, affinity)  # the GPU box's CPU share for one GPU
             # warm and cold separately: the two halves of the batch as launches of their own
             for key, rows in (("warm", np.arange(B // 2)), ("cold", np.arange(B // 2, B))):
                 r = Resident(w, torch, pa, dev, local_rank, rows)
@@ -546,6 +610,10 @@ def main():
             with_cpu = not args.no_cpu_baseline
             if with_cpu:
                 line["cpu_baseline"] = cpu_batch_baseline(w, cores)
+                line["cpu_baseline"]["host"] = {"os_cpu_count": os.cpu_count(), "affinity": affinity,
+                                                "threads_used": cores}
+                if affinity > cores:  # every core this process may run on, next to the one-GPU share
+                    line["cpu_baseline"]["all_cores"] = cpu_batch_baseline(w, affinity)
                 line["cpu_serial_closed_loop"] = cpu_serial_closed_loop()
             line["configs"] = extra_configs(torch, pa, dev, local_rank, cores, peak_measured, with_cpu)
         print(json.dumps(line), flush=True)

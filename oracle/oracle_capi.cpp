@@ -33,7 +33,7 @@ struct OracleParams {
     int32_t max_iter, stop_crit, max_no_progress, disable_acceleration;
     int32_t alm_max_iter;
     int32_t method; ///< 0 = pantr, 1 = panoc, 2 = strucpanoc (mpc-driver.cpp:364-384)
-    int32_t force_linesearch, lbfgs_memory, lbfgs_force_pos_def, pad0;
+    int32_t force_linesearch, lbfgs_memory, lbfgs_force_pos_def, variant; ///< variant: PANTRParams::variant (0 = the specification)
 };
 enum Method : int32_t { MethodPANTR = 0, MethodPANOC = 1, MethodStrucPANOC = 2 };
 
@@ -74,7 +74,7 @@ void oracle_default_params(OracleParams *p) {
     p->alm_penalty_update_factor = alm.penalty_update_factor;
     p->alm_initial_tolerance = alm.initial_tolerance;
     p->alm_tolerance_update_factor = alm.tolerance_update_factor;
-    p->alm_max_iter = alm.max_iter; p->pad0 = 0;
+    p->alm_max_iter = alm.max_iter; p->variant = 0;
     PANOCParams pn;
     LBFGSParams lb;
     p->min_linesearch_coefficient = pn.min_linesearch_coefficient;
@@ -145,6 +145,7 @@ static PANTRSolver<P> make_solver(const OracleParams &p) {
     a.initial_radius = p.initial_radius; a.min_radius = p.min_radius;
     a.max_iter = p.max_iter; a.stop_crit = p.stop_crit; a.max_no_progress = p.max_no_progress;
     a.disable_acceleration = p.disable_acceleration;
+    a.variant = p.variant;
     s.dir_params.hessian_vec_factor = p.hessian_vec_factor;
     s.accel_params.tol_scale = p.tol_scale; s.accel_params.tol_scale_root = p.tol_scale_root;
     s.accel_params.tol_max = p.tol_max; s.accel_params.max_iter_factor = p.max_iter_factor;

@@ -57,6 +57,14 @@ struct PANTRParams {
     double initial_radius = NaN;
     double min_radius     = 100 * eps_mach;
     int disable_acceleration = 0;
+    /// Variants of the six places where recollections of upstream alpaqa differ, for
+    /// scripts/adjudicate_choices.py only - 0 is the specification the kernels follow.  Bits:
+    ///   1  Lipschitz estimate: finite-difference step x + h instead of x - h
+    ///   2  initial trust radius ||grad psi(x0)|| instead of 0.1 ||grad psi(x0)||
+    ///   4  q_K = 0 (the active set does not move with the Newton step) instead of q_K = p_K
+    ///   8  the model value the ratio test divides by also counts the active set's part of the step:
+    ///      + grad_K' p_K + 1/2 p_K' H_KK p_K + p_K' H_KJ q_J  (one more product)
+    int variant = 0;
 };
 struct NewtonTRDirectionParams {
     double hessian_vec_factor = 0.5; // dodo.py:31 sets 1
@@ -266,7 +274,7 @@ struct PANTRSolver {
                 double h = g > 0 ? std::fmax(g * params.lip_eps, params.lip_delta)
                                  : std::fmin(g * params.lip_eps, -params.lip_delta);
                 work[i]     = h;
-                curr->xh[i] = curr->x[i] - h;
+                curr->xh[i] = (params.variant & 1) ? curr->x[i] + h : curr->x[i] - h;
             }
             double norm_h = std::sqrt(dot(work.data(), work.data(), n));
             problem.eval_grad_psi(curr->xh.data(), cand->grad.data());
@@ -290,7 +298,7 @@ struct PANTRSolver {
         int k = 0, no_progress = 0;
         double radius = params.initial_radius;
         if (!std::isfinite(radius) || radius == 0)
-            radius = 0.1 * std::sqrt(dot(curr->grad.data(), curr->grad.data(), n));
+            radius = ((params.variant & 2) ? 1.0 : 0.1) * std::sqrt(dot(curr->grad.data(), curr->grad.data(), n));
         radius = std::fmax(radius, params.min_radius);
 
         while (true) {
@@ -339,7 +347,7 @@ struct PANTRSolver {
                 bool any_K       = nJ < n;
                 for (int i = 0; i < n; ++i) {
                     rJ[i] = mask[i] ? inv_gamma * prox->p[i] : 0.0;
-                    q[i]  = mask[i] ? 0.0 : prox->p[i];
+                    q[i]  = mask[i] ? 0.0 : ((params.variant & 4) ? 0.0 : prox->p[i]);
                 }
                 // The product with q_K is skipped when q_K = 0 (active bounds the prox step does not leave:
                 // nine iterations in ten of the hanging-chain benchmark): its result is exactly zero.
@@ -363,7 +371,16 @@ struct PANTRSolver {
                                          vfull.data(), wz, wr, wd, wBd, wev, cg_its);
                 s.cg_iterations += cg_its;
                 for (int i = 0; i < n; ++i)
-                    q[i] = mask[i] ? vfull[i] : prox->p[i];
+                    q[i] = mask[i] ? vfull[i] : ((params.variant & 4) ? 0.0 : prox->p[i]);
+                if ((params.variant & 8) && any_K) { // model value of the whole step q = (q_J, p_K), gradient = grad psi(xbar)
+                    problem.eval_hess_psi_prod(prox->x.data(), q.data(), work.data());
+                    double lin = 0, quad = 0;
+                    for (int i = 0; i < n; ++i) {
+                        lin += prox->grad[i] * q[i];
+                        quad += q[i] * work[i];
+                    }
+                    q_model = lin + 0.5 * quad;
+                }
                 bool q_finite = true;
                 for (int i = 0; i < n; ++i)
                     q_finite = q_finite && std::isfinite(q[i]);

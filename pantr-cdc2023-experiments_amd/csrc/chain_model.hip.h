@@ -295,19 +295,36 @@ struct ChainModel {
     }
     /// Start the LDS-DMA of one stage into the landing buffer `buf`: 2 KiB (K rows) for the
     /// forward sweep; 4 KiB of tape + 1 KiB of tangent tape for the adjoint sweep.
+    /// (HIDE: wave_math.hip.h, lds_dma_row)
+    template <bool HIDE = false>
     __device__ static __forceinline__ void prefetch_fwd(const Lane &L, const double4 *tape_stage, char *buf) {
         const char *src = reinterpret_cast<const char *>(tape_stage) + L.l * 16;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            lds_dma_row(src + i * 1024, buf + i * 1024);
+        lds_dma_row<0, HIDE>(src, buf); // (the immediate offset moves both addresses)
+        lds_dma_row<1024, HIDE>(src, buf);
     }
+    template <bool HIDE = false>
     __device__ static __forceinline__ void prefetch_rev(const Lane &L, const double4 *tape_stage,
                                                         const double4 *st_stage, char *buf) {
         const char *src = reinterpret_cast<const char *>(tape_stage) + L.l * 16;
-#pragma unroll
-        for (int i = 0; i < TAPE_STAGE_BYTES / 1024; ++i)
-            lds_dma_row(src + i * 1024, buf + i * 1024);
-        lds_dma_row(reinterpret_cast<const char *>(st_stage) + L.l * 16, buf + TAPE_STAGE_BYTES);
+        static_assert(TAPE_STAGE_BYTES == 4096, "four 1 KiB transfers");
+        lds_dma_row<0, HIDE>(src, buf);
+        lds_dma_row<1024, HIDE>(src, buf);
+        lds_dma_row<2048, HIDE>(src, buf);
+        lds_dma_row<3072, HIDE>(src, buf);
+        lds_dma_row<0, HIDE>(reinterpret_cast<const char *>(st_stage) + L.l * 16, buf + TAPE_STAGE_BYTES);
+    }
+    /// The same plus the stage's tangent-state row (256 bytes, one 4-byte transfer per lane) behind the tangent
+    /// tape in the landing buffer: sweeps that run two stages ahead read it from LDS (xt_lds) instead of waiting
+    /// for a register load among the transfers in flight.  Six transfers.
+    static constexpr int LDS_STAGE_BYTES_XT = LDS_STAGE_BYTES + XT_DOUBLES * 8;
+    template <bool HIDE = false>
+    __device__ static __forceinline__ void prefetch_rev_xt(const Lane &L, const double4 *tape_stage, const double4 *st_stage,
+                                                           const double *xt_row, char *buf) {
+        prefetch_rev<HIDE>(L, tape_stage, st_stage, buf);
+        lds_dma_row256<HIDE>(reinterpret_cast<const char *>(xt_row) + L.l * 4, buf + LDS_STAGE_BYTES);
+    }
+    __device__ static __forceinline__ double xt_lds(const Lane &L, const char *buf) {
+        return reinterpret_cast<const double *>(buf + LDS_STAGE_BYTES)[L.q];
     }
     struct TapeK {
         double K[DIM];

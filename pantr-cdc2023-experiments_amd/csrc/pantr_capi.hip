@@ -273,7 +273,7 @@ int set_option(SolverOptions &o, const char *kv) {
 /// and with the static part (four landing buffers, the mailbox).
 size_t spec_lds_bytes(const pantr_batch &b) { return spec_lds_doubles<ChainModel>(b.npad) * sizeof(double); }
 size_t spec_lds_total(const pantr_batch &b) {
-    return spec_lds_bytes(b) + 2 * WaveProblem<ChainModel>::tape_lds_bytes() + sizeof(SpecBox);
+    return spec_lds_bytes(b) + 2 * SpecProblemT<ChainModel>::tape_lds_bytes() + sizeof(SpecBox);
 }
 /// The same question for the quadcopter family (pantr_alm_spec_kernel): dynamic LDS of the two-wavefront
 /// workgroup; auto: every instance resident at once, at most one workgroup per pair of SIMDs.
@@ -380,13 +380,13 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
         return fail(PANTR_ERR_OUT_OF_RANGE, "horizon too long for method=panoc|strucpanoc: their vectors do not fit the 160 KiB LDS");
     HIP_TRY(hipEventRecord(b->ev_start, stream));
     if (method == 0 && use_speculation(b, B)) {
-        const size_t lds = residency_lds(b, spec_lds_bytes(*b), 2 * WaveProblem<ChainModel>::tape_lds_bytes() + sizeof(SpecBox));
+        const size_t lds = residency_lds(b, spec_lds_bytes(*b), 2 * SpecProblemT<ChainModel>::tape_lds_bytes() + sizeof(SpecBox));
         if (b->opts.residency > 0)
             if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(&pantr_solve_spec_kernel<ChainModel>), lds))
                 return rc;
         hipLaunchKernelGGL(pantr_solve_spec_kernel<ChainModel>, dim3(B), dim3(2 * WAVE), lds, stream, a);
     } else if (method == 0) {
-        const size_t lds = residency_lds(b, b->lds_bytes_pantr, WaveProblem<ChainModel>::tape_lds_bytes());
+        const size_t lds = residency_lds(b, b->lds_bytes_pantr, SolveProblemT<ChainModel, 0>::tape_lds_bytes());
         if (b->opts.residency > 0)
             if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(&pantr_solve_kernel<ChainModel, 0>), lds))
                 return rc;
@@ -470,6 +470,33 @@ int run_eval(pantr_batch *b, int32_t B, int mode, double gamma, const double *x0
 
 } // namespace
 
+// ---- achievable HBM bandwidth (the yardstick next to the 8 TB/s spec peak, SURVEY.md 8(d)) --------
+namespace {
+using f32x4 = float __attribute__((ext_vector_type(4))); // one global_load_dwordx4 / global_store_dwordx4 per access
+/// dst[i] = src[i], 16 bytes per lane per access, UNROLL independent accesses in flight per lane, grid-stride.
+/// NT: streaming (non-temporal) loads and stores.
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void copy16_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < count; i += UNROLL * stride) {
+        f32x4 v[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k)
+            v[k] = NT ? __builtin_nontemporal_load(&src[i + k * stride]) : src[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            if (NT)
+                __builtin_nontemporal_store(v[k], &dst[i + k * stride]);
+            else
+                dst[i + k * stride] = v[k];
+        }
+    }
+    for (; i < count; i += stride)
+        dst[i] = src[i];
+}
+} // namespace
+
 extern "C" {
 
 const char *pantr_last_error(void) { return g_last_error.c_str(); }
@@ -498,36 +525,12 @@ int pantr_device_count(void) {
     return c;
 }
 
-// ---- achievable HBM bandwidth (the yardstick next to the 8 TB/s spec peak, SURVEY.md 8(d)) --------
-namespace {
-/// 16 bytes per lane per access, four independent accesses in flight per lane, grid-stride,
-/// streaming (non-temporal) loads and stores: dst[i] = src[i].
-__global__ __launch_bounds__(256) void copy16_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst,
-                                                     size_t count) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < count; i += 4 * stride) {
-        double2 a, b, c, d;
-        a.x = __builtin_nontemporal_load(&src[i].x);              a.y = __builtin_nontemporal_load(&src[i].y);
-        b.x = __builtin_nontemporal_load(&src[i + stride].x);     b.y = __builtin_nontemporal_load(&src[i + stride].y);
-        c.x = __builtin_nontemporal_load(&src[i + 2 * stride].x); c.y = __builtin_nontemporal_load(&src[i + 2 * stride].y);
-        d.x = __builtin_nontemporal_load(&src[i + 3 * stride].x); d.y = __builtin_nontemporal_load(&src[i + 3 * stride].y);
-        __builtin_nontemporal_store(a.x, &dst[i].x);              __builtin_nontemporal_store(a.y, &dst[i].y);
-        __builtin_nontemporal_store(b.x, &dst[i + stride].x);     __builtin_nontemporal_store(b.y, &dst[i + stride].y);
-        __builtin_nontemporal_store(c.x, &dst[i + 2 * stride].x); __builtin_nontemporal_store(c.y, &dst[i + 2 * stride].y);
-        __builtin_nontemporal_store(d.x, &dst[i + 3 * stride].x); __builtin_nontemporal_store(d.y, &dst[i + 3 * stride].y);
-    }
-    for (; i < count; i += stride)
-        dst[i] = src[i];
-}
-} // namespace
-
 int pantr_device_copy_bandwidth(int32_t device, int64_t bytes, int32_t reps, double *gb_per_s) {
     if (!gb_per_s || bytes < (1 << 20) || reps < 1)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "need an output pointer, bytes >= 1 MiB and reps >= 1");
     HIP_TRY(hipSetDevice(device));
-    const size_t count = (size_t)bytes / sizeof(double2);
-    double2 *src = nullptr, *dst = nullptr;
+    const size_t count = (size_t)bytes / sizeof(f32x4);
+    f32x4 *src = nullptr, *dst = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&] {
         if (src) (void)hipFree(src);
@@ -535,26 +538,40 @@ int pantr_device_copy_bandwidth(int32_t device, int64_t bytes, int32_t reps, dou
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     };
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&src), count * sizeof(double2));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dst), count * sizeof(double2));
-    if (e == hipSuccess) e = hipMemset(src, 1, count * sizeof(double2));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&src), count * sizeof(f32x4));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dst), count * sizeof(f32x4));
+    if (e == hipSuccess) e = hipMemset(src, 1, count * sizeof(f32x4));
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    // the best of a few launch shapes (which one wins moves with the device's clocks and memory state):
+    // one access per thread on a grid that covers the buffer; grid-stride with 4 accesses in flight on 8 and
+    // 16 workgroups per compute unit, default and non-temporal policy
     float best_ms = 0;
-    for (int r = 0; e == hipSuccess && r < reps + 1; ++r) { // first pass untimed (page faults, clocks)
-        (void)hipEventRecord(e0, nullptr);
-        hipLaunchKernelGGL(copy16_kernel, dim3(256 * 8), dim3(256), 0, nullptr, src, dst, count);
-        (void)hipEventRecord(e1, nullptr);
-        e = hipEventSynchronize(e1);
-        float ms = 0;
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-        if (r > 0 && (best_ms == 0 || ms < best_ms))
-            best_ms = ms;
+    for (int shape = 0; e == hipSuccess && shape < 5; ++shape) {
+        for (int r = 0; e == hipSuccess && r < reps + 1; ++r) { // first pass untimed (page faults, clocks)
+            (void)hipEventRecord(e0, nullptr);
+            const unsigned full = (unsigned)((count + 255) / 256);
+            switch (shape) {
+            case 0: hipLaunchKernelGGL((copy16_kernel<1, false>), dim3(full), dim3(256), 0, nullptr, src, dst, count); break;
+            case 1: hipLaunchKernelGGL((copy16_kernel<4, false>), dim3(cus * 8), dim3(256), 0, nullptr, src, dst, count); break;
+            case 2: hipLaunchKernelGGL((copy16_kernel<4, true>), dim3(cus * 8), dim3(256), 0, nullptr, src, dst, count); break;
+            case 3: hipLaunchKernelGGL((copy16_kernel<4, false>), dim3(cus * 16), dim3(256), 0, nullptr, src, dst, count); break;
+            default: hipLaunchKernelGGL((copy16_kernel<1, true>), dim3(full), dim3(256), 0, nullptr, src, dst, count); break;
+            }
+            (void)hipEventRecord(e1, nullptr);
+            e = hipEventSynchronize(e1);
+            float ms = 0;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (r > 0 && (best_ms == 0 || ms < best_ms))
+                best_ms = ms;
+        }
     }
     cleanup();
     if (e != hipSuccess)
         return fail(PANTR_ERR_NO_DEVICE, std::string("copy bandwidth measurement: ") + hipGetErrorString(e));
-    *gb_per_s = 2.0 * (double)(count * sizeof(double2)) / (best_ms * 1e-3) / 1e9; // read + write
+    *gb_per_s = 2.0 * (double)(count * sizeof(f32x4)) / (best_ms * 1e-3) / 1e9; // read + write
     return PANTR_OK;
 }
 
@@ -641,7 +658,7 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
         const size_t xs_bytes = WaveProblem<ChainModel>::XS_DOUBLES * sizeof(double);
         b->lds_bytes       = (size_t)NUM_VEC * b->npad * sizeof(double) + xs_bytes; // dynamic part: all vectors (comparators)
         b->lds_bytes_pantr = (size_t)NUM_CG_VEC * b->npad * sizeof(double) + xs_bytes;
-        static_lds         = WaveProblem<ChainModel>::tape_lds_bytes();
+        static_lds         = SolveProblemT<ChainModel, 0>::tape_lds_bytes();
     }
     if ((b->al() ? b->lds_bytes : b->lds_bytes_pantr) + static_lds > 160 * 1024)
         return fail(PANTR_ERR_OUT_OF_RANGE, "decision vectors do not fit the 160 KiB LDS");
@@ -931,7 +948,8 @@ int pantr_batch_footprint(const pantr_batch_t *b, int64_t *lds_bytes, int64_t *w
             *lds_bytes = (int64_t)(alm_spec_lds_bytes(*b) + sizeof(SpecBox));
         else
             *lds_bytes = (int64_t)((pantr_chain ? b->lds_bytes_pantr : cmp_scalar ? b->lds_bytes_cmp : b->lds_bytes) +
-                                   (b->al() ? 0 : WaveProblem<ChainModel>::tape_lds_bytes()));
+                                   (b->al() ? 0 : pantr_chain ? SolveProblemT<ChainModel, 0>::tape_lds_bytes()
+                                                              : SolveProblemT<ChainModel, 1>::tape_lds_bytes()));
     }
     if (ws_bytes_per_instance) *ws_bytes_per_instance = (int64_t)(b->ws_per_instance * sizeof(double));
     return PANTR_OK;

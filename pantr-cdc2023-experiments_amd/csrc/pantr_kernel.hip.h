@@ -163,8 +163,11 @@ enum : int { SPEC_EVAL = 1, SPEC_EXIT = 2, SPEC_MODEL = 3 };
 // ---------------------------------------------------------------------------------------
 // Wave-cooperative problem functions of the single-shooting problem
 // ---------------------------------------------------------------------------------------
-template <class M, bool ITER_GLOBAL = false, bool SPEC = false>
+/// DEPTH: how many stages ahead a Hessian-vector product requests its tape rows (1 | 2; hess_prod_tape).
+template <class M, bool ITER_GLOBAL = false, bool SPEC = false, int DEPTH = 1>
 struct WaveProblem {
+    static_assert(DEPTH == 1 || DEPTH == 2, "one or two stages ahead");
+    static constexpr int PREFETCH_DEPTH = DEPTH;
     using Lane  = typename M::Lane;
     using State = typename M::State;
     const Lane &L;
@@ -176,11 +179,12 @@ struct WaveProblem {
     double *Xt;     ///< global: tangent-state rows of the current Hv, M::XT_DOUBLES per stage
     double4 *tape;  ///< global: recorded second-order rows, M::TAPE_D4_PER_STAGE per stage
     double4 *st;    ///< global: tangent spring vectors of the current Hv, M::ST_D4_PER_STAGE per stage
-    char *tbuf0, *tbuf1; ///< LDS: two stage-sized landing buffers (distinct objects) for the LDS-DMA
+    char *tbuf0, *tbuf1; ///< LDS: stage-sized landing buffers (distinct objects) for the LDS-DMA (a third: tbuf2 below)
     /// The first stage's K rows of the current tape are already in flight to (or in) tbuf0: every
     /// product leaves them there for the next one, so only the first product after a recording
     /// waits for them.
     mutable bool primed = false;
+    char *tbuf2 = nullptr; ///< DEPTH == 2: the third landing buffer (stage k's rows land in buffer k mod 3)
     double *giter = nullptr; ///< ITER_GLOBAL: this instance's NUM_ITER_VEC iterate vectors in the HBM workspace
     // speculation (see SpecBox): nullptr / unused in one-wavefront workgroups
     SpecBox *spec = nullptr;   ///< LDS mailbox
@@ -241,7 +245,9 @@ struct WaveProblem {
     }
 
     /// Static LDS of a kernel using this problem: the two landing buffers.
-    __host__ __device__ static size_t tape_lds_bytes() { return 2 * (size_t)M::LDS_STAGE_BYTES; }
+    /// bytes of one landing buffer (DEPTH == 2: with the tangent-state row behind the tangent tape)
+    static constexpr int LANDING_BYTES = DEPTH == 2 ? M::LDS_STAGE_BYTES_XT : M::LDS_STAGE_BYTES;
+    __host__ __device__ static size_t tape_lds_bytes() { return (size_t)(DEPTH + 1) * LANDING_BYTES; }
     /// Doubles of HBM workspace one instance needs: X and Xt rows, the tape, the tangent tape, and
     /// (used by the ITER_GLOBAL layout) the iterate vectors.
     __host__ __device__ static size_t workspace_doubles(int N) {
@@ -519,7 +525,131 @@ struct WaveProblem {
     /// landing buffers are distinct __shared__ objects and the stage loops are unrolled by two,
     /// so every LDS read names a buffer no DMA is writing (otherwise the compiler drains the
     /// in-flight DMA with vmcnt(0) before each read and the prefetch hides nothing).
-    __device__ __forceinline__ void hess_prod_tape(const double *v, double *Hv) const {
+    // ---- DEPTH == 2 -------------------------------------------------------------------------------
+    // Two stages ahead.  A wavefront of the one-stage-ahead form keeps 2-5 KiB of tape rows in flight; with a
+    // thousand such wavefronts on the chip the memory system runs at bytes-in-flight / latency, far below what
+    // it can deliver, and a product takes twice as long as on an empty chip (profiles/r04_product_under_load.txt).
+    // Here stage k's rows land in buffer k mod 3 and are requested while stage k -+ 2 computes.  s_waitcnt
+    // vmcnt(n) leaves the n youngest vector-memory operations of the wavefront in flight (they complete in
+    // order on this target), so each stage start names what may stay behind: the next stage's rows and the
+    // stores the previous stage issued after requesting them - counted from the source below (forward: two
+    // LDS-DMA operations, then five stores per stage; adjoint: six LDS-DMA operations);
+    // scripts/check_vmem_counts.py verifies the counts in the compiled code.  A smaller n is always safe.
+    template <int N_>
+    __device__ static __forceinline__ void wait_vmem_but() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+    }
+    __device__ __forceinline__ void hess_prod_tape_d2(const double *v, double *Hv) const {
+        wave_sync();
+#ifdef PANTR_PHASE_TIMING
+        const long long hv_t0_ = clock64();
+#endif
+        // ---- forward tangent sweep ----
+        State s_t{0.0, 0.0};
+        auto stage_fwd = [&](int k, char *cur, char *nxt2) {
+            // stage k's K rows have landed in `cur`; in flight behind them may be: stage k+1's rows (two
+            // operations, issued at the start of stage k-1) and the five stores stage k-1 issued after them
+            if (k == 0) {
+                if (N > 1)
+                    wait_vmem_but<2>(); // stage 1's rows
+                else
+                    wait_vmem();
+            } else if (k + 1 < N) {
+                wait_vmem_but<7>();
+            } else {
+                wait_vmem_but<5>(); // the last stage: nothing was requested after its rows but stage k-1's stores
+            }
+            if (k + 2 < N)
+                M::template prefetch_fwd<true>(L, tape + (size_t)(k + 2) * M::TAPE_D4_PER_STAGE, nxt2);
+            const double uc_t = M::load_input(L, v + M::nu * k);
+            M::xt_store(L, Xt + (size_t)k * M::XT_DOUBLES, s_t);
+            s_t = M::rk4_tan(L, cur, s_t, uc_t, st + (size_t)k * M::ST_D4_PER_STAGE, xs());
+        };
+        if (!primed)
+            prime();
+        for (int k = 0; k < N; k += 3) {
+            stage_fwd(k, tbuf0, tbuf2);
+            if (k + 1 < N)
+                stage_fwd(k + 1, tbuf1, tbuf0);
+            if (k + 2 < N)
+                stage_fwd(k + 2, tbuf2, tbuf1);
+        }
+        wave_sync();
+#ifdef PANTR_PHASE_TIMING
+        fwd_cycles += clock64() - hv_t0_;
+#endif
+        // ---- second-order adjoint sweep: stage k's rows (K, M, the tangent tape and the tangent-state row) in
+        // buffer k mod 3; nothing here loads into registers from HBM, so every wait of the sweep is one of the
+        // explicit ones below ----
+        State lam_t{0.0, 0.0};
+        M::cost_grad_x_add_tan(L, L.end ? s_t.x : s_t.v, lam_t);
+        auto rows_rev = [&](int k, char *buf) {
+            M::template prefetch_rev_xt<true>(L, tape + (size_t)k * M::TAPE_D4_PER_STAGE, st + (size_t)k * M::ST_D4_PER_STAGE,
+                                              Xt + (size_t)k * M::XT_DOUBLES, buf);
+        };
+        auto stage_rev = [&](int k, char *cur, char *nxt2) {
+            // stage k's rows have landed; behind them may be stage k-1's (six transfers, the youngest operations)
+            if (k >= 1)
+                wait_vmem_but<6>();
+            else
+                wait_vmem();
+            const double xt = M::xt_lds(L, cur);
+            double uc_t = M::load_input(L, v + M::nu * k);
+            if (k > 1) // two stages ahead
+                rows_rev(k - 2, nxt2);
+            State sbar_t;
+            double ubar_t;
+            M::rk4_adj_tan(L, cur, lam_t, sbar_t, ubar_t, xs());
+            M::store_input_grad(L, Hv + M::nu * k, __builtin_fma(M::c2g, uc_t, ubar_t));
+            lam_t = sbar_t;
+            M::cost_grad_x_add_tan(L, xt, lam_t);
+        };
+        // the first two stages' rows, the older request first (every request names its buffer: the compiler
+        // must see which landing buffer an LDS read can not be waiting for)
+        int k = N - 1;
+        auto first_rows = [&](char *b_last, char *b_before) {
+            rows_rev(k, b_last);
+            asm volatile("" ::: "memory");
+            if (k > 0)
+                rows_rev(k - 1, b_before);
+        };
+        if (k % 3 == 2)
+            first_rows(tbuf2, tbuf1);
+        else if (k % 3 == 1)
+            first_rows(tbuf1, tbuf0);
+        else
+            first_rows(tbuf0, tbuf2);
+        // down to a multiple of three by hand, then three stages per trip
+        if (k % 3 == 2) {
+            stage_rev(k, tbuf2, tbuf0);
+            --k;
+        }
+        if (k >= 0 && k % 3 == 1) {
+            stage_rev(k, tbuf1, tbuf2);
+            --k;
+        }
+        if (k >= 0) { // k % 3 == 0
+            stage_rev(k, tbuf0, tbuf1);
+            --k;
+        }
+        for (; k >= 2; k -= 3) {
+            stage_rev(k, tbuf2, tbuf0);
+            stage_rev(k - 1, tbuf1, tbuf2);
+            stage_rev(k - 2, tbuf0, tbuf1);
+        }
+        wave_sync();
+        prime(); // for the next product (the CG algebra runs meanwhile)
+        primed = true;
+    }
+    /// Request the K rows of the first two stages (stage 0's first).
+    __device__ __forceinline__ void prime() const {
+        M::template prefetch_fwd<true>(L, tape, tbuf0);
+        asm volatile("" ::: "memory");
+        if (N > 1)
+            M::template prefetch_fwd<true>(L, tape + (size_t)M::TAPE_D4_PER_STAGE, tbuf1);
+    }
+    // ---- DEPTH == 1 -------------------------------------------------------------------------------
+    __device__ __forceinline__ void hess_prod_tape_d1(const double *v, double *Hv) const {
         wave_sync();
 #ifdef PANTR_PHASE_TIMING
         const long long hv_t0_ = clock64();
@@ -580,6 +710,12 @@ struct WaveProblem {
         wave_sync();
         M::prefetch_fwd(L, tape, tbuf0); // for the next product (the CG algebra runs meanwhile)
         primed = true;
+    }
+    __device__ __forceinline__ void hess_prod_tape(const double *v, double *Hv) const {
+        if constexpr (DEPTH == 2)
+            hess_prod_tape_d2(v, Hv);
+        else
+            hess_prod_tape_d1(v, Hv);
     }
 
     // ---- vector helpers over the LDS vectors: lane l owns i = l, l+64, ... ------------------
@@ -1213,6 +1349,19 @@ __device__ __forceinline__ InnerResult inner_solve(PB &pb, const KernelParams &P
 // ---------------------------------------------------------------------------------------
 // The solve kernel for problems without general constraints (m = 0: ALM = one inner solve)
 // ---------------------------------------------------------------------------------------
+/// How far ahead the products of the two PANTR kernels of the hanging chain request their tape rows.  One
+/// wavefront per instance is what large batches run: a thousand and more wavefronts stream their tapes at once
+/// and the memory system delivers bytes-in-flight / latency - two stages ahead (N = 120, 1024 instances: 704 ->
+/// 521 ms per pass; the bench batch tiled eight times 19.9 -> 21.3 k steps/s).  Two wavefronts per instance is
+/// what small batches run, where a product is bound by its own instructions and the second stage in flight only
+/// costs some (67.6 -> 74.9 ms on the 600-instance bench batch): one stage ahead.  profiles/r04_prefetch_depth.txt.
+constexpr int CHAIN_SOLVE_PREFETCH_DEPTH = 2;
+constexpr int CHAIN_SPEC_PREFETCH_DEPTH  = 1;
+template <class M, int METHOD>
+using SolveProblemT = WaveProblem<M, METHOD == 0, false, METHOD == 0 ? CHAIN_SOLVE_PREFETCH_DEPTH : 1>;
+template <class M>
+using SpecProblemT = WaveProblem<M, true, true, CHAIN_SPEC_PREFETCH_DEPTH>;
+
 /// One instance, start to finish, on the calling wavefront (the body of both solve kernels).
 template <int METHOD, class PB, class M>
 __device__ __forceinline__ void solve_chain_instance(const SolveArgs &a, PB &pb, const typename M::Lane &, int lane,
@@ -1269,10 +1418,14 @@ __global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // 
     const long long t_start = wall_clock64(); // constant-rate clock, P.tick_s seconds per tick
     typename M::Lane L(lane);
 
-    __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
-    __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
-    using PB = WaveProblem<M, METHOD == 0>; // PANTR: iterates in HBM; the comparators: everything in LDS
+    using PB = SolveProblemT<M, METHOD>; // PANTR: iterates in HBM; the comparators: everything in LDS
+    __shared__ __attribute__((aligned(16))) char tape_buf0[PB::LANDING_BYTES];
+    __shared__ __attribute__((aligned(16))) char tape_buf1[PB::LANDING_BYTES];
     PB pb{L, a.prm.box, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
+    if constexpr (PB::PREFETCH_DEPTH == 2) {
+        __shared__ __attribute__((aligned(16))) char tape_buf2[PB::LANDING_BYTES];
+        pb.tbuf2 = tape_buf2;
+    }
     pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
     pb.xrow = lds + PB::LDS_SLOTS * a.npad;
@@ -1285,7 +1438,7 @@ __global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // 
 /// landing buffers, trajectory and tangent rows.  Dynamic LDS: spec_lds_doubles(npad) doubles.
 template <class M>
 __host__ __device__ constexpr size_t spec_lds_doubles(size_t npad) {
-    using PB = WaveProblem<M, true, true>;
+    using PB = SpecProblemT<M>;
     return (PB::LDS_SLOTS + PB::HELPER_SLOTS) * npad + 2 * PB::XS_DOUBLES;
 }
 template <class M>
@@ -1298,15 +1451,20 @@ __global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs
     const long long t_start = wall_clock64();
     typename M::Lane L(lane);
 
-    __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
-    __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
-    __shared__ __attribute__((aligned(16))) char helper_buf0[M::LDS_STAGE_BYTES];
-    __shared__ __attribute__((aligned(16))) char helper_buf1[M::LDS_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char tape_buf0[SpecProblemT<M>::LANDING_BYTES];
+    __shared__ __attribute__((aligned(16))) char tape_buf1[SpecProblemT<M>::LANDING_BYTES];
+    __shared__ __attribute__((aligned(16))) char helper_buf0[SpecProblemT<M>::LANDING_BYTES];
+    __shared__ __attribute__((aligned(16))) char helper_buf1[SpecProblemT<M>::LANDING_BYTES];
     __shared__ SpecBox box;
-    using PB = WaveProblem<M, true, true>;
+    using PB = SpecProblemT<M>;
     double *my = lds + (wave ? PB::LDS_SLOTS * a.npad + PB::XS_DOUBLES : 0);
     PB pb{L, a.prm.box, my, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr,
           wave ? helper_buf0 : tape_buf0, wave ? helper_buf1 : tape_buf1};
+    if constexpr (PB::PREFETCH_DEPTH == 2) {
+        __shared__ __attribute__((aligned(16))) char tape_buf2[PB::LANDING_BYTES];
+        __shared__ __attribute__((aligned(16))) char helper_buf2[PB::LANDING_BYTES];
+        pb.tbuf2 = wave ? helper_buf2 : tape_buf2;
+    }
     pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
     pb.xrow   = my + (wave ? PB::HELPER_SLOTS : PB::LDS_SLOTS) * a.npad;

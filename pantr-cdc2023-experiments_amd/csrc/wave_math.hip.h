@@ -311,10 +311,34 @@ __device__ __forceinline__ void wave_sync() {
 /// LDS-DMA (gfx950 global_load_lds_dwordx4): every lane fetches 16 bytes from its own global
 /// address and the wavefront's 1 KiB lands contiguously at the wave-uniform LDS address
 /// `lds_row` (+ lane*16), without passing through VGPRs.  Completion is tracked by vmcnt.
+/// OFFSET: the instruction's immediate offset, added to BOTH addresses (scripts/microbench/lds_dma_offset_test.hip):
+/// the consecutive 1 KiB rows of a stage go with one address register pair and one M0 value.
+/// HIDE: for sweeps that keep transfers of two stages in flight and wait for exactly the rows they are about to
+/// read (s_waitcnt vmcnt(n), WaveProblem::hess_prod_tape, DEPTH = 2).  The compiler keeps a record of its own of
+/// the LDS objects such transfers write and may put a full s_waitcnt vmcnt(0) in front of reads of them - it does
+/// not see the waits of the sweep - which would drain the pipeline.  Passing the (wave-uniform) address through an
+/// empty asm hides the object from that record: the explicit waits are the only ones, and they are sufficient
+/// (every read of a landing buffer follows the wait for its rows in program order).
+template <int OFFSET = 0, bool HIDE = false>
 __device__ __forceinline__ void lds_dma_row(const void *gsrc_lane, void *lds_row) {
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void *)gsrc_lane,
-        (__attribute__((address_space(3))) void *)lds_row, 16, 0, 0);
+    auto dst = (__attribute__((address_space(3))) char *)lds_row;
+    if constexpr (HIDE) {
+        int a = __builtin_amdgcn_readfirstlane((int)(uintptr_t)dst);
+        asm volatile("" : "+s"(a));
+        dst = (decltype(dst))(uintptr_t)(unsigned)a;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane, dst, 16, OFFSET, 0);
+}
+/// The 4-byte form (global_load_lds_dword): every lane fetches 4 bytes, the wavefront's 256 bytes land contiguously.
+template <bool HIDE = false>
+__device__ __forceinline__ void lds_dma_row256(const void *gsrc_lane, void *lds_row) {
+    auto dst = (__attribute__((address_space(3))) char *)lds_row;
+    if constexpr (HIDE) {
+        int a = __builtin_amdgcn_readfirstlane((int)(uintptr_t)dst);
+        asm volatile("" : "+s"(a));
+        dst = (decltype(dst))(uintptr_t)(unsigned)a;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane, dst, 4, 0, 0);
 }
 /// Wait until this wavefront's outstanding global loads/stores and LDS-DMA have completed.
 __device__ __forceinline__ void wait_vmem() {

@@ -116,17 +116,20 @@ def closed_loop_batch(problem, horizon, num_sim=NUM_SIM, starts=(True, False), d
     b = PantrBatch(problem, horizon, 1, device=device, opts=opts)
     u_dist = np.array([[-1.0, 1.0, 1.0]]) if chain else np.zeros((1, b.nu))      # dodo.py:94-100
     num_dist = 5 if chain else 0
-    x0, u0, y0, sol, warm_flags = [], [], [], [], []
+    x0, u0, y0, sol, warm_flags, cost = [], [], [], [], [], []
     for warm in starts:
         states, inputs, stats, rec = b.mpc(num_sim, warm, u_dist, num_dist=num_dist, record=True)
         if not np.all(stats["status"] == 1):
             raise RuntimeError(f"{problem} N={horizon} {'warm' if warm else 'cold'}: a closed-loop step did not converge")
         x0.append(states[:num_sim, 0]); u0.append(rec["guess_u"][:, 0]); y0.append(rec["guess_y"][:, 0])
         sol.append(inputs[:, 0]); warm_flags += [warm] * num_sim
+        cost.append(stats["n_hess_psi_prod"][:num_sim, 0].astype(np.float64) * horizon)
     m = b.m
     b.close()
     return dict(problem=problem, horizon=horizon, x0=np.vstack(x0), u0=np.vstack(u0),
                 y0=np.vstack(y0) if m else None, sol=np.vstack(sol), warm=np.array(warm_flags), opts=opts,
+                # what every instance cost when it was recorded: products x horizon (sharding deals longest first)
+                cost=np.concatenate(cost),
                 label=f"{problem} N={horizon}: {num_sim} time steps x {len(starts)} starts")
 
 
@@ -137,7 +140,7 @@ def headline_batch(device=0, num_sim=300, horizon=60):
     w = closed_loop_batch("hanging_chain", horizon, num_sim, starts=(True,), device=device)
     B = len(w["x0"])
     return dict(w, x0=np.vstack([w["x0"], w["x0"]]), u0=np.vstack([w["u0"], np.zeros_like(w["u0"])]),
-                sol=w["sol"], warm=np.r_[np.ones(B, bool), np.zeros(B, bool)],
+                sol=w["sol"], warm=np.r_[np.ones(B, bool), np.zeros(B, bool)], cost=None,  # (the cold twins have no record)
                 label=f"hanging_chain N={horizon}: {num_sim} time steps of one warm closed loop, each solved warm and cold")
 
 
@@ -151,12 +154,13 @@ def stress_batch(B=1024, device=0, horizon=120):
         x0 = b.simulate_dynamics(x0, d)
     n = b.n
     b.close()
-    return dict(problem="hanging_chain", horizon=horizon, x0=x0, u0=np.zeros((B, n)), y0=None, sol=None,
+    return dict(problem="hanging_chain", horizon=horizon, x0=x0, u0=np.zeros((B, n)), y0=None, sol=None, cost=None,
                 warm=np.zeros(B, bool), opts=tuple(DODO_PANTR_OPTS),
                 label=f"hanging_chain N={horizon}: {B} synthetic initial states (mt19937_64(12345)), cold")
 
 
 def expected_cost(horizon, warm):
-    """Relative cost of one instance for longest-first dealing: the published mean
-    solver times grow like N^2.7 and a cold start costs about 2.5 warm ones."""
+    """Relative cost of one instance for longest-first dealing where a batch holds no recorded solves (the replay
+    batches carry `cost`, their own recorded product counts): the published mean solver times grow like N^2.7
+    and a cold start costs about 2.5 warm ones."""
     return float(horizon) ** 2.7 * (1.0 if warm else 2.5)

@@ -29,7 +29,7 @@ PARAM_DOUBLES = [
     "lbfgs_min_div_fac", "lbfgs_min_abs_s", "cbfgs_alpha", "cbfgs_eps",
 ]
 PARAM_INTS = ["max_iter", "stop_crit", "max_no_progress", "disable_acceleration", "alm_max_iter", "method",
-              "force_linesearch", "lbfgs_memory", "lbfgs_force_pos_def", "pad0"]
+              "force_linesearch", "lbfgs_memory", "lbfgs_force_pos_def", "variant"]
 METHOD = {"pantr": 0, "panoc": 1, "strucpanoc": 2}  # mpc-driver.cpp:364-384
 
 STOP_CRIT = {"ApproxKKT": 0, "ApproxKKT2": 1, "ProjGradNorm": 2, "ProjGradNorm2": 3,

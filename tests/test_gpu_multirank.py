@@ -1,0 +1,56 @@
+"""Two processes on the HIP path (-m gpu): the multi-GPU mode of SURVEY.md section 8(e) - one process per GPU, no
+collective on the data path - rehearsed on the one GPU a test box has: both ranks share device 0 and meet over gloo.
+What the driver's 1/2/4/8-GPU run does with RCCL and one device per rank is this code path."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_two_rank_sharded_batch_on_the_device(tmp_path):
+    """world_size 2: deal (longest first), solve every shard with the device kernels, gather, MAX - the gathered
+    solutions equal the unsharded device solve and the oracle's, bit for bit."""
+    script = os.path.join(ROOT, "tests", "gloo_shard_worker.py")
+    port = 33500 + (os.getpid() % 2000)
+    out = tmp_path / "result.npz"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script, str(out), "device"]
+    r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = np.load(out)
+    assert "pantr_solve" in str(d["kernel"])                              # the shards ran on the HIP path
+    assert np.array_equal(d["gathered"], d["unsharded_device"])           # sharded == unsharded
+    assert np.array_equal(d["gathered"], d["serial"])                     # == the oracle
+    assert d["world"] == 2 and sorted(np.concatenate([d["idx0"], d["idx1"]]).tolist()) == list(range(len(d["serial"])))
+
+
+@pytest.mark.parametrize("mode", [["--headline-only"], ["--workload", "sweep", "--scaling", "strong"]])
+def test_bench_launches_its_own_ranks(mode):
+    """`python bench.py --gpus 2` started bare (no torch.distributed.run around it, no WORLD_SIZE): it starts its two
+    ranks itself, before any HIP call of its own, and rank 0 prints the line (PANTR_BENCH_REHEARSAL: both ranks on
+    the one GPU, rendezvous over gloo).  Weak mode: two replicas of the batch; strong mode: one batch dealt to the
+    ranks by its recorded costs, gathered == unsharded."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PANTR_BENCH_REHEARSAL="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"] + mode
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
+    if "strong" in mode:
+        assert line["scaling"] == "strong" and line["config"]["gathered_equals_unsharded"] is True
+        assert "recorded n_hess_psi_prod" in line["config"]["partition"]
+        assert line["bound"]["slowest_instance_in_kernel_ms"] <= line["bound"]["ms_per_pass"] * 1.05
+    else:
+        assert line["scaling"] == "weak" and line["config"]["converged"] == 600
+        assert line["config"]["max_abs_dev_from_recorded_closed_loop"] == 0.0
