@@ -45,7 +45,7 @@ HORIZON = 60
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 HBM_COPY_GUIDE_GBS = 6290.0  # MI355X_MICROARCH.md:36: 6.29 TB/s measured with a float4 copy (79 % of the spec peak)
 FIXTURE = os.path.join(ROOT, "tests", "golden", "mpc_hanging_chain_N60_warm300.npz")
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 # PMC summary of the headline command (scripts/profile.sh + scripts/summarize_profiles.py)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_summary.json")
 # published mean solver time per MPC step, alpaqa PANTR, unstated CPU, 1 thread
@@ -74,6 +74,31 @@ def measured_traffic(instances):
         if "valu_issue" in d:  # what binds instead of HBM: VALU issue of lone wavefronts (same PMC passes)
             src["valu_issue"] = {k: d["valu_issue"][k] for k in ("simd_issue_slots_used_frac", "wave_slot_occupancy_frac",
                                                                  "cycles_per_valu_instruction_of_a_wavefront")}
+        return float(d["hbm_traffic_bytes_per_launch"]["total"]), src
+    except (OSError, KeyError, ValueError) as e:
+        src["refused"] = f"no usable summary ({type(e).__name__})"
+        return None, src
+
+
+def measured_workload_traffic(name, instances):
+    """HBM bytes per launch of a memory-bound workload from its committed rocprofv3 PMC passes
+    (scripts/traffic_profile.sh + scripts/summarize_traffic.py -> profiles/<tag>_<name>_traffic.json), with where they
+    come from; None unless the summary was taken at exactly this tree's sources (hash) and batch size."""
+    import pantr_amd as pa
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{name}_traffic.json")
+    src = {"file": os.path.relpath(path, ROOT), "csrc_sha256": pa.source_hash()}
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        src["profiled_csrc_sha256"] = d["run"].get("source_hash")
+        if src["profiled_csrc_sha256"] != src["csrc_sha256"]:
+            src["refused"] = "the kernels changed since the PMC passes were taken"
+            return None, src
+        if int(d["run"]["instances"]) != instances:
+            src["refused"] = "the PMC passes were taken on another batch size"
+            return None, src
+        src["traffic_over_algorithmic"] = d["traffic_over_algorithmic"]
+        src["profiled_kernel_ms"] = d["kernel_trace"]["avg_ms"]
         return float(d["hbm_traffic_bytes_per_launch"]["total"]), src
     except (OSError, KeyError, ValueError) as e:
         src["refused"] = f"no usable summary ({type(e).__name__})"
@@ -252,16 +277,17 @@ def extra_configs(torch, pa, dev, local_rank, cores, peak_measured, with_cpu):
     from pantr_amd import workloads
     out = {}
 
-    def one(name, ws, description, cpu_sample=None):
+    def one(name, ws, description, cpu_sample=None, traffic_name=None, with_cpu=with_cpu):
         rs = [Resident(w, torch, pa, dev, local_rank) for w in ws]
         wall, kms = time_group(rs, torch)
         for r in rs:
             r.check(name)
         total = sum(r.B for r in rs)
         dom = int(np.argmax(kms))                      # the launch that decides the wall time
+        traffic, traffic_src = measured_workload_traffic(traffic_name, total) if traffic_name else (None, None)
         cfg = {"workload": description, "instances": total, "launches_per_pass": len(rs),
                "value": total / wall, "unit": "steps/s", "ms_per_pass": wall * 1e3,
-               "roofline": roofline_obj(rs[dom].alg_bytes(), kms[dom], rs[dom].kernel_name(), peak_measured),
+               "roofline": roofline_obj(rs[dom].alg_bytes(), kms[dom], rs[dom].kernel_name(), peak_measured, traffic, traffic_src),
                "all_launches": {"algorithmic_bytes": int(sum(r.alg_bytes() for r in rs)),
                                 "achieved_GBps": sum(r.alg_bytes() for r in rs) / wall / 1e9,
                                 "kernel_ms": kms}}
@@ -294,7 +320,13 @@ def extra_configs(torch, pa, dev, local_rank, cores, peak_measured, with_cpu):
     # configs[4] on ONE GPU: all 1024
     one("stress_N120", [workloads.stress_batch(1024, device=local_rank)],
         "BASELINE.json configs[4] on one GPU: hanging_chain N=120 (n=360), 1024 synthetic cold instances in one launch",
-        cpu_sample=np.arange(0, 1024, 8))
+        cpu_sample=np.arange(0, 1024, 8), traffic_name="stress")
+    # the memory-bound regime of the headline kernel family: the bench batch tiled eight times into ONE launch
+    hw = workloads.headline_batch(device=local_rank, num_sim=300, horizon=HORIZON)
+    tiled = dict(hw, x0=np.tile(hw["x0"], (8, 1)), u0=np.tile(hw["u0"], (8, 1)), sol=None, warm=np.tile(hw["warm"], 8))
+    one("tile8", [tiled], "the 600-instance bench batch tiled 8 times: 4800 hanging_chain N=60 instances in one launch (one "
+        "wavefront per instance, seven per compute unit): where the kernel is bound by the memory system", traffic_name="tile8",
+        with_cpu=False)
     return out
 
 

@@ -257,8 +257,17 @@ int pantr_device_copy_bandwidth(int32_t device, int64_t bytes, int32_t reps, dou
  * the namespace): which one depends on the problem, on `method=` and - method=pantr - on `speculation=`
  * and B (one or two wavefronts per instance).  Measurement code names its dominant kernel with it. */
 const char *pantr_batch_kernel_name(const pantr_batch_t *b, int32_t B);
-/* Bytes of LDS per workgroup and of HBM workspace per instance for this handle. */
+/* Bytes of LDS per workgroup and of HBM workspace per instance for this handle: of the kernel a solve of the
+ * handle's maximum batch size launches (pantr_batch_footprint), or of B instances (pantr_batch_footprint_for) - a
+ * smaller batch may run the two-wavefront kernel, which takes about twice the LDS (pantr_batch_kernel_name(b, B)
+ * names the kernel the figure belongs to). */
 int pantr_batch_footprint(const pantr_batch_t *b, int64_t *lds_bytes, int64_t *ws_bytes_per_instance);
+int pantr_batch_footprint_for(const pantr_batch_t *b, int32_t B, int64_t *lds_bytes, int64_t *ws_bytes_per_instance);
+/* pantr_batch_solve_device checks where its four buffers live (hipPointerGetAttributes) once per set of base
+ * pointers and not again while a caller passes the same set - the queries stay off the launch path.  Contract: a
+ * caller that frees or re-allocates any of those buffers calls this before its next solve (a failed solve forgets
+ * the set by itself).  A handle is not thread-safe: one thread at a time. */
+int pantr_batch_forget_buffers(pantr_batch_t *b);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,8 @@ struct ChainModel {
         int e[DIM];     ///< upper-triangle indices of row c of a symmetric 3x3
         bool active, mass, end, first, lead, grav;
         double inv_m_l; ///< 1/m on the masses' lanes, 0 elsewhere (keeps idle lanes' derivatives at 0)
+        double mass_l;  ///< 1 on the masses' lanes, 0 elsewhere: `mass ? x : 0` as one multiplication in the tangent sweeps
+        double nend_l;  ///< 0 on the end point's lanes, 1 elsewhere: `end ? a : a - b` as fma(-nend_l, b, a)
         __device__ explicit Lane(int lane) {
             l      = lane;
             p      = lane & 15;
@@ -81,6 +83,8 @@ struct ChainModel {
             lead   = active && c == 0;
             grav   = mass && c == DIM - 1;
             inv_m_l = mass ? inv_m : 0.0;
+            mass_l  = mass ? 1.0 : 0.0;
+            nend_l  = end ? 0.0 : 1.0;
             q      = active ? DIM * p + c : 31;
             pc     = p < NP ? p : NP - 1;
             int cc = c < DIM ? c : 0;
@@ -295,33 +299,44 @@ struct ChainModel {
     }
     /// Start the LDS-DMA of one stage into the landing buffer `buf`: 2 KiB (K rows) for the
     /// forward sweep; 4 KiB of tape + 1 KiB of tangent tape for the adjoint sweep.
-    /// (HIDE: wave_math.hip.h, lds_dma_row)
-    template <bool HIDE = false>
+    /// The transfers of a stage: immediate offsets on one address register pair.  GROUP: as asm groups with one M0
+    /// write each (wave_math.hip.h, lds_dma_rows) - the sweeps that wait for their rows with explicit vmcnt counts
+    /// (two stages ahead) use these; the one-stage-ahead sweeps keep the builtin form, whose transfers the
+    /// compiler schedules among the stage's other instructions.
+    template <bool GROUP = false>
     __device__ static __forceinline__ void prefetch_fwd(const Lane &L, const double4 *tape_stage, char *buf) {
         const char *src = reinterpret_cast<const char *>(tape_stage) + L.l * 16;
-        lds_dma_row<0, HIDE>(src, buf); // (the immediate offset moves both addresses)
-        lds_dma_row<1024, HIDE>(src, buf);
+        if constexpr (GROUP) {
+            lds_dma_rows<2>(src, buf);
+        } else {
+            lds_dma_row<0>(src, buf);
+            lds_dma_row<1024>(src, buf);
+        }
     }
-    template <bool HIDE = false>
+    template <bool GROUP = false>
     __device__ static __forceinline__ void prefetch_rev(const Lane &L, const double4 *tape_stage,
                                                         const double4 *st_stage, char *buf) {
+        static_assert(TAPE_STAGE_BYTES == 4096 && ST_STAGE_BYTES == 1024, "four + one 1 KiB transfers");
         const char *src = reinterpret_cast<const char *>(tape_stage) + L.l * 16;
-        static_assert(TAPE_STAGE_BYTES == 4096, "four 1 KiB transfers");
-        lds_dma_row<0, HIDE>(src, buf);
-        lds_dma_row<1024, HIDE>(src, buf);
-        lds_dma_row<2048, HIDE>(src, buf);
-        lds_dma_row<3072, HIDE>(src, buf);
-        lds_dma_row<0, HIDE>(reinterpret_cast<const char *>(st_stage) + L.l * 16, buf + TAPE_STAGE_BYTES);
+        if constexpr (GROUP) {
+            lds_dma_rows<4>(src, buf);
+            lds_dma_rows<1>(reinterpret_cast<const char *>(st_stage) + L.l * 16, buf + TAPE_STAGE_BYTES);
+        } else {
+            lds_dma_row<0>(src, buf);
+            lds_dma_row<1024>(src, buf);
+            lds_dma_row<2048>(src, buf);
+            lds_dma_row<3072>(src, buf);
+            lds_dma_row<0>(reinterpret_cast<const char *>(st_stage) + L.l * 16, buf + TAPE_STAGE_BYTES);
+        }
     }
     /// The same plus the stage's tangent-state row (256 bytes, one 4-byte transfer per lane) behind the tangent
     /// tape in the landing buffer: sweeps that run two stages ahead read it from LDS (xt_lds) instead of waiting
     /// for a register load among the transfers in flight.  Six transfers.
     static constexpr int LDS_STAGE_BYTES_XT = LDS_STAGE_BYTES + XT_DOUBLES * 8;
-    template <bool HIDE = false>
     __device__ static __forceinline__ void prefetch_rev_xt(const Lane &L, const double4 *tape_stage, const double4 *st_stage,
                                                            const double *xt_row, char *buf) {
-        prefetch_rev<HIDE>(L, tape_stage, st_stage, buf);
-        lds_dma_row256<HIDE>(reinterpret_cast<const char *>(xt_row) + L.l * 4, buf + LDS_STAGE_BYTES);
+        prefetch_rev<true>(L, tape_stage, st_stage, buf);
+        lds_dma_256(reinterpret_cast<const char *>(xt_row) + L.l * 4, buf + LDS_STAGE_BYTES);
     }
     __device__ static __forceinline__ double xt_lds(const Lane &L, const char *buf) {
         return reinterpret_cast<const double *>(buf + LDS_STAGE_BYTES)[L.q];
@@ -394,8 +409,10 @@ struct ChainModel {
         ldA        = __builtin_fma(gA.M[2], gA.D[2], ldA);
         ldB        = __builtin_fma(gB.M[2], gB.D[2], ldB);
         double nA = next_point(L, ldA), nB = next_point(L, ldB);
-        oA = L.end ? ldA : ldA - nA;
-        oB = L.end ? ldB : ldB - nB;
+        // end ? ld : ld - n, without the select: one rounding either way; the lane after the end point holds a
+        // finite value (clamped tape reads), so 0 * n is 0
+        oA = __builtin_fma(-L.nend_l, nA, ldA);
+        oB = __builtin_fma(-L.nend_l, nB, ldB);
     }
     /// Tangent of one RK4 step; the stage's K rows are in LDS at `buf`.
     __device__ static __forceinline__ State rk4_tan(const Lane &L, const char *buf, const State &s_in, double uc_t,
@@ -423,19 +440,21 @@ struct ChainModel {
         // G_j from kbv_j (springs), m_j = kbx_j on the masses (0 elsewhere: keeps kbv at 0 off the masses)
         const double sgx = c6 * mu_t.x, sgv = c6 * mu_t.v;
         const double sgx2 = 2.0 * sgx, sgv2 = 2.0 * sgv;
-        const double m4   = L.mass ? sgx : 0.0;
+        // m = mass ? x : 0 as one multiplication (the x of these sweeps are finite; a zero's sign may differ): 66.3 against
+        // 67.3 ms per pass of the bench batch with selects
+        const double m4   = L.mass_l * sgx;
         const double kbv3 = __builtin_fma(Ts, m4, sgv2);
         double G4, G3, G2, G1;
         fc_adj_tan2(L, buf, 3, 2, sgv, kbv3, xs, G4, G3);
         const double kbx3 = __builtin_fma(Ts, G4, sgx2);
-        const double m3   = L.mass ? kbx3 : 0.0;
+        const double m3   = L.mass_l * kbx3;
         const double kbv2 = __builtin_fma(hTs, m3, sgv2);
         const double kbx2 = __builtin_fma(hTs, G3, sgx2);
-        const double m2   = L.mass ? kbx2 : 0.0;
+        const double m2   = L.mass_l * kbx2;
         const double kbv1 = __builtin_fma(hTs, m2, sgv);
         fc_adj_tan2(L, buf, 1, 0, kbv2, kbv1, xs, G2, G1);
         const double kbx1 = __builtin_fma(hTs, G2, sgx);
-        const double m1   = L.mass ? kbx1 : 0.0;
+        const double m1   = L.mass_l * kbx1;
         sbar_t = {(((mu_t.x + G4) + G3) + G2) + G1, (((mu_t.v + m4) + m3) + m2) + m1};
         ubar_t = ((sgx + kbx3) + kbx2) + kbx1;
     }

@@ -937,14 +937,19 @@ int pantr_batch_get_param(const pantr_batch_t *b, const char *key, double *value
 }
 
 int pantr_batch_footprint(const pantr_batch_t *b, int64_t *lds_bytes, int64_t *ws_bytes_per_instance) {
+    return pantr_batch_footprint_for(b, b ? b->maxB : 0, lds_bytes, ws_bytes_per_instance);
+}
+int pantr_batch_footprint_for(const pantr_batch_t *b, int32_t B, int64_t *lds_bytes, int64_t *ws_bytes_per_instance) {
     if (!b)
         return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
-    if (lds_bytes) { // of the solve kernel the handle's current method selects, for a batch of its maximum size
+    if (B < 1 || B > b->maxB)
+        return fail(PANTR_ERR_OUT_OF_RANGE, "batch size outside [1, max_instances]");
+    if (lds_bytes) { // of the solve kernel the handle's current method and options select for a batch of B (pantr_batch_kernel_name)
         const bool pantr_chain = !b->al() && b->opts.method == host::Method::PANTR;
         const bool cmp_scalar = b->al() && b->opts.method != host::Method::PANTR;
-        if (pantr_chain && use_speculation(b, b->maxB))
+        if (pantr_chain && use_speculation(b, B))
             *lds_bytes = (int64_t)spec_lds_total(*b);
-        else if (b->al() && use_alm_speculation(b, b->maxB))
+        else if (b->al() && use_alm_speculation(b, B))
             *lds_bytes = (int64_t)(alm_spec_lds_bytes(*b) + sizeof(SpecBox));
         else
             *lds_bytes = (int64_t)((pantr_chain ? b->lds_bytes_pantr : cmp_scalar ? b->lds_bytes_cmp : b->lds_bytes) +
@@ -1023,6 +1028,7 @@ int pantr_batch_solve_device(pantr_batch_t *b, int32_t B, const double *d_x0, do
             if (!ok) {
                 (void)hipGetLastError();
                 return fail(PANTR_ERR_NO_DEVICE,
+                            // (the set stays unaccepted: checked_ptrs is only written after all four passed)
                             "pantr_batch_solve_device: a buffer is not device (or managed) memory of this handle's GPU as "
                             "seen by the HIP runtime this library is bound to (in a process that also uses PyTorch, "
                             "import torch and initialise torch.cuda before the first call into this library)");
@@ -1030,8 +1036,18 @@ int pantr_batch_solve_device(pantr_batch_t *b, int32_t B, const double *d_x0, do
         }
         std::memcpy(b->checked_ptrs, ptrs, sizeof ptrs);
     }
-    return launch_solve(b, B, d_x0, d_u, d_y, reinterpret_cast<DeviceStats *>(d_stats),
-                        static_cast<hipStream_t>(stream));
+    const int rc = launch_solve(b, B, d_x0, d_u, d_y, reinterpret_cast<DeviceStats *>(d_stats),
+                                static_cast<hipStream_t>(stream));
+    if (rc != PANTR_OK) // whatever went wrong: the next call looks at its buffers again
+        std::memset(b->checked_ptrs, 0, sizeof b->checked_ptrs);
+    return rc;
+}
+
+int pantr_batch_forget_buffers(pantr_batch_t *b) {
+    if (!b)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
+    std::memset(b->checked_ptrs, 0, sizeof b->checked_ptrs);
+    return PANTR_OK;
 }
 
 int pantr_batch_last_kernel_ms(pantr_batch_t *b, float *ms) {

@@ -584,7 +584,7 @@ struct WaveProblem {
         State lam_t{0.0, 0.0};
         M::cost_grad_x_add_tan(L, L.end ? s_t.x : s_t.v, lam_t);
         auto rows_rev = [&](int k, char *buf) {
-            M::template prefetch_rev_xt<true>(L, tape + (size_t)k * M::TAPE_D4_PER_STAGE, st + (size_t)k * M::ST_D4_PER_STAGE,
+            M::prefetch_rev_xt(L, tape + (size_t)k * M::TAPE_D4_PER_STAGE, st + (size_t)k * M::ST_D4_PER_STAGE,
                                               Xt + (size_t)k * M::XT_DOUBLES, buf);
         };
         auto stage_rev = [&](int k, char *cur, char *nxt2) {
@@ -1457,21 +1457,6 @@ __global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs
     __shared__ __attribute__((aligned(16))) char helper_buf1[SpecProblemT<M>::LANDING_BYTES];
     __shared__ SpecBox box;
     using PB = SpecProblemT<M>;
-    double *my = lds + (wave ? PB::LDS_SLOTS * a.npad + PB::XS_DOUBLES : 0);
-    PB pb{L, a.prm.box, my, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr,
-          wave ? helper_buf0 : tape_buf0, wave ? helper_buf1 : tape_buf1};
-    if constexpr (PB::PREFETCH_DEPTH == 2) {
-        __shared__ __attribute__((aligned(16))) char tape_buf2[PB::LANDING_BYTES];
-        __shared__ __attribute__((aligned(16))) char helper_buf2[PB::LANDING_BYTES];
-        pb.tbuf2 = wave ? helper_buf2 : tape_buf2;
-    }
-    pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
-    pb.bind_workspace(a.ws, inst);
-    pb.xrow   = my + (wave ? PB::HELPER_SLOTS : PB::LDS_SLOTS) * a.npad;
-    pb.wg_lds = lds;
-    pb.spec   = &box;
-    pb.spec_tick_s = a.prm.tick_s;
-    pb.spec_patience_s = a.prm.spec_patience_s;
     if (threadIdx.x == 0) {
         box.req_seq = 0;
         box.done_seq = 0;
@@ -1479,7 +1464,26 @@ __global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs
         box.abort = 0;
     }
     __syncthreads(); // the only workgroup barrier: the mailbox exists before either wavefront reads it
+    // The two wavefronts build their problem objects in branches of their own, so that each sees its landing
+    // buffers as the constants they are (an address selected by the wavefront's index would be a register value:
+    // every LDS-DMA transfer would fetch it with v_readfirstlane before it can write M0).
+    auto bind = [&](PB &pb, double *my, int slots) {
+        pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
+        pb.bind_workspace(a.ws, inst);
+        pb.xrow   = my + slots * a.npad;
+        pb.wg_lds = lds;
+        pb.spec   = &box;
+        pb.spec_tick_s = a.prm.tick_s;
+        pb.spec_patience_s = a.prm.spec_patience_s;
+    };
     if (wave == 1) {
+        double *my = lds + PB::LDS_SLOTS * a.npad + PB::XS_DOUBLES;
+        PB pb{L, a.prm.box, my, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, helper_buf0, helper_buf1};
+        if constexpr (PB::PREFETCH_DEPTH == 2) {
+            __shared__ __attribute__((aligned(16))) char helper_buf2[PB::LANDING_BYTES];
+            pb.tbuf2 = helper_buf2;
+        }
+        bind(pb, my, PB::HELPER_SLOTS);
         for (int i = lane; i < PB::HELPER_SLOTS * a.npad; i += WAVE)
             my[i] = 0.0;
         wave_sync();
@@ -1489,6 +1493,13 @@ __global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs
         pb.spec_serve(a.prm, t_start);
         return;
     }
+    double *my = lds;
+    PB pb{L, a.prm.box, my, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
+    if constexpr (PB::PREFETCH_DEPTH == 2) {
+        __shared__ __attribute__((aligned(16))) char tape_buf2[PB::LANDING_BYTES];
+        pb.tbuf2 = tape_buf2;
+    }
+    bind(pb, my, PB::LDS_SLOTS);
     // where a SIMD holds a helper of one instance and the solver of another, the solver issues first
     __builtin_amdgcn_s_setprio(3);
     solve_chain_instance<0, PB, M>(a, pb, L, lane, inst, t_start, my);

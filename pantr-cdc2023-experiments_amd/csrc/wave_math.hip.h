@@ -312,34 +312,45 @@ __device__ __forceinline__ void wave_sync() {
 /// address and the wavefront's 1 KiB lands contiguously at the wave-uniform LDS address
 /// `lds_row` (+ lane*16), without passing through VGPRs.  Completion is tracked by vmcnt.
 /// OFFSET: the instruction's immediate offset, added to BOTH addresses (scripts/microbench/lds_dma_offset_test.hip):
-/// the consecutive 1 KiB rows of a stage go with one address register pair and one M0 value.
-/// HIDE: for sweeps that keep transfers of two stages in flight and wait for exactly the rows they are about to
-/// read (s_waitcnt vmcnt(n), WaveProblem::hess_prod_tape, DEPTH = 2).  The compiler keeps a record of its own of
-/// the LDS objects such transfers write and may put a full s_waitcnt vmcnt(0) in front of reads of them - it does
-/// not see the waits of the sweep - which would drain the pipeline.  Passing the (wave-uniform) address through an
-/// empty asm hides the object from that record: the explicit waits are the only ones, and they are sufficient
-/// (every read of a landing buffer follows the wait for its rows in program order).
-template <int OFFSET = 0, bool HIDE = false>
+/// the consecutive 1 KiB rows of a stage go with one address register pair.
+template <int OFFSET = 0>
 __device__ __forceinline__ void lds_dma_row(const void *gsrc_lane, void *lds_row) {
-    auto dst = (__attribute__((address_space(3))) char *)lds_row;
-    if constexpr (HIDE) {
-        int a = __builtin_amdgcn_readfirstlane((int)(uintptr_t)dst);
-        asm volatile("" : "+s"(a));
-        dst = (decltype(dst))(uintptr_t)(unsigned)a;
-    }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane, dst, 16, OFFSET, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
+                                     (__attribute__((address_space(3))) void *)lds_row, 16, OFFSET, 0);
 }
-/// The 4-byte form (global_load_lds_dword): every lane fetches 4 bytes, the wavefront's 256 bytes land contiguously.
-template <bool HIDE = false>
-__device__ __forceinline__ void lds_dma_row256(const void *gsrc_lane, void *lds_row) {
-    auto dst = (__attribute__((address_space(3))) char *)lds_row;
-    if constexpr (HIDE) {
-        int a = __builtin_amdgcn_readfirstlane((int)(uintptr_t)dst);
-        asm volatile("" : "+s"(a));
-        dst = (decltype(dst))(uintptr_t)(unsigned)a;
-    }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane, dst, 4, 0, 0);
+/// ROWS consecutive 1 KiB rows (ROWS <= 4) from one per-lane global address to one LDS address, as one group of
+/// global_load_lds_dwordx4 with immediate offsets 0, 1024, ... and M0 written ONCE: the builtin form writes M0
+/// anew before every transfer (two scalar instructions each), and a lone wavefront pays for every instruction
+/// it issues.  The transfers are invisible to the compiler's s_waitcnt bookkeeping - which only makes the waits
+/// it inserts for its own loads more conservative (vmcnt counts every operation) - and to its record of the LDS
+/// objects LDS-DMA writes, from which it would otherwise put a full s_waitcnt vmcnt(0) in front of some reads of
+/// the landing buffers (it does not see a sweep's explicit vmcnt(n) waits): a sweep using this waits for its rows
+/// explicitly (WaveProblem::hess_prod_tape_d2).  lds_row must be wave-uniform.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm" // (M0 on the clobber list: the compiler writes M0 right before each of its own uses)
+template <int ROWS>
+__device__ __forceinline__ void lds_dma_rows(const void *gsrc_lane, void *lds_row) {
+    static_assert(ROWS >= 1 && ROWS <= 4, "immediate offsets up to 3072");
+    const int dst = __builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) char *)lds_row);
+    if constexpr (ROWS == 1)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(dst) : "memory", "m0");
+    else if constexpr (ROWS == 2)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
+                     ::"v"(gsrc_lane), "s"(dst) : "memory", "m0");
+    else if constexpr (ROWS == 3)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:2048" ::"v"(gsrc_lane), "s"(dst) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                     ::"v"(gsrc_lane), "s"(dst) : "memory", "m0");
 }
+/// The 4-byte form in the same manner: 256 bytes per wavefront.
+__device__ __forceinline__ void lds_dma_256(const void *gsrc_lane, void *lds_row) {
+    const int dst = __builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) char *)lds_row);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc_lane), "s"(dst) : "memory", "m0");
+}
+#pragma clang diagnostic pop
 /// Wait until this wavefront's outstanding global loads/stores and LDS-DMA have completed.
 __device__ __forceinline__ void wait_vmem() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

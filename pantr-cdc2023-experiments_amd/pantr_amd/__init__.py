@@ -92,7 +92,8 @@ EXPORTS = (
     "pantr_batch_get_trace", "pantr_batch_eval_psi", "pantr_batch_eval_psi_grad_psi",
     "pantr_batch_eval_hess_psi_prod", "pantr_batch_eval_prox_grad_step",
     "pantr_batch_simulate_dynamics", "pantr_batch_mpc", "pantr_last_error", "pantr_version", "pantr_device_count",
-    "pantr_batch_footprint", "pantr_batch_eval_grad_L", "pantr_batch_create_from_files",
+    "pantr_batch_footprint", "pantr_batch_footprint_for", "pantr_batch_forget_buffers", "pantr_batch_eval_grad_L",
+    "pantr_batch_create_from_files",
     "pantr_batch_get_penalty_alm_split", "pantr_problem_data_load", "pantr_problem_data_destroy",
     "pantr_problem_data_get", "pantr_problem_dims", "pantr_problem_defaults", "pantr_batch_eval_g",
     "pantr_batch_mpc_record", "pantr_device_copy_bandwidth", "pantr_source_hash", "pantr_stats_size",
@@ -167,6 +168,8 @@ def lib():
         L.pantr_batch_simulate_dynamics.argtypes = [vp, _i32, vp, vp, vp]
         L.pantr_batch_mpc.argtypes = [vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp, vp]
         L.pantr_batch_footprint.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.pantr_batch_footprint_for.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.pantr_batch_forget_buffers.argtypes = [vp]
         L.pantr_batch_eval_grad_L.argtypes = [vp, _i32, vp, vp, vp, vp]
         L.pantr_batch_eval_g.argtypes = [vp, _i32, vp, vp, vp]
         L.pantr_batch_mpc_record.argtypes = [vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -354,10 +357,19 @@ class PantrBatch:
         f.restype, f.argtypes = C.c_char_p, [C.c_void_p, _i32]
         return f(self._h, self.max_instances if B is None else int(B)).decode()
 
-    def footprint(self):
+    def footprint(self, B=None):
+        """(LDS bytes per workgroup, HBM workspace bytes per instance) of the kernel a solve of B instances launches
+        (default: the handle's maximum batch size; kernel_name(B) names that kernel)."""
         a, b = C.c_int64(), C.c_int64()
-        _check(lib().pantr_batch_footprint(self._h, C.byref(a), C.byref(b)))
+        if B is None:
+            _check(lib().pantr_batch_footprint(self._h, C.byref(a), C.byref(b)))
+        else:
+            _check(lib().pantr_batch_footprint_for(self._h, B, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def forget_buffers(self):
+        """After freeing or re-allocating buffers passed to solve_device: have the next call check them again."""
+        _check(lib().pantr_batch_forget_buffers(self._h))
 
     # ---- hot path ------------------------------------------------------------------------
     def solve(self, x0, u0):

@@ -4,7 +4,7 @@
 #   scripts/collect_records.sh r03
 set -e
 cd "$(dirname "$0")/.."
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=gpurun_out/$TAG
 for f in bench bench_streams4; do
     [ -s $R/$f.json ] && tail -1 $R/$f.json > profiles/${TAG}_$f.json
@@ -17,6 +17,8 @@ done
 grep -v amdgpu.ids $R/saturation.txt > profiles/${TAG}_saturation.txt
 grep -v 'amdgpu.ids\|rocprofv3\|Opened result\|HSA version' $R/rows_workload.txt > profiles/${TAG}_rows_f1_f4_workload.txt
 cp "$(ls -t gpurun_out/prof_rows/*/*_kernel_stats.csv | head -1)" profiles/${TAG}_rows_f1_f4_kernel_stats.csv
+[ -s $R/product_under_load.txt ] && grep -v amdgpu.ids $R/product_under_load.txt > profiles/${TAG}_product_under_load.txt
 python scripts/summarize_profiles.py $TAG > /dev/null
+python scripts/summarize_traffic.py $TAG stress tile8
 python scripts/kernel_resources.py > profiles/${TAG}_kernel_resources.txt 2> /dev/null || true
 ls -la profiles/ | grep ${TAG}_

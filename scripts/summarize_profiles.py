@@ -16,7 +16,7 @@ def newest(pattern):
     return max(files, key=os.path.getmtime) if files else None
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -33,9 +33,20 @@ def timed_grid():
     raise SystemExit("no timed launch of the solve kernel in the trace")
 
 
+def gpu_agent():
+    """Compute units, SIMDs per CU and the engine clock (MHz) of the profiled GPU, from the trace's agent table."""
+    f = newest(os.path.join(src, "stats", "*", "*_agent_info.csv"))
+    for r in csv.DictReader(open(f)):
+        if r["Agent_Type"] == "GPU":
+            return int(r["Cu_Count"]), int(r["Simd_Per_Cu"]), float(r["Max_Engine_Clk_Fcompute"])
+    raise SystemExit("no GPU agent in the trace")
+
+
 GRID, KERNEL_FULL = timed_grid()
+CUS, SIMDS_PER_CU, CLK_MHZ = gpu_agent()
 summary = {"tag": tag, "command": "python3 bench.py --steps 3 --warmup 1 --headline-only",
            "kernel": KERNEL_FULL, "wavefronts_per_instance": GRID // (INSTANCES * 64),
+           "gpu": {"compute_units": CUS, "simds_per_cu": SIMDS_PER_CU, "engine_clock_mhz": CLK_MHZ},
            # the code these numbers describe: bench.py prints roofline.traffic only while csrc/ still hashes to this
            "csrc_sha256": pa.source_hash()}
 stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
@@ -75,25 +86,25 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         "note": "KiB -> bytes; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request)"}
 if "SQ_INSTS_VALU" in pmc and "SQ_WAVE_CYCLES" in pmc and summary.get("kernel_trace_timed_launches", {}).get("avg_ms"):
     # what actually bounds the kernel: VALU issue of lone wavefronts (MI355X_MICROARCH.md: SQ_WAVE_CYCLES counts
-    # quad-cycles; a 64-wide fp64 / DPP instruction occupies a SIMD for 4 cycles; 256 CUs x 4 SIMDs, 2.4 GHz)
+    # quad-cycles; a 64-wide fp64 / DPP instruction occupies a SIMD for 4 cycles; CUs, SIMDs and clock from the trace's agent table)
     ms = summary["kernel_trace_timed_launches"]["avg_ms"]
-    simd_cycles = 1024 * ms * 1e-3 * 2.4e9
+    simd_cycles = CUS * SIMDS_PER_CU * ms * 1e-3 * CLK_MHZ * 1e6
     wave_cycles = 4 * pmc["SQ_WAVE_CYCLES"]
     summary["valu_issue"] = {
         "valu_wave_instructions_per_launch": pmc["SQ_INSTS_VALU"],
         "simd_issue_slots_used_frac": 4 * pmc["SQ_INSTS_VALU"] / simd_cycles,
         "wave_slot_occupancy_frac": wave_cycles / simd_cycles,
         "cycles_per_valu_instruction_of_a_wavefront": wave_cycles / pmc["SQ_INSTS_VALU"],
-        "mean_wavefront_ms": wave_cycles / pmc["SQ_WAVES"] / 2.4e9 * 1e3,
+        "mean_wavefront_ms": wave_cycles / pmc["SQ_WAVES"] / (CLK_MHZ * 1e6) * 1e3,
         "note": "one wavefront per instance: the pass lasts as long as its slowest instance, so most SIMD cycles idle"}
 if "SQ_LDS_IDX_ACTIVE" in pmc and summary.get("kernel_trace_timed_launches", {}).get("avg_ms"):
     ms = summary["kernel_trace_timed_launches"]["avg_ms"]
-    cu_cycles = 256 * ms * 1e-3 * 2.4e9
+    cu_cycles = CUS * ms * 1e-3 * CLK_MHZ * 1e6
     summary["lds"] = {
         "lds_busy_frac_of_cu_cycles": pmc["SQ_LDS_IDX_ACTIVE"] / cu_cycles,
         "bank_conflict_frac_of_lds_cycles": pmc.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(pmc["SQ_LDS_IDX_ACTIVE"], 1.0),
         "lds_instructions_per_launch": pmc.get("SQ_INSTS_LDS"),
-        "note": "SQ_LDS_IDX_ACTIVE / (256 CUs x kernel time x 2.4 GHz): averaged over the whole pass, including its "
+        "note": "SQ_LDS_IDX_ACTIVE / (CUs x kernel time x engine clock): averaged over the whole pass, including its "
                 "tail when few instances are left; while all 600 run the fraction is about pass / mean-solve-time higher"}
 json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))

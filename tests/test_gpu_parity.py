@@ -228,6 +228,35 @@ def test_config5_stress_horizon_120():
             assert st[key][b] == st_o[key], key
 
 
+def test_config5_full_launch_through_the_one_wavefront_kernel():
+    """BASELINE.json configs[4] as bench.py launches it: all 1024 instances of N=120 in ONE launch, which
+    `speculation=auto` sends to pantr_solve_kernel<ChainModel, 0> (one wavefront per instance, tape rows requested
+    two stages ahead, four instances per compute unit - the memory system under load).  All 1024 are certified;
+    32 of them, spread over the launch, equal the oracle's solve bit for bit, counters included; a second launch
+    reproduces the first."""
+    from concurrent.futures import ThreadPoolExecutor
+    from pantr_amd import workloads
+    w = workloads.stress_batch(1024)
+    N, B = 120, 1024
+    batch = pa.PantrBatch("hanging_chain", N, B, opts=w["opts"])
+    assert batch.kernel_name(B) == "pantr_solve_kernel<ChainModel, 0>"
+    u, st = batch.solve(w["x0"], w["u0"])
+    u2, st2 = batch.solve(w["x0"], w["u0"])
+    batch.close()
+    assert np.all(st["status"] == 1) and np.all(st["eps"] <= 1e-8) and np.all(np.abs(u) <= 1.0)
+    assert np.array_equal(u, u2) and np.array_equal(st["n_hess_psi_prod"], st2["n_hess_psi_prod"])
+    pick = list(range(5, B, 32))
+    assert len(pick) == 32
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+        res = list(ex.map(lambda b: ob.solve(N, w["x0"][b], w["u0"][b])[:2], pick))
+    for b, (u_o, st_o) in zip(pick, res):
+        assert np.array_equal(u[b], u_o), b
+        for key in ("status", "iterations", "cg_iterations", "accepted", "rejected", "n_hess_psi_prod", "n_hess_psi_prod_calls",
+                    "n_psi", "n_psi_grad_psi", "n_grad_L"):
+            assert st[key][b] == st_o[key], (b, key)
+        assert st["eps"][b] == st_o["eps"] and st["final_psi"][b] == st_o["final_psi"]
+
+
 def test_config4_horizon_sweep():
     """BASELINE.json configs[3] at its stated size: hanging_chain N in {10,...,60} x {cold, warm} x 60
     timed MPC steps = 720 instances (dodo.py:10,69-95).  Every device closed loop equals the
@@ -454,6 +483,8 @@ def test_kernel_name_follows_method_speculation_and_batch_size():
     assert b.kernel_name(600) == "pantr_solve_spec_kernel<ChainModel>"      # auto: small batches speculate
     assert b.kernel_name(1024) == "pantr_solve_kernel<ChainModel, 0>"       # auto: large ones do not
     lds_auto, ws = b.footprint()
+    assert b.footprint(1024) == (lds_auto, ws) and b.footprint(600)[0] > lds_auto   # the figure follows the kernel of B
+    b.forget_buffers()
     b.close()
     b = pa.PantrBatch("hanging_chain", 60, 600, opts=tuple(pa.DODO_PANTR_OPTS) + ("speculation=off",))
     assert b.kernel_name() == "pantr_solve_kernel<ChainModel, 0>"

@@ -311,3 +311,12 @@ def test_eval_wrappers_validate_shapes():
         b.simulate_dynamics(np.zeros((2, 57)), np.zeros((2, 2)))
     with pytest.raises(ValueError):
         b.eval_prox_grad_step(1.0, np.zeros((1, 9)), np.zeros((1, 57)))
+
+
+def test_explicit_vmcnt_waits_are_covered_in_the_compiled_kernel():
+    """scripts/check_vmem_counts.py: every `s_waitcnt vmcnt(n)` of the two-stages-ahead product sweeps is preceded,
+    in the compiled one-wavefront kernel, by at least n vector-memory instructions since the previous such wait
+    (what makes leaving n operations in flight safe)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_vmem_counts.py"), pa.LIB_PATH],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
