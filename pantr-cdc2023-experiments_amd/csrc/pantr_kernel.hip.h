@@ -1404,6 +1404,9 @@ __device__ __forceinline__ void solve_chain_instance(const SolveArgs &a, PB &pb,
         st.outer_iterations = 1;
         st.inner_convergence_failures = r.status == Converged ? 0 : 1;
         st.spec_timeouts = pb.spec_timeouts;
+#ifdef PANTR_PHASE_TIMING
+        st.sum_tau = (double)pb.fwd_cycles; // profiling build, method=pantr: shader cycles in the forward halves of the products
+#endif
         write_stats(a.stats + inst, st);
     }
 }

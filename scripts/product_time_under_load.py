@@ -28,7 +28,8 @@ def run(name, N, X0, U0, opts):
     other = st["elapsed_s"].sum() - st["phase_s"].sum()
     print(f"{name:44s} {b.kernel_name(len(X0)):38s} pass {ms:7.1f} ms  mean solve {st['elapsed_s'].mean()*1e3:7.1f} ms  "
           f"{t/c*1e6:6.1f} us per product  (psi_grad {st['phase_s'][:,1].sum()/max(st['n_psi_grad_psi'].sum(),1)*1e6:5.0f}, "
-          f"grad_L+tape {st['phase_s'][:,3].sum()/max(st['n_grad_L'].sum(),1)*1e6:5.0f} us)  converged {int((st['status']==1).sum())}")
+          f"grad_L+tape {st['phase_s'][:,3].sum()/max(st['n_grad_L'].sum(),1)*1e6:5.0f} us; forward halves "
+          f"{100*st['sum_tau'].sum()/2.4e9/max(t,1e-30):3.0f} % of the products' time at 2.4 GHz)  converged {int((st['status']==1).sum())}")
     b.close()
 
 
