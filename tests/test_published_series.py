@@ -82,3 +82,34 @@ def test_cold_start_costs_what_it_cost_the_reference(closed_loops, problem):
     ratio = closed_loops[(problem, False)].sum() / closed_loops[(problem, True)].sum()
     ref = published(problem, False).mean() / published(problem, True).mean()
     assert abs(ratio / ref - 1) < 0.30, (ratio, ref)
+
+
+# ---- the two comparators of row f4 (method=panoc, strucpanoc; mpc-driver.cpp:371-384) against their published series ----
+@pytest.fixture(scope="module")
+def comparator_loops():
+    out = {}
+    for method in ("panoc", "strucpanoc"):
+        for warm in (False, True):
+            stats = ob.mpc(60, 60, warm, params=ob.dodo_params(method))[3]
+            assert all(s["status"] == 1 for s in stats)
+            out[(method, warm)] = np.array([work(s) for s in stats], float)     # (no products: gradients and values)
+    return out
+
+
+@pytest.mark.parametrize("method,warm", [("panoc", False), ("panoc", True), ("strucpanoc", False), ("strucpanoc", True)])
+def test_comparators_rank_their_steps_like_the_reference(comparator_loops, method, warm):
+    """PANOC+ and structured PANOC+ (L-BFGS 50) on the hanging chain, N = 60: per-step work against the published
+    per-step time - Spearman 0.79 / 0.92 (PANOC+ cold / warm), 0.77 / 0.87 (structured)."""
+    w = comparator_loops[(method, warm)]
+    p = np.array(PUB["series"]["hanging_chain"][method]["warm" if warm else "cold"])
+    assert spearmanr(w, p)[0] >= 0.7
+
+
+@pytest.mark.parametrize("warm", [False, True])
+def test_comparators_relative_cost_is_the_published_one(comparator_loops, warm):
+    """Both comparators spend their time in the same sweeps, so their work ratio is comparable with the ratio of the
+    published mean times: 2.01 against 1.86 (cold), 1.37 against 1.35 (warm)."""
+    key = "warm" if warm else "cold"
+    ratio = comparator_loops[("panoc", warm)].sum() / comparator_loops[("strucpanoc", warm)].sum()
+    ref = np.mean(PUB["series"]["hanging_chain"]["panoc"][key]) / np.mean(PUB["series"]["hanging_chain"]["strucpanoc"][key])
+    assert abs(ratio / ref - 1) < 0.15, (ratio, ref)
