@@ -81,6 +81,7 @@ struct pantr_batch {
     int32_t penalty_alm_split = 0;
     double tick_s = 1e-8;  ///< seconds per wall_clock64() tick of this device
     int32_t eval_reps = 1; ///< development aid: repeat count of the timed op in the eval kernels
+    int32_t eval_depth = 1; ///< tests: prefetch depth of the products the chain's evaluation kernel runs (1 | 2)
 };
 
 namespace {
@@ -454,7 +455,10 @@ int run_eval(pantr_batch *b, int32_t B, int mode, double gamma, const double *x0
     a.x0 = b->d_x0; a.u = b->d_u; a.v = v ? b->d_v : nullptr;
     a.out_s = b->d_s; a.out_v = b->d_o1; a.out_v2 = b->d_o2; a.ws = b->d_ws; a.gamma = gamma;
     a.box = b->box;
-    hipLaunchKernelGGL(pantr_eval_kernel<ChainModel>, dim3(B), dim3(WAVE), eval_lds_bytes(*b), 0, a);
+    if (b->eval_depth == 2)
+        hipLaunchKernelGGL((pantr_eval_kernel<ChainModel, 2>), dim3(B), dim3(WAVE), eval_lds_bytes(*b), 0, a);
+    else
+        hipLaunchKernelGGL((pantr_eval_kernel<ChainModel, 1>), dim3(B), dim3(WAVE), eval_lds_bytes(*b), 0, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     std::vector<double> s((size_t)B * 4);
@@ -692,7 +696,9 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
                                   (const void *)&pantr_solve_kernel<ChainModel, 2>})
                 if (int rc = raise_dynamic_lds(k, b->lds_bytes))
                     return rc;
-        if (int rc = raise_dynamic_lds((const void *)&pantr_eval_kernel<ChainModel>, eval_lds_bytes(*b)))
+        if (int rc = raise_dynamic_lds((const void *)&pantr_eval_kernel<ChainModel, 2>, eval_lds_bytes(*b)))
+            return rc;
+        if (int rc = raise_dynamic_lds((const void *)&pantr_eval_kernel<ChainModel, 1>, eval_lds_bytes(*b)))
             return rc;
     }
     const size_t B  = b->maxB;
@@ -1170,6 +1176,12 @@ extern "C" int pantr_debug_read_workspace(pantr_batch_t *b, int32_t inst, int64_
     HIP_TRY(hipMemcpy(out, b->d_ws + (size_t)inst * b->ws_per_instance + offset, (size_t)count * sizeof(double),
                       hipMemcpyDeviceToHost));
     return PANTR_OK;
+}
+
+/// Tests / development: the prefetch depth (1 | 2) of the products the chain's evaluation kernel runs.
+extern "C" void pantr_debug_set_eval_prefetch_depth(pantr_batch_t *b, int depth) {
+    if (b)
+        b->eval_depth = depth == 2 ? 2 : 1;
 }
 
 extern "C" void pantr_debug_set_eval_reps(pantr_batch_t *b, int r) {

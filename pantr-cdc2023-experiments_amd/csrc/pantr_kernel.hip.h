@@ -1527,16 +1527,20 @@ struct EvalArgs {
     BoxData box;
 };
 
-template <class M>
+/// DEPTH: how far ahead the products of this kernel request their tape rows (both forms of hess_prod_tape are
+/// tested against the oracle through it).
+template <class M, int DEPTH = 1>
 __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x, inst = blockIdx.x;
     if (inst >= a.B)
         return;
     typename M::Lane L(lane);
-    __shared__ __attribute__((aligned(16))) char tape_buf0[M::LDS_STAGE_BYTES];
-    __shared__ __attribute__((aligned(16))) char tape_buf1[M::LDS_STAGE_BYTES];
-    WaveProblem<M> pb{L, a.box, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
+    using PB = WaveProblem<M, false, false, DEPTH>;
+    __shared__ __attribute__((aligned(16))) char landing[(DEPTH + 1) * PB::LANDING_BYTES];
+    PB pb{L, a.box, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, landing, landing + PB::LANDING_BYTES};
+    if constexpr (DEPTH == 2)
+        pb.tbuf2 = landing + 2 * PB::LANDING_BYTES;
     pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
     pb.xrow = lds + 4 * a.npad;

@@ -454,8 +454,11 @@ class PantrBatch:
                                                    _ptr(grad)))
         return psi, grad
 
-    def eval_hess_psi_prod(self, x0, u, v):
-        """Hv: records the second-order tape at u, then replays it for v (the solver's path)."""
+    def eval_hess_psi_prod(self, x0, u, v, prefetch_depth=None):
+        """Hv: records the second-order tape at u, then replays it for v (the solver's path).  prefetch_depth (tests,
+        hanging chain): 1 | 2 stages ahead - the two forms of the product the solve kernels use."""
+        if prefetch_depth is not None:
+            lib().pantr_debug_set_eval_prefetch_depth(self._h, int(prefetch_depth))
         B, x0, u, v = self._rows(x0, u, v)
         Hv = np.zeros((B, self.n))
         _check(lib().pantr_batch_eval_hess_psi_prod(self._h, B, _ptr(x0), _ptr(u), _ptr(v), _ptr(Hv)))

@@ -12,6 +12,9 @@ x0, u = x0[:B], u[:B]
 v = np.random.default_rng(0).standard_normal(u.shape)
 L = pa.lib()
 b = pa.PantrBatch("hanging_chain", 60, B)
+depth = int(os.environ.get("PREFETCH_DEPTH", "1"))  # 1 | 2: which form of the product the evaluation kernel runs
+L.pantr_debug_set_eval_prefetch_depth(b._h, depth)
+print(f"tape rows requested {depth} stage(s) ahead")
 res = {}
 for reps in (1, 101):
     L.pantr_debug_set_eval_reps(b._h, reps)

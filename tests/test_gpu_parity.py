@@ -35,7 +35,11 @@ def test_psi_grad_hess_prod_match_oracle(rng, N):
     x0, u, v = random_states(rng, B), random_inputs(rng, B, N), rng.standard_normal((B, NU * N))
     psi = with_batch.eval_psi(x0, u)
     psi2, grad = with_batch.eval_psi_grad_psi(x0, u)
-    Hv = with_batch.eval_hess_psi_prod(x0, u, v)  # tape record + replay, the solver's path
+    Hv = with_batch.eval_hess_psi_prod(x0, u, v, prefetch_depth=1)  # tape record + replay, the solver's path
+    # ... and with the tape rows requested two stages ahead (explicit vmcnt waits, three landing buffers, the
+    # tangent-state row by LDS-DMA: what the one-wavefront solve kernel runs) - the same bits
+    Hv2 = with_batch.eval_hess_psi_prod(x0, u, v, prefetch_depth=2)
+    assert np.array_equal(Hv2, Hv)
     for b in range(B):
         f_o, g_o = ob.psi_grad(N, x0[b], u[b])
         Hv_o = ob.hess_prod(N, x0[b], u[b], v[b])
