@@ -507,11 +507,11 @@ const char *pantr_last_error(void) { return g_last_error.c_str(); }
 const char *pantr_version(void) {
     // any build switch that changes what the library computes or reports is named here
 #if defined(PANTR_PHASE_TIMING) && defined(PANTR_REST_TIMING)
-    return "pantr-mi355x 0.2 (gfx950) +phase-timing +rest-timing";
+    return "pantr-mi355x 0.4 (gfx950) +phase-timing +rest-timing";
 #elif defined(PANTR_PHASE_TIMING)
-    return "pantr-mi355x 0.2 (gfx950) +phase-timing";
+    return "pantr-mi355x 0.4 (gfx950) +phase-timing";
 #else
-    return "pantr-mi355x 0.2 (gfx950)";
+    return "pantr-mi355x 0.4 (gfx950)";
 #endif
 }
 const char *pantr_source_hash(void) {
