@@ -15,7 +15,7 @@ OUT=gpurun_out/$TAG
 P=$PWD/pantr-cdc2023-experiments_amd
 mkdir -p $OUT
 timeout -k 10 900 python -m pytest tests -q -m gpu > $OUT/gpu_tests.log 2>&1; tail -2 $OUT/gpu_tests.log
-timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.json; echo
+( time timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench_time.txt; tail -c 300 $OUT/bench.json; echo; cat $OUT/bench_time.txt
 timeout -k 10 400 bash scripts/profile.sh > $OUT/profile.log 2>&1
 timeout -k 10 600 bash scripts/traffic_profile.sh stress tile8 > $OUT/traffic_profile.txt 2>&1; cat $OUT/traffic_profile.txt
 rm -rf gpurun_out/prof_rows
