@@ -106,9 +106,10 @@ constexpr int NUM_ITER_VEC = 12; ///< three iterates x {x, xhat, grad, p}
 /// r_J, z, r, d, step; the decision vector a sweep reads stage by stage is staged in z's slot, which
 /// is dead outside the CG loop); the three iterates live in HBM/L2 (WaveProblem<M, true>): they are
 /// touched by element-wise passes only, every lane reading and writing its own elements as coalesced
-/// 512-byte rows.  7 slots x 192 doubles + the 10 KiB landing buffers = 20.5 KiB at N = 60 (seven
-/// instances per CU) and 31 KiB at N = 120 (five per CU); with everything in LDS it was 40 KiB and
-/// 70 KiB.
+/// 512-byte rows.  7 slots x 192 doubles + the landing buffers of the products (10 KiB one stage ahead,
+/// 15.75 KiB two stages ahead: the one-wavefront kernel) = 20.5 / 26.5 KiB at N = 60 (six instances of the
+/// one-wavefront kernel per CU) and 31 / 37 KiB at N = 120 (four per CU); with everything in LDS it was 40 KiB
+/// and 70 KiB.
 constexpr int NUM_CG_VEC = 7;
 /// The in/out vector of an inner solve shares the slot of the direction's scratch vector (PANTR:
 /// the CG step; PANOC: unused): it is read before the first and written after the last use of
@@ -244,7 +245,7 @@ struct WaveProblem {
         return s;
     }
 
-    /// Static LDS of a kernel using this problem: the two landing buffers.
+    /// Static LDS of a kernel using this problem: the DEPTH + 1 landing buffers.
     /// bytes of one landing buffer (DEPTH == 2: with the tangent-state row behind the tangent tape)
     static constexpr int LANDING_BYTES = DEPTH == 2 ? M::LDS_STAGE_BYTES_XT : M::LDS_STAGE_BYTES;
     __host__ __device__ static size_t tape_lds_bytes() { return (size_t)(DEPTH + 1) * LANDING_BYTES; }
@@ -519,12 +520,10 @@ struct WaveProblem {
         }
     }
 
-    /// Hv = d/du (grad psi(u)^T v) at the point the tape was recorded at (psi_grad<true>):
-    /// tangent forward sweep F_t = K d_t, second-order adjoint sweep ld_t = K lF_t + M d_t.
-    /// Stage k+-1's rows stream from HBM into LDS (LDS-DMA) while stage k computes.  The two
-    /// landing buffers are distinct __shared__ objects and the stage loops are unrolled by two,
-    /// so every LDS read names a buffer no DMA is writing (otherwise the compiler drains the
-    /// in-flight DMA with vmcnt(0) before each read and the prefetch hides nothing).
+    // ---- Hessian-vector products: hess_prod_tape(v, Hv) = d/du (grad psi(u)^T v) at the point the tape was
+    // recorded at (psi_grad<true>): tangent forward sweep F_t = K d_t, second-order adjoint sweep ld_t = K lF_t +
+    // M d_t, the stages' tape rows streaming from HBM into LDS by LDS-DMA one (DEPTH == 1) or two (DEPTH == 2)
+    // stages ahead of the stage that computes.  Same arithmetic, same bits. ----
     // ---- DEPTH == 2 -------------------------------------------------------------------------------
     // Two stages ahead.  A wavefront of the one-stage-ahead form keeps 2-5 KiB of tape rows in flight; with a
     // thousand such wavefronts on the chip the memory system runs at bytes-in-flight / latency, far below what
@@ -649,6 +648,9 @@ struct WaveProblem {
             M::template prefetch_fwd<true>(L, tape + (size_t)M::TAPE_D4_PER_STAGE, tbuf1);
     }
     // ---- DEPTH == 1 -------------------------------------------------------------------------------
+    // One stage ahead: a full wait at every stage start.  The two landing buffers are distinct __shared__ objects
+    // and the stage loops are unrolled by two, so every LDS read names a buffer no transfer is writing (otherwise
+    // the compiler drains the transfers in flight with vmcnt(0) before each read and the prefetch hides nothing).
     __device__ __forceinline__ void hess_prod_tape_d1(const double *v, double *Hv) const {
         wave_sync();
 #ifdef PANTR_PHASE_TIMING
