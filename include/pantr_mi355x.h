@@ -91,7 +91,12 @@ typedef struct pantr_problem_data pantr_problem_data_t; /* numeric data read fro
  * prefix or an unparsable value is PANTR_ERR_INVALID_ARGUMENT.  Durations accept "30s",
  * "500ms", "2min"; enums their alpaqa names ("ProjGradUnitNorm").
  * pantr_params_create applies the reference driver's defaults (mpc-driver.cpp:51-53,
- * 109-111) on top of alpaqa's. */
+ * 109-111) on top of alpaqa's.
+ * Options of this implementation, spelled like "method=" (no prefix; the reference has no counterpart, results
+ * are the same whatever their value): "speculation=auto|on|off" (method=pantr: a second wavefront per instance
+ * evaluates ahead; auto = on for batches that leave the SIMDs idle), "spec_patience=<duration>" (how long a solver
+ * wavefront waits for that helper before it goes on alone, default 1s; pantr_stats_t::spec_timeouts),
+ * "residency=auto|<k>" (at most k workgroups per compute unit: a measurement aid). */
 int pantr_params_create(pantr_params_t **out);
 void pantr_params_destroy(pantr_params_t *p);
 int pantr_params_set(pantr_params_t *p, const char *kv);
