@@ -54,3 +54,31 @@ def test_bench_launches_its_own_ranks(mode):
     else:
         assert line["scaling"] == "weak" and line["config"]["converged"] == 600
         assert line["config"]["max_abs_dev_from_recorded_closed_loop"] == 0.0
+
+
+def test_bench_line_contract():
+    """The one JSON line of `bench.py` at N = 1 (--headline-only: seconds): the keys and types the driver reads, the
+    roofline object for the dominant kernel - live HIP-event timing, algorithmic bytes from the instances' own
+    counters against the 8 TB/s peak - and a traffic figure only together with the source hash it was measured at."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--headline-only"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"] == "MPC-steps solved/sec, hanging_chain N=60 cold+warm, 1/2/4/8 MI355X" and d["unit"] == "steps/s"
+    assert (d["n_gpus"], d["steps"], d["warmup"]) == (1, 3, 1) and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert abs(d["value"] - 600 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "workload" in d["config"] and d["config"]["instances_per_gpu"] == 600 and d["config"]["converged"] == 600
+    assert d["config"]["max_abs_dev_from_recorded_closed_loop"] == 0.0          # measured, not a literal
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.01 < rf["frac"] < 1.0
+    assert rf["kernel"] == "pantr_solve_spec_kernel<ChainModel>" and 0 < rf["kernel_ms"] <= d["ms_per_step"] * 1.01
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    src = rf["traffic_source"]
+    assert (rf["traffic"] is None) == ("refused" in src)                        # a figure only with its provenance
+    if rf["traffic"] is not None:
+        assert src["profiled_csrc_sha256"] == src["csrc_sha256"] and rf["traffic"] > rf["algorithmic_bytes_per_launch"]

@@ -320,3 +320,18 @@ def test_explicit_vmcnt_waits_are_covered_in_the_compiled_kernel():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_vmem_counts.py"), pa.LIB_PATH],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_bench_started_bare_launches_ranks_and_reports_their_failure():
+    """`python bench.py --gpus 2` without WORLD_SIZE becomes the launcher (before any HIP call): it starts two rank
+    processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and leaves with a failure when they fail - which
+    they do here, loudly, because there is no GPU (the product has no CPU path)."""
+    if pa.device_count() > 0:
+        pytest.skip("a HIP device is present (tests/test_gpu_multirank.py runs the real thing)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    t = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and time.time() - t < 120
+    assert r.stderr.count("bench.py needs an MI355X") == 2          # both ranks were started, both said why they left
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # and no result line was made up
