@@ -51,13 +51,21 @@ struct AlmSolveArgs {
 };
 
 /// Wave-cooperative single-shooting problem with an augmented-Lagrangian term, scalar model M.
-template <class M, bool SPEC = false>
+/// NJ_: 0, or the number of elements of an n-vector every lane owns (nj, known at compile time: the element-wise
+/// passes of the solver are then straight-line code, Owned<NJ> in pantr_kernel.hip.h).
+template <class M, bool SPEC = false, int NJ_ = 0>
 struct ScalarALProblem {
     static constexpr int nx = M::nx, nu = M::nu, nc = M::nc;
     static constexpr bool HAS_SPEC = SPEC; ///< a helper wavefront evaluates ahead (pantr_alm_spec_kernel; SpecBox)
+    static constexpr int NJ = NJ_;
     int lane;
     const BoxData *box; ///< bounds of u (box C) and of the constraints (box D), kernel argument
-    double *lds; ///< n-vectors: NUM_VEC slots of npad doubles
+    double *lds; ///< n-vectors: NUM_VEC slots of npad doubles, then the two of the bounds
+    /// LDS n-vectors: box C tiled over the horizon (element i: the bounds of input i mod nu), padding 0 - so that a
+    /// pass reads its bounds like any other operand (a select among the kernel arguments on i mod nu compiles to
+    /// nested exec-mask branches: 1.5 us per pass), and a padding element's prox step is exactly 0.
+    double *lbv, *ubv;
+    static constexpr int BOX_VECS = 2;
     int N, n, npad, nj, m, mpad, mj;
     const double *x0; ///< LDS: the initial state (problem parameter) of this instance, nx doubles
     double *mv;  ///< m-vectors: y, Sigma, e1, e2, yh0, yh1, yh2, y/Sigma, mpad doubles each
@@ -104,7 +112,7 @@ struct ScalarALProblem {
     static constexpr int COEF = 20;
     __host__ __device__ static size_t coef_doubles(int N) { return M::angles_are_integrated_inputs ? 0 : (size_t)COEF * N; }
     __host__ __device__ static size_t lds_doubles(int N, int npad, int mpad, bool dedicated_scratch = false) {
-        return (size_t)NUM_VEC * npad + (size_t)MV_COUNT * mpad + (size_t)2 * (N + 1) * nx +
+        return (size_t)(NUM_VEC + BOX_VECS) * npad + (size_t)MV_COUNT * mpad + (size_t)2 * (N + 1) * nx +
                (size_t)(N + 1) * M::TRIG_DOUBLES_PER_STAGE + X0_DOUBLES + coef_doubles(N) +
                (dedicated_scratch ? scratch_doubles(N) : 0);
     }
@@ -1178,8 +1186,12 @@ struct ScalarALProblem {
     /// grad <- the helper's gradient, tape <- the buffer it recorded into (yhat is in the iterate's slot already).
     __device__ __forceinline__ void spec_adopt(double *grad) {
         wave_sync();
-        for (int i = lane; i < n; i += WAVE)
-            grad[i] = hG[i];
+        if constexpr (NJ > 0) {
+            Owned<NJ>::load(hG, lane).store(grad, lane);
+        } else {
+            for (int i = lane; i < n; i += WAVE)
+                grad[i] = hG[i];
+        }
         tape_cur = 1 - tape_cur;
         tape     = tape0 + (size_t)tape_cur * workspace_doubles(N);
         wave_sync();
@@ -1263,21 +1275,44 @@ struct ScalarALProblem {
     }
 
     // ---- vector helpers over the LDS n-vectors (same reduction order as the chain problem) -------
+    /// The bounds of u as n-vectors (lbv, ubv); once per instance, after the LDS was cleared.
+    __device__ __forceinline__ void fill_bounds() const {
+        for (int i = lane; i < n; i += WAVE) {
+            lbv[i] = box_pick(box->u_lb, i % nu);
+            ubv[i] = box_pick(box->u_ub, i % nu);
+        }
+        wave_sync();
+    }
+    using OV = Owned<(NJ > 0 ? NJ : 1)>;
     __device__ __forceinline__ double dot(const double *a, const double *b) const {
         double acc = 0.0;
-        for (int j = 0; j < nj; ++j) {
-            int i = j * WAVE + lane;
-            if (i < n)
-                acc = acc + a[i] * b[i];
+        if constexpr (NJ > 0) {
+            const OV av = OV::load(a, lane), bv = OV::load(b, lane);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc = acc + av[j] * bv[j];
+        } else {
+            for (int j = 0; j < nj; ++j) {
+                int i = j * WAVE + lane;
+                if (i < n)
+                    acc = acc + a[i] * b[i];
+            }
         }
         return uniform(wave_sum(acc));
     }
     __device__ __forceinline__ double dot_masked(const double *a, const double *b, uint32_t mask) const {
         double acc = 0.0;
-        for (int j = 0; j < nj; ++j) {
-            int i = j * WAVE + lane;
-            if (i < n)
-                acc = acc + a[i] * ((mask >> j) & 1u ? b[i] : 0.0);
+        if constexpr (NJ > 0) {
+            const OV av = OV::load(a, lane), bv = OV::load(b, lane);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc = acc + av[j] * ((mask >> j) & 1u ? bv[j] : 0.0);
+        } else {
+            for (int j = 0; j < nj; ++j) {
+                int i = j * WAVE + lane;
+                if (i < n)
+                    acc = acc + a[i] * ((mask >> j) & 1u ? b[i] : 0.0);
+            }
         }
         return uniform(wave_sum(acc));
     }
@@ -1293,32 +1328,60 @@ struct ScalarALProblem {
     __device__ __forceinline__ void prox_grad_step(double gamma, const double *x, const double *grad,
                                                    double *xh, double *p, double &pTp, double &gradTp) const {
         double a1 = 0.0, a2 = 0.0;
-        for (int j = 0; j < nj; ++j) {
-            int i = j * WAVE + lane;
-            if (i < n) {
-                int c     = i % nu;
-                double xi = x[i], gi = grad[i];
-                double t  = (-gamma) * gi;
-                double pi = fmin(fmax(t, box_pick(box->u_lb, c) - xi), box_pick(box->u_ub, c) - xi);
-                p[i]      = pi;
-                xh[i]     = xi + pi;
-                a1        = a1 + pi * pi;
-                a2        = a2 + pi * gi;
+        if constexpr (NJ > 0) {
+            const OV xv = OV::load(x, lane), gv = OV::load(grad, lane), lo = OV::load(lbv, lane),
+                     hi = OV::load(ubv, lane);
+            OV pv, xhv;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { // (padding: x = grad = lb = ub = 0, so p = 0 and xhat = 0)
+                double t = (-gamma) * gv[j];
+                pv[j]    = fmin(fmax(t, lo[j] - xv[j]), hi[j] - xv[j]);
+                xhv[j]   = xv[j] + pv[j];
+                a1       = a1 + pv[j] * pv[j];
+                a2       = a2 + pv[j] * gv[j];
             }
+            pv.store(p, lane);
+            xhv.store(xh, lane);
+            wave_sum2(a1, a2);
+            pTp    = uniform(a1);
+            gradTp = uniform(a2);
+        } else {
+            for (int j = 0; j < nj; ++j) {
+                int i = j * WAVE + lane;
+                if (i < n) {
+                    double xi = x[i], gi = grad[i];
+                    double t  = (-gamma) * gi;
+                    double pi = fmin(fmax(t, lbv[i] - xi), ubv[i] - xi);
+                    p[i]      = pi;
+                    xh[i]     = xi + pi;
+                    a1        = a1 + pi * pi;
+                    a2        = a2 + pi * gi;
+                }
+            }
+            pTp    = uniform(wave_sum(a1));
+            gradTp = uniform(wave_sum(a2));
         }
-        pTp    = uniform(wave_sum(a1));
-        gradTp = uniform(wave_sum(a2));
     }
     __device__ __forceinline__ double proj_grad_unit_norm(const double *x, const double *grad) const {
         double r = 0.0;
-        for (int j = 0; j < nj; ++j) {
-            int i = j * WAVE + lane;
-            if (i < n) {
-                int c     = i % nu;
-                double xi = x[i];
-                double t  = (-1.0) * grad[i];
-                double pi = fmin(fmax(t, box_pick(box->u_lb, c) - xi), box_pick(box->u_ub, c) - xi);
+        if constexpr (NJ > 0) {
+            const OV xv = OV::load(x, lane), gv = OV::load(grad, lane), lo = OV::load(lbv, lane),
+                     hi = OV::load(ubv, lane);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                double t  = (-1.0) * gv[j];
+                double pi = fmin(fmax(t, lo[j] - xv[j]), hi[j] - xv[j]);
                 r         = fmax(r, fabs(pi));
+            }
+        } else {
+            for (int j = 0; j < nj; ++j) {
+                int i = j * WAVE + lane;
+                if (i < n) {
+                    double xi = x[i];
+                    double t  = (-1.0) * grad[i];
+                    double pi = fmin(fmax(t, lbv[i] - xi), ubv[i] - xi);
+                    r         = fmax(r, fabs(pi));
+                }
             }
         }
         return uniform(wave_max(r));
@@ -1327,16 +1390,27 @@ struct ScalarALProblem {
                                                       int &nJ) const {
         uint32_t mask = 0;
         int cnt       = 0;
-        for (int j = 0; j < nj; ++j) {
-            int i   = j * WAVE + lane;
-            bool in = false;
-            if (i < n) {
-                int c      = i % nu;
-                double xfw = x[i] - gamma * grad[i];
-                in = box_pick(box->u_lb, c) < xfw && xfw < box_pick(box->u_ub, c);
+        if constexpr (NJ > 0) {
+            const OV xv = OV::load(x, lane), gv = OV::load(grad, lane), lo = OV::load(lbv, lane),
+                     hi = OV::load(ubv, lane);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { // (padding: 0 < 0 is false)
+                double xfw = xv[j] - gamma * gv[j];
+                bool in    = lo[j] < xfw && xfw < hi[j];
+                mask |= (in ? 1u : 0u) << j;
+                cnt += __builtin_popcountll(__ballot(in ? 1 : 0));
             }
-            mask |= (in ? 1u : 0u) << j;
-            cnt += __builtin_popcountll(__ballot(in ? 1 : 0)); // wave-uniform count, no reduction needed
+        } else {
+            for (int j = 0; j < nj; ++j) {
+                int i   = j * WAVE + lane;
+                bool in = false;
+                if (i < n) {
+                    double xfw = x[i] - gamma * grad[i];
+                    in = lbv[i] < xfw && xfw < ubv[i];
+                }
+                mask |= (in ? 1u : 0u) << j;
+                cnt += __builtin_popcountll(__ballot(in ? 1 : 0)); // wave-uniform count, no reduction needed
+            }
         }
         nJ = cnt;
         return mask;
@@ -1352,6 +1426,7 @@ __device__ __forceinline__ void alm_solve_instance(const AlmSolveArgs &a, PB &pb
     const int n = a.n, m = a.m;
     if (lane < M::nx) // the problem parameter of this instance (pb.x0 reads it)
         x0_lds[lane] = a.x0[(size_t)inst * M::nx + lane];
+    pb.fill_bounds();
     double *x_io = pb.vec(S_XIO), *y = pb.mvec(PB::MV_Y), *Sig = pb.mvec(PB::MV_SIG), *e1 = pb.mvec(PB::MV_E1),
            *e2 = pb.mvec(PB::MV_E2);
     for (int i = lane; i < n; i += WAVE)
@@ -1459,7 +1534,9 @@ template <class M, int METHOD, class PB>
 __device__ __forceinline__ double *alm_bind(PB &pb, const AlmSolveArgs &a, double *lds, int lane, int inst) {
     pb.lane = lane; pb.box = &a.prm.box; pb.lds = lds; pb.N = a.N; pb.n = a.n; pb.npad = a.npad; pb.nj = a.nj;
     pb.m = a.m; pb.mpad = a.mpad; pb.mj = a.mj;
-    pb.mv = lds + (size_t)NUM_VEC * a.npad;
+    pb.lbv = lds + (size_t)NUM_VEC * a.npad;
+    pb.ubv = pb.lbv + a.npad;
+    pb.mv = lds + (size_t)(NUM_VEC + PB::BOX_VECS) * a.npad;
     pb.X  = pb.mv + (size_t)PB::MV_COUNT * a.mpad;
     pb.Xt = pb.X + (size_t)(a.N + 1) * M::nx;
     pb.TG = reinterpret_cast<double2 *>(pb.Xt + (size_t)(a.N + 1) * M::nx);
@@ -1473,7 +1550,7 @@ __device__ __forceinline__ double *alm_bind(PB &pb, const AlmSolveArgs &a, doubl
 }
 
 /// ALM outer loop (m > 0) around the inner solver METHOD names, one wavefront per instance.
-template <class M, int METHOD>
+template <class M, int METHOD, int NJ = 0>
 __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
@@ -1481,7 +1558,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
     if (inst >= a.B)
         return;
     const long long t_start = wall_clock64();
-    using PB = ScalarALProblem<M>;
+    using PB = ScalarALProblem<M, false, NJ>;
     PB pb;
     double *x0_lds = alm_bind<M, METHOD>(pb, a, lds, lane, inst);
     pb.tape = a.ws + (size_t)inst * PB::workspace_doubles(a.N);
@@ -1495,7 +1572,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
 /// method = pantr with a helper wavefront per instance (ScalarALProblem: speculation).  Wavefront 0 is
 /// the solver of pantr_alm_kernel<M, 0>; wavefront 1 serves its requests on LDS of its own behind the
 /// solver's (helper_lds_doubles) and on the instance's second tape buffer.
-template <class M>
+template <class M, int NJ = 0>
 __global__ __launch_bounds__(2 * WAVE) void pantr_alm_spec_kernel(AlmSolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
@@ -1504,7 +1581,7 @@ __global__ __launch_bounds__(2 * WAVE) void pantr_alm_spec_kernel(AlmSolveArgs a
         return;
     const long long t_start = wall_clock64();
     __shared__ SpecBox box;
-    using PB = ScalarALProblem<M, true>;
+    using PB = ScalarALProblem<M, true, NJ>;
     PB pb;
     double *x0_lds = alm_bind<M, 0>(pb, a, lds, lane, inst);
     const size_t solver_doubles = PB::lds_doubles(a.N, a.npad, a.mpad, false);
@@ -1575,7 +1652,9 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
     PB pb;
     pb.lane = lane; pb.box = &a.box; pb.lds = lds; pb.N = a.N; pb.n = a.n; pb.npad = a.npad; pb.nj = a.nj;
     pb.m = a.m; pb.mpad = a.mpad; pb.mj = a.mj;
-    pb.mv = lds + (size_t)NUM_VEC * a.npad;
+    pb.lbv = lds + (size_t)NUM_VEC * a.npad;
+    pb.ubv = pb.lbv + a.npad;
+    pb.mv = lds + (size_t)(NUM_VEC + PB::BOX_VECS) * a.npad;
     pb.X  = pb.mv + (size_t)PB::MV_COUNT * a.mpad;
     pb.Xt = pb.X + (size_t)(a.N + 1) * M::nx;
     pb.TG = reinterpret_cast<double2 *>(pb.Xt + (size_t)(a.N + 1) * M::nx);
@@ -1592,6 +1671,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
         pb.coef = x0_lds + PB::X0_DOUBLES;
         pb.scr  = pb.vec(PB::CG_BASE + 3); // five vector slots this kernel does not use
     }
+    pb.fill_bounds();
     double *u = pb.vec(0), *v = pb.vec(1), *o = pb.vec(2);
     for (int i = lane; i < a.n; i += WAVE) {
         u[i] = a.u[(size_t)inst * a.n + i];

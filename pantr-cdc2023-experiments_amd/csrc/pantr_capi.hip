@@ -27,6 +27,9 @@ static_assert(sizeof(pantr_stats_t) == sizeof(DeviceStats), "stats layout mismat
 
 namespace {
 
+/// Elements of an n-vector per lane that the quadcopter family's PANTR kernels know at compile time (n <= 256).
+constexpr int ALM_NJ = 4;
+
 thread_local std::string g_last_error;
 
 int fail(int code, const std::string &msg) {
@@ -355,10 +358,18 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
         HIP_TRY(hipEventRecord(b->ev_start, stream));
         with_quad_model(b, [&](auto model) {
             using M = decltype(model);
-            if (method == 0 && use_alm_speculation(b, B))
-                hipLaunchKernelGGL(pantr_alm_spec_kernel<M>, dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
-            else if (method == 0)
-                hipLaunchKernelGGL((pantr_alm_kernel<M, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+            const bool fixed_nj = b->nj == ALM_NJ;
+            if (method == 0 && use_alm_speculation(b, B)) {
+                if (fixed_nj)
+                    hipLaunchKernelGGL((pantr_alm_spec_kernel<M, ALM_NJ>), dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
+                else
+                    hipLaunchKernelGGL((pantr_alm_spec_kernel<M, 0>), dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
+            } else if (method == 0) {
+                if (fixed_nj)
+                    hipLaunchKernelGGL((pantr_alm_kernel<M, 0, ALM_NJ>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+                else
+                    hipLaunchKernelGGL((pantr_alm_kernel<M, 0, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+            }
             else if (method == 1)
                 hipLaunchKernelGGL((pantr_alm_kernel<M, 1>), dim3(B), dim3(WAVE), b->lds_bytes_cmp, stream, a);
             else
@@ -506,7 +517,11 @@ extern "C" {
 const char *pantr_last_error(void) { return g_last_error.c_str(); }
 const char *pantr_version(void) {
     // any build switch that changes what the library computes or reports is named here
-#if defined(PANTR_PHASE_TIMING) && defined(PANTR_REST_TIMING)
+#define PANTR_STR2(x) #x
+#define PANTR_STR(x) PANTR_STR2(x)
+#if defined(PANTR_PHASE_TIMING) && defined(PANTR_REST_TIMING) && defined(PANTR_REST_SPLIT)
+    return "pantr-mi355x 0.4 (gfx950) +phase-timing +rest-timing +rest-split=" PANTR_STR(PANTR_REST_SPLIT);
+#elif defined(PANTR_PHASE_TIMING) && defined(PANTR_REST_TIMING)
     return "pantr-mi355x 0.4 (gfx950) +phase-timing +rest-timing";
 #elif defined(PANTR_PHASE_TIMING)
     return "pantr-mi355x 0.4 (gfx950) +phase-timing";
@@ -637,6 +652,10 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
         model_defaults(id, sh, b->box, b->x_init, b->u_guess);
     }
     b->nj   = (b->n + WAVE - 1) / WAVE;
+    // the quadcopter family up to n = 256: every lane owns ALM_NJ elements of every vector (padding included), a
+    // compile-time constant of the PANTR kernels - their element-wise passes are straight-line code (Owned<NJ>)
+    if (id != ProblemId::HangingChain && b->nj <= ALM_NJ)
+        b->nj = ALM_NJ;
     b->npad = b->nj * WAVE;
     b->mj   = (b->m + WAVE - 1) / WAVE;
     b->mpad = b->mj * WAVE;
@@ -667,15 +686,19 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
     if ((b->al() ? b->lds_bytes : b->lds_bytes_pantr) + static_lds > 160 * 1024)
         return fail(PANTR_ERR_OUT_OF_RANGE, "decision vectors do not fit the 160 KiB LDS");
     if (b->al()) {
-        for (const void *k : {(const void *)&pantr_alm_kernel<QuadModelT<false>, 0>,
-                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 0>,
+        for (const void *k : {(const void *)&pantr_alm_kernel<QuadModelT<false>, 0, 0>,
+                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 0, 0>,
+                              (const void *)&pantr_alm_kernel<QuadModelT<false>, 0, ALM_NJ>,
+                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 0, ALM_NJ>,
                               (const void *)&pantr_alm_eval_kernel<QuadModelT<false>>,
                               (const void *)&pantr_alm_eval_kernel<QuadModelT<true>>})
             if (int rc = raise_dynamic_lds(k, b->lds_bytes))
                 return rc;
         if (alm_spec_lds_bytes(*b) + sizeof(SpecBox) <= 160 * 1024)
-            for (const void *k : {(const void *)&pantr_alm_spec_kernel<QuadModelT<false>>,
-                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<true>>})
+            for (const void *k : {(const void *)&pantr_alm_spec_kernel<QuadModelT<false>, 0>,
+                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<true>, 0>,
+                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<false>, ALM_NJ>,
+                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<true>, ALM_NJ>})
                 if (int rc = raise_dynamic_lds(k, alm_spec_lds_bytes(*b)))
                     return rc;
         if (b->lds_bytes_cmp <= 160 * 1024) // else the comparators are refused at launch
@@ -972,11 +995,16 @@ const char *pantr_batch_kernel_name(const pantr_batch_t *b, int32_t B) {
     const int method = static_cast<int>(b->opts.method);
     if (b->al()) {
         const bool realistic = b->problem == ProblemId::RealisticQuadcopter;
+        // (the last template argument: the compile-time elements per lane, ALM_NJ, or 0 = generic passes)
         static const char *names[2][3] = {
-            {"pantr_alm_kernel<QuadModelT<false>, 0>", "pantr_alm_kernel<QuadModelT<false>, 1>", "pantr_alm_kernel<QuadModelT<false>, 2>"},
-            {"pantr_alm_kernel<QuadModelT<true>, 0>", "pantr_alm_kernel<QuadModelT<true>, 1>", "pantr_alm_kernel<QuadModelT<true>, 2>"}};
+            {"pantr_alm_kernel<QuadModelT<false>, 0, 0>", "pantr_alm_kernel<QuadModelT<false>, 1, 0>", "pantr_alm_kernel<QuadModelT<false>, 2, 0>"},
+            {"pantr_alm_kernel<QuadModelT<true>, 0, 0>", "pantr_alm_kernel<QuadModelT<true>, 1, 0>", "pantr_alm_kernel<QuadModelT<true>, 2, 0>"}};
+        const bool fixed_nj = b->nj == ALM_NJ;
         if (use_alm_speculation(b, B))
-            return realistic ? "pantr_alm_spec_kernel<QuadModelT<true>>" : "pantr_alm_spec_kernel<QuadModelT<false>>";
+            return realistic ? (fixed_nj ? "pantr_alm_spec_kernel<QuadModelT<true>, 4>" : "pantr_alm_spec_kernel<QuadModelT<true>, 0>")
+                             : (fixed_nj ? "pantr_alm_spec_kernel<QuadModelT<false>, 4>" : "pantr_alm_spec_kernel<QuadModelT<false>, 0>");
+        if (method == 0 && fixed_nj)
+            return realistic ? "pantr_alm_kernel<QuadModelT<true>, 0, 4>" : "pantr_alm_kernel<QuadModelT<false>, 0, 4>";
         return names[realistic ? 1 : 0][method];
     }
     if (method == 0)

@@ -285,6 +285,7 @@ struct WaveProblem {
 
     // ---- speculation: the main wavefront's side (no-ops without a mailbox) ---------------------
     static constexpr bool HAS_SPEC = SPEC; ///< only the two-wavefront kernel instantiates the hooks
+    static constexpr int NJ = 0;           ///< elements per lane known at compile time (Owned<NJ>): not here
     static_assert(!SPEC || ITER_GLOBAL, "speculation needs the iterates in HBM");
     /// Post "evaluate psi, the bound test and grad_L + tape at ivec(xh_slot)"; the helper starts at once.
     __device__ __forceinline__ void spec_request(int xh_slot, double psi_x, double gradTp, double pTp, double Lip,
@@ -810,6 +811,89 @@ struct WaveProblem {
     }
 };
 
+// ---------------------------------------------------------------------------------------
+// Element-wise passes with a compile-time number of elements per lane (PB::NJ > 0)
+// ---------------------------------------------------------------------------------------
+// A lone wavefront pays for every instruction and for every dependent LDS round trip.  The generic passes
+// (`for (j < nj) { i = 64 j + lane; if (i < n) ... }`) run one trip per element under an exec mask; with NJ
+// known at compile time and the padding of every vector kept at zero a pass is straight-line code: all of a
+// lane's elements are loaded first (one wait), the arithmetic of the NJ elements interleaves, the stores
+// follow.  Element by element and sum by sum the operations - and their order - are those of the generic
+// passes: a padding element contributes +0 to a sum (or is masked out), which changes no bit.
+template <int NJ>
+struct Owned {
+    double v[NJ];
+    __device__ __forceinline__ static Owned load(const double *a, int lane) {
+        Owned r;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            r.v[j] = a[j * WAVE + lane];
+        return r;
+    }
+    __device__ __forceinline__ void store(double *a, int lane) const {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            a[j * WAVE + lane] = v[j];
+    }
+    __device__ __forceinline__ double &operator[](int j) { return v[j]; }
+    __device__ __forceinline__ const double &operator[](int j) const { return v[j]; }
+};
+/// Two / three wave_sum()s level by level side by side (the same sums: each chain is wave_sum's).
+__device__ __forceinline__ void wave_sum2(double &x, double &y) {
+    double a, b, c, d;
+    row_partner<true>(x, a, b);
+    row_partner<true>(y, c, d);
+    x = a + b;
+    y = c + d;
+    row_partner<false>(x, a, b);
+    row_partner<false>(y, c, d);
+    x = a + b;
+    y = c + d;
+    double px = dpp_partner<0x128>(x), py = dpp_partner<0x128>(y);
+    x = x + px;
+    y = y + py;
+    px = xor4_partner(x), py = xor4_partner(y);
+    x = x + px;
+    y = y + py;
+    px = dpp_partner<0x4E>(x), py = dpp_partner<0x4E>(y);
+    x = x + px;
+    y = y + py;
+    px = dpp_partner<0xB1>(x), py = dpp_partner<0xB1>(y);
+    x = x + px;
+    y = y + py;
+}
+__device__ __forceinline__ void wave_sum3(double &x, double &y, double &z) {
+    double a, b, c, d, e, f;
+    row_partner<true>(x, a, b);
+    row_partner<true>(y, c, d);
+    row_partner<true>(z, e, f);
+    x = a + b;
+    y = c + d;
+    z = e + f;
+    row_partner<false>(x, a, b);
+    row_partner<false>(y, c, d);
+    row_partner<false>(z, e, f);
+    x = a + b;
+    y = c + d;
+    z = e + f;
+    double px = dpp_partner<0x128>(x), py = dpp_partner<0x128>(y), pz = dpp_partner<0x128>(z);
+    x = x + px;
+    y = y + py;
+    z = z + pz;
+    px = xor4_partner(x), py = xor4_partner(y), pz = xor4_partner(z);
+    x = x + px;
+    y = y + py;
+    z = z + pz;
+    px = dpp_partner<0x4E>(x), py = dpp_partner<0x4E>(y), pz = dpp_partner<0x4E>(z);
+    x = x + px;
+    y = y + py;
+    z = z + pz;
+    px = dpp_partner<0xB1>(x), py = dpp_partner<0xB1>(y), pz = dpp_partner<0xB1>(z);
+    x = x + px;
+    y = y + py;
+    z = z + pz;
+}
+
 struct IterateRef {
     int base; ///< first of 4 consecutive vector slots: x, xhat, grad, p
     int yh;   ///< index of this iterate's yhat m-vector (problems with general constraints)
@@ -829,11 +913,37 @@ __device__ __forceinline__ bool is_finite(double v) { return fabs(v) < __builtin
 // Profiling build (-DPANTR_PHASE_TIMING; `make phase` builds it as a separate library, never over
 // the product): stats.phase_s[] receives the seconds spent per phase (scripts/phase_timing.sh);
 // all documented stats fields keep their meaning and pantr_version() reports the build.
-#if defined(PANTR_REST_TIMING)
+#if defined(PANTR_REST_SPLIT)
+// Third profiling variant (`make phase EXTRA_HIPFLAGS="-DPANTR_REST_TIMING -DPANTR_REST_SPLIT=<base>"`,
+// scripts/rest_timing.py): the time outside the evaluations in sixteen pieces, four per build - phase_s[i]
+// receives piece <base> + i.  Pieces: 0 iterate swap + the wait for the helper's result, 1 bound test, 2 progress
+// check, 3 stop criterion; 4 prox copy (+ adoption of the helper's gradient), 5 prox step, 6 request to the helper,
+// 7 inactive set + right-hand side; 8 CG start, 9 first CG pass + d'Bd, 10 second CG pass, 11 the rest of a CG
+// iteration (and the model value); 12 full step, 13 candidate, 14 its prox step (+ the deferred model value),
+// 15 ratio test and radius.
+#define PANTR_FINE(k)                                                                              \
+    do {                                                                                           \
+        long long t_ = wall_clock64();                                                             \
+        const int b_ = rest_cur_ - (PANTR_REST_SPLIT);                                             \
+        if (b_ >= 0 && b_ < 4)                                                                     \
+            rest_bucket_[b_] += (double)(t_ - rest_last_) * P.tick_s;                              \
+        rest_last_ = t_;                                                                           \
+        rest_cur_  = (k);                                                                          \
+    } while (0)
+#define PANTR_REGION(k) do {} while (0)
+#define PANTR_PHASE(idx, ...)                                                                      \
+    do {                                                                                           \
+        const int keep_ = rest_cur_;                                                               \
+        PANTR_FINE(-100);                                                                          \
+        __VA_ARGS__;                                                                               \
+        PANTR_FINE(keep_);                                                                         \
+    } while (0)
+#elif defined(PANTR_REST_TIMING)
 // Second profiling variant (`make phase EXTRA_HIPFLAGS=-DPANTR_REST_TIMING`, scripts/rest_timing.py;
 // pantr_version() says "+rest-timing"): where a PANTR iteration's time OUTSIDE the evaluations goes.
 // phase_s[] then means: [0] all evaluations, [1] from the end of the CG loop to the stop criterion of the
 // next iteration, [2] prox iterate .. start of the CG loop, [3] the CG loop without its products.
+#define PANTR_FINE(k) do {} while (0)
 #define PANTR_REGION(k)                                                                            \
     do {                                                                                           \
         long long t_ = wall_clock64();                                                             \
@@ -849,6 +959,7 @@ __device__ __forceinline__ bool is_finite(double v) { return fabs(v) < __builtin
         PANTR_REGION(keep_);                                                                       \
     } while (0)
 #elif defined(PANTR_PHASE_TIMING)
+#define PANTR_FINE(k) do {} while (0)
 #define PANTR_REGION(k) do {} while (0)
 #define PANTR_PHASE(idx, ...)                                                                      \
     do {                                                                                           \
@@ -857,6 +968,7 @@ __device__ __forceinline__ bool is_finite(double v) { return fabs(v) < __builtin
         st.phase_s[idx] += (double)(wall_clock64() - t0_) * P.tick_s;                              \
     } while (0)
 #else
+#define PANTR_FINE(k) do {} while (0)
 #define PANTR_REGION(k) do {} while (0)
 #define PANTR_PHASE(idx, ...)                                                                    \
     do {                                                                                           \
@@ -880,6 +992,10 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                                                    DeviceStats &st, double *trace, int trace_cap) {
     const int lane = threadIdx.x & (WAVE - 1); // (two-wavefront workgroups: speculation)
     const int n = pb.n, nj = pb.nj;
+    // PB::NJ > 0: every lane owns exactly NJ elements of every vector (padding included, kept at zero) and the
+    // passes below are straight-line code on them (Owned<NJ>); otherwise the generic loops over nj
+    constexpr int NJ = PB::NJ;
+    using OV = Owned<(NJ > 0 ? NJ : 1)>;
     // iterate vectors (pb.ivec: HBM or LDS, the problem decides) and the CG block in LDS
     enum { S_IT0 = 0, S_IT1 = 4, S_IT2 = 8, S_Q = PB::CG_BASE + 0, S_WORK = PB::CG_BASE + 1, S_RJ = PB::CG_BASE + 2,
            S_Z = PB::CG_BASE + 3, S_R = PB::CG_BASE + 4, S_D = PB::CG_BASE + 5, S_STEP = PB::XIO_SLOT };
@@ -950,6 +1066,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
     int rest_cur_ = 1;
 #endif
     while (status == Busy) {
+        PANTR_FINE(0);
         // speculation (PB::HAS_SPEC, two-wavefront workgroups): psi(xhat), the bound test, grad_L(xhat)
         // and the tape of a rejected candidate's successor were evaluated by the helper wavefront
         // during the CG loop; taken here, dropped if the candidate was accepted
@@ -965,6 +1082,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                 have_spec = pb.spec_take(spec_psi);
         }
         // ---- psi(xhat) + quadratic upper bound backtracking on the new current iterate ----
+        PANTR_FINE(1);
         while (true) {
             // keeps the trajectory (and yhat) for grad_L(xhat)
             if (have_spec)
@@ -984,15 +1102,23 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
             ++st.n_prox_grad_step;
             ++st.qub_backtracks;
         }
+        PANTR_FINE(2);
         if (which != 0) {
             // did x move at all?  (the previous iterate now sits in cand or prox)
             const double *xo = pb.ivec(which == 1 ? cand.base : prox.base);
             const double *xn = X_(curr);
             bool same = true;
-            for (int j = 0; j < nj; ++j) {
-                int i = j * WAVE + lane;
-                if (i < n)
-                    same = same && xn[i] == xo[i];
+            if constexpr (NJ > 0) {
+                const OV a = OV::load(xn, lane), b = OV::load(xo, lane);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    same = same && a[j] == b[j];
+            } else {
+                for (int j = 0; j < nj; ++j) {
+                    int i = j * WAVE + lane;
+                    if (i < n)
+                        same = same && xn[i] == xo[i];
+                }
             }
             bool all_same = __builtin_amdgcn_readfirstlane(__all(same ? 1 : 0)) != 0;
             no_progress   = all_same ? no_progress + 1 : 0;
@@ -1000,6 +1126,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
         }
 
         // ---- stop criterion ----
+        PANTR_FINE(3);
         if (P.stop_crit == ProjGradUnitNorm) {
             eps_k = pb.proj_grad_unit_norm(X_(curr), G_(curr));
             ++st.n_prox_grad_step;
@@ -1021,11 +1148,16 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
             break;
 
         PANTR_REGION(2);
+        PANTR_FINE(4);
         // ---- forward-backward step: prox iterate xbar = xhat_k, grad via grad_L(xhat) ----
-        for (int j = 0; j < nj; ++j) {
-            int i = j * WAVE + lane;
-            if (i < n)
-                X_(prox)[i] = XH_(curr)[i];
+        if constexpr (NJ > 0) {
+            OV::load(XH_(curr), lane).store(X_(prox), lane);
+        } else {
+            for (int j = 0; j < nj; ++j) {
+                int i = j * WAVE + lane;
+                if (i < n)
+                    X_(prox)[i] = XH_(curr)[i];
+            }
         }
         prox.psi_x = curr.psi_xh;
         // grad_L(xhat): xbar = xhat_k was the last point psi was evaluated at (trajectory X is still
@@ -1039,13 +1171,16 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
         ++st.n_grad_L;
         prox.gamma = curr.gamma;
         prox.L     = curr.L;
+        PANTR_FINE(5);
         pb.prox_grad_step(prox.gamma, X_(prox), G_(prox), XH_(prox), P_(prox), prox.pTp, prox.gradTp);
         ++st.n_prox_grad_step;
+        PANTR_FINE(6);
         if constexpr (PB::HAS_SPEC)
             if (!P.disable_acceleration) // should the candidate be rejected: xbar's own next steps, meanwhile
                 pb.spec_request(prox.base + 1, prox.psi_x, prox.gradTp, prox.pTp, prox.L, P, prox.yh);
 
         // ---- Newton trust-region direction at xbar (Steihaug-Toint CG on the inactive set) ----
+        PANTR_FINE(7);
         bool accept    = false, model_deferred = false;
         double rho     = __builtin_nan(""), q_model = __builtin_nan("");
         int nJ = 0, cg_its = 0;
@@ -1055,14 +1190,28 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
             const uint32_t mask = pb.inactive_mask(prox.gamma, X_(prox), G_(prox), nJ);
             const double inv_gamma = -1.0 / prox.gamma;
             bool qK_zero = true;
-            for (int j = 0; j < nj; ++j) {
-                int i = j * WAVE + lane;
-                if (i < n) {
-                    bool in   = (mask >> j) & 1u;
-                    double pi = P_(prox)[i];
-                    rJ[i]     = in ? inv_gamma * pi : 0.0;
-                    q[i]      = in ? 0.0 : pi;
-                    qK_zero   = qK_zero && (in || pi == 0.0);
+            if constexpr (NJ > 0) {
+                const OV pp = OV::load(P_(prox), lane);
+                OV rj, qq;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { // (padding: outside J, p = 0)
+                    bool in = (mask >> j) & 1u;
+                    rj[j]   = in ? inv_gamma * pp[j] : 0.0;
+                    qq[j]   = in ? 0.0 : pp[j];
+                    qK_zero = qK_zero && (in || pp[j] == 0.0);
+                }
+                rj.store(rJ, lane);
+                qq.store(q, lane);
+            } else {
+                for (int j = 0; j < nj; ++j) {
+                    int i = j * WAVE + lane;
+                    if (i < n) {
+                        bool in   = (mask >> j) & 1u;
+                        double pi = P_(prox)[i];
+                        rJ[i]     = in ? inv_gamma * pi : 0.0;
+                        q[i]      = in ? 0.0 : pi;
+                        qK_zero   = qK_zero && (in || pi == 0.0);
+                    }
                 }
             }
             // H q_K is not evaluated when q_K = 0 (active bounds the prox step does not leave - nine
@@ -1088,16 +1237,33 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
             PANTR_REGION(3);
             while (true) {
                 if (state == CGSTART) {
+                    PANTR_FINE(8);
                     // all 64 nj slots: the CG passes below run without bounds checks, the padding of
                     // every vector they touch is zero and stays zero (rJ's and work's are never written)
-                    for (int j = 0; j < nj; ++j) {
-                        int i    = j * WAVE + lane;
-                        double g = rJ[i];
-                        z[i]     = 0.0;
-                        r[i]     = g;
-                        d[i]     = -g;
+                    if constexpr (NJ > 0) {
+                        const OV g = OV::load(rJ, lane);
+                        OV zz, dd;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            zz[j] = 0.0;
+                            dd[j] = -g[j];
+                            acc   = acc + g[j] * g[j];
+                        }
+                        zz.store(z, lane);
+                        g.store(r, lane);
+                        dd.store(d, lane);
+                        r_sq = uniform(wave_sum(acc));
+                    } else {
+                        for (int j = 0; j < nj; ++j) {
+                            int i    = j * WAVE + lane;
+                            double g = rJ[i];
+                            z[i]     = 0.0;
+                            r[i]     = g;
+                            d[i]     = -g;
+                        }
+                        r_sq = pb.dot(r, r);
                     }
-                    r_sq            = pb.dot(r, r);
                     double grad_mag = __builtin_sqrt(r_sq);
                     if (!(grad_mag > 0.0)) {
                         for (int j = 0; j < nj; ++j) {
@@ -1119,10 +1285,19 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                 ++st.n_hess_psi_prod;
                 ++st.n_hess_psi_prod_calls;
                 if (state == KTERM) {
-                    for (int j = 0; j < nj; ++j) {
-                        int i = j * WAVE + lane;
-                        if (i < n && ((mask >> j) & 1u))
-                            rJ[i] = rJ[i] + P.hessian_vec_factor * work[i];
+                    if constexpr (NJ > 0) {
+                        OV rj = OV::load(rJ, lane);
+                        const OV w = OV::load(work, lane);
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            rj[j] = (mask >> j) & 1u ? rj[j] + P.hessian_vec_factor * w[j] : rj[j];
+                        rj.store(rJ, lane);
+                    } else {
+                        for (int j = 0; j < nj; ++j) {
+                            int i = j * WAVE + lane;
+                            if (i < n && ((mask >> j) & 1u))
+                                rJ[i] = rJ[i] + P.hessian_vec_factor * work[i];
+                        }
                     }
                     state = CGSTART;
                     continue;
@@ -1135,58 +1310,86 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                     //   d = -r + beta d; z = step
                     // element by element and sum by sum.
                     ++cg_its;
-                    double acc = 0.0;
-                    for (int j = 0; j < nj; ++j) {
-                        int i    = j * WAVE + lane;
-                        double b = (mask >> j) & 1u ? work[i] : 0.0;
-                        acc      = acc + d[i] * b;
-                    }
-                    double dBd = uniform(wave_sum(acc));
-                    bool to_boundary = false, neg_curv = dBd <= 0.0;
-                    double alpha = 0, r_next_sq = 0;
-                    if (!neg_curv) {
-                        alpha = r_sq / dBd;
-                        double a2 = 0.0, a3 = 0.0;
-                        for (int j = 0; j < nj; ++j) {
-                            int i     = j * WAVE + lane;
-                            double si = z[i] + alpha * d[i];
-                            step[i]   = si;
-                            a2        = a2 + si * si;
-                            double b  = (mask >> j) & 1u ? work[i] : 0.0;
-                            double ri = r[i] + alpha * b; // unused if the step reaches the boundary
-                            r[i]      = ri;
-                            a3        = a3 + ri * ri;
+                    if constexpr (NJ > 0) {
+                        // everything a CG iteration reads, at once; its three passes work on registers
+                        const OV dv = OV::load(d, lane), wv = OV::load(work, lane), zv = OV::load(z, lane),
+                                 rv = OV::load(r, lane);
+                        PANTR_FINE(9);
+                        OV bv;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            bv[j] = (mask >> j) & 1u ? wv[j] : 0.0;
+                            acc   = acc + dv[j] * bv[j];
                         }
-                        a2          = wave_sum(a2);
-                        a3          = wave_sum(a3);
-                        to_boundary = __builtin_sqrt(uniform(a2)) >= radius;
-                        r_next_sq   = uniform(a3);
-                    }
-                    if (neg_curv || to_boundary) {
-                        // ||z + t d|| = radius
-                        double zz = pb.dot(z, z), zd = pb.dot(z, d), dd = pb.dot(d, d);
-                        double qa_ = dd, qb_ = 2.0 * zd, qc_ = zz - radius * radius;
-                        double sqd = __builtin_sqrt(qb_ * qb_ - (4.0 * qa_) * qc_);
-                        double aux = qb_ + copysign(sqd, qb_);
-                        double t1 = (-aux) / (2.0 * qa_), t2 = (-(2.0 * qc_)) / aux;
-                        double ta = fmin(t1, t2), tb = fmax(t1, t2);
-                        if (neg_curv) {
-                            for (int j = 0; j < nj; ++j) {
-                                int i = j * WAVE + lane;
-                                if (i < n) {
-                                    double zi = z[i], di = d[i];
-                                    r[i] = zi + ta * di;
-                                    d[i] = zi + tb * di;
+                        double dBd = uniform(wave_sum(acc));
+                        bool to_boundary = false, neg_curv = dBd <= 0.0;
+                        double alpha = 0, r_next_sq = 0;
+                        PANTR_FINE(10);
+                        OV sv, rn;
+                        if (!neg_curv) {
+                            alpha = r_sq / dBd;
+                            double a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) {
+                                sv[j] = zv[j] + alpha * dv[j];
+                                a2    = a2 + sv[j] * sv[j];
+                                rn[j] = rv[j] + alpha * bv[j]; // unused if the step reaches the boundary
+                                a3    = a3 + rn[j] * rn[j];
+                            }
+                            sv.store(step, lane);
+                            rn.store(r, lane);
+                            wave_sum2(a2, a3);
+                            to_boundary = __builtin_sqrt(uniform(a2)) >= radius;
+                            r_next_sq   = uniform(a3);
+                        }
+                        PANTR_FINE(11);
+                        if (neg_curv || to_boundary) {
+                            // ||z + t d|| = radius
+                            double zz = 0.0, zd = 0.0, dd = 0.0;
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) {
+                                zz = zz + zv[j] * zv[j];
+                                zd = zd + zv[j] * dv[j];
+                                dd = dd + dv[j] * dv[j];
+                            }
+                            wave_sum3(zz, zd, dd);
+                            zz = uniform(zz), zd = uniform(zd), dd = uniform(dd);
+                            double qa_ = dd, qb_ = 2.0 * zd, qc_ = zz - radius * radius;
+                            double sqd = __builtin_sqrt(qb_ * qb_ - (4.0 * qa_) * qc_);
+                            double aux = qb_ + copysign(sqd, qb_);
+                            double t1 = (-aux) / (2.0 * qa_), t2 = (-(2.0 * qc_)) / aux;
+                            double ta = fmin(t1, t2), tb = fmax(t1, t2);
+                            // (the padding stays zero whatever ta and tb are)
+                            if (neg_curv) {
+                                OV ra, db;
+#pragma unroll
+                                for (int j = 0; j < NJ; ++j) {
+                                    const bool own = j * WAVE + lane < n;
+                                    ra[j] = own ? zv[j] + ta * dv[j] : 0.0;
+                                    db[j] = own ? zv[j] + tb * dv[j] : 0.0;
                                 }
+                                ra.store(r, lane);
+                                db.store(d, lane);
+                                state = EVAL_A;
+                                vin   = r;
+                            } else {
+                                OV sb;
+#pragma unroll
+                                for (int j = 0; j < NJ; ++j)
+                                    sb[j] = j * WAVE + lane < n ? zv[j] + tb * dv[j] : 0.0;
+                                sb.store(step, lane);
+                                if ((model_deferred = defer_model())) {
+                                    ++st.n_hess_psi_prod;
+                                    ++st.n_hess_psi_prod_calls;
+                                    break;
+                                }
+                                state = EVAL_STEP;
+                                vin   = step;
                             }
-                            state = EVAL_A;
-                            vin   = r;
-                        } else {
-                            for (int j = 0; j < nj; ++j) {
-                                int i = j * WAVE + lane;
-                                if (i < n)
-                                    step[i] = z[i] + tb * d[i];
-                            }
+                            continue;
+                        }
+                        if (__builtin_sqrt(r_next_sq) < tolerance || cg_i > cg_max) {
                             if ((model_deferred = defer_model())) {
                                 ++st.n_hess_psi_prod;
                                 ++st.n_hess_psi_prod_calls;
@@ -1194,32 +1397,122 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                             }
                             state = EVAL_STEP;
                             vin   = step;
+                            continue;
                         }
+                        double beta = r_next_sq / r_sq;
+                        r_sq        = r_next_sq;
+                        OV dn;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            dn[j] = (-rn[j]) + beta * dv[j];
+                        dn.store(d, lane);
+                        sv.store(z, lane);
+                        ++cg_i;
+                        vin = d;
+                        continue;
+                    } else {
+                        PANTR_FINE(9);
+                        double acc = 0.0;
+                        for (int j = 0; j < nj; ++j) {
+                            int i    = j * WAVE + lane;
+                            double b = (mask >> j) & 1u ? work[i] : 0.0;
+                            acc      = acc + d[i] * b;
+                        }
+                        double dBd = uniform(wave_sum(acc));
+                        bool to_boundary = false, neg_curv = dBd <= 0.0;
+                        double alpha = 0, r_next_sq = 0;
+                        PANTR_FINE(10);
+                        if (!neg_curv) {
+                            alpha = r_sq / dBd;
+                            double a2 = 0.0, a3 = 0.0;
+                            for (int j = 0; j < nj; ++j) {
+                                int i     = j * WAVE + lane;
+                                double si = z[i] + alpha * d[i];
+                                step[i]   = si;
+                                a2        = a2 + si * si;
+                                double b  = (mask >> j) & 1u ? work[i] : 0.0;
+                                double ri = r[i] + alpha * b; // unused if the step reaches the boundary
+                                r[i]      = ri;
+                                a3        = a3 + ri * ri;
+                            }
+                            a2          = wave_sum(a2);
+                            a3          = wave_sum(a3);
+                            to_boundary = __builtin_sqrt(uniform(a2)) >= radius;
+                            r_next_sq   = uniform(a3);
+                        }
+                        PANTR_FINE(11);
+                        if (neg_curv || to_boundary) {
+                            // ||z + t d|| = radius
+                            double zz = pb.dot(z, z), zd = pb.dot(z, d), dd = pb.dot(d, d);
+                            double qa_ = dd, qb_ = 2.0 * zd, qc_ = zz - radius * radius;
+                            double sqd = __builtin_sqrt(qb_ * qb_ - (4.0 * qa_) * qc_);
+                            double aux = qb_ + copysign(sqd, qb_);
+                            double t1 = (-aux) / (2.0 * qa_), t2 = (-(2.0 * qc_)) / aux;
+                            double ta = fmin(t1, t2), tb = fmax(t1, t2);
+                            if (neg_curv) {
+                                for (int j = 0; j < nj; ++j) {
+                                    int i = j * WAVE + lane;
+                                    if (i < n) {
+                                        double zi = z[i], di = d[i];
+                                        r[i] = zi + ta * di;
+                                        d[i] = zi + tb * di;
+                                    }
+                                }
+                                state = EVAL_A;
+                                vin   = r;
+                            } else {
+                                for (int j = 0; j < nj; ++j) {
+                                    int i = j * WAVE + lane;
+                                    if (i < n)
+                                        step[i] = z[i] + tb * d[i];
+                                }
+                                if ((model_deferred = defer_model())) {
+                                    ++st.n_hess_psi_prod;
+                                    ++st.n_hess_psi_prod_calls;
+                                    break;
+                                }
+                                state = EVAL_STEP;
+                                vin   = step;
+                            }
+                            continue;
+                        }
+                        if (__builtin_sqrt(r_next_sq) < tolerance || cg_i > cg_max) {
+                            if ((model_deferred = defer_model())) {
+                                ++st.n_hess_psi_prod;
+                                ++st.n_hess_psi_prod_calls;
+                                break;
+                            }
+                            state = EVAL_STEP;
+                            vin   = step;
+                            continue;
+                        }
+                        double beta = r_next_sq / r_sq;
+                        r_sq        = r_next_sq;
+                        for (int j = 0; j < nj; ++j) {
+                            int i = j * WAVE + lane;
+                            d[i]  = (-r[i]) + beta * d[i];
+                            z[i]  = step[i];
+                        }
+                        ++cg_i;
+                        vin = d;
                         continue;
                     }
-                    if (__builtin_sqrt(r_next_sq) < tolerance || cg_i > cg_max) {
-                        if ((model_deferred = defer_model())) {
-                            ++st.n_hess_psi_prod;
-                            ++st.n_hess_psi_prod_calls;
-                            break;
-                        }
-                        state = EVAL_STEP;
-                        vin   = step;
-                        continue;
-                    }
-                    double beta = r_next_sq / r_sq;
-                    r_sq        = r_next_sq;
-                    for (int j = 0; j < nj; ++j) {
-                        int i = j * WAVE + lane;
-                        d[i]  = (-r[i]) + beta * d[i];
-                        z[i]  = step[i];
-                    }
-                    ++cg_i;
-                    vin = d;
-                    continue;
                 }
                 // model value m(p) = p'g + 1/2 p'Hp of the vector just multiplied
-                double mval = pb.dot(vin, rJ) + 0.5 * pb.dot_masked(vin, work, mask);
+                double mval;
+                if constexpr (NJ > 0) {
+                    const OV vv = OV::load(vin, lane), gv = OV::load(rJ, lane), wv = OV::load(work, lane);
+                    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        a1 = a1 + vv[j] * gv[j];
+                        a2 = a2 + vv[j] * ((mask >> j) & 1u ? wv[j] : 0.0);
+                    }
+                    wave_sum2(a1, a2);
+                    mval = uniform(a1) + 0.5 * uniform(a2);
+                } else {
+                    mval = pb.dot(vin, rJ) + 0.5 * pb.dot_masked(vin, work, mask);
+                }
                 if (state == EVAL_A) {
                     qa    = mval;
                     state = EVAL_B;
@@ -1241,15 +1534,32 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                 break;
             }
             PANTR_REGION(1);
+            PANTR_FINE(12);
             st.cg_iterations += cg_its;
             // full step: Newton part on J, prox step on the active set
             bool fin = true;
-            for (int j = 0; j < nj; ++j) {
-                int i = j * WAVE + lane;
-                if (i < n) {
-                    double qi = (mask >> j) & 1u ? step[i] : P_(prox)[i];
-                    q[i]      = qi;
-                    fin       = fin && is_finite(qi);
+            OV xc;             // NJ > 0: the candidate xbar + q and q'q, formed in the same pass
+            double qq_acc = 0.0; // q'q
+            if constexpr (NJ > 0) {
+                const OV sv = OV::load(step, lane), pp = OV::load(P_(prox), lane), xp = OV::load(X_(prox), lane);
+                OV qv;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { // (padding: outside J, p = 0)
+                    qv[j]  = (mask >> j) & 1u ? sv[j] : pp[j];
+                    fin    = fin && is_finite(qv[j]);
+                    xc[j]  = xp[j] + qv[j];
+                    qq_acc = qq_acc + qv[j] * qv[j];
+                }
+                qv.store(q, lane);
+                qq_acc = uniform(wave_sum(qq_acc));
+            } else {
+                for (int j = 0; j < nj; ++j) {
+                    int i = j * WAVE + lane;
+                    if (i < n) {
+                        double qi = (mask >> j) & 1u ? step[i] : P_(prox)[i];
+                        q[i]      = qi;
+                        fin       = fin && is_finite(qi);
+                    }
                 }
             }
             bool q_finite = __builtin_amdgcn_readfirstlane(__all(fin ? 1 : 0)) != 0;
@@ -1266,19 +1576,26 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
             };
             if (!q_finite)
                 settle_model();
+            PANTR_FINE(13);
             if (q_finite && (model_deferred || q_model < 0)) {
-                for (int j = 0; j < nj; ++j) {
-                    int i = j * WAVE + lane;
-                    if (i < n)
-                        X_(cand)[i] = X_(prox)[i] + q[i];
+                if constexpr (NJ > 0) {
+                    xc.store(X_(cand), lane);
+                } else {
+                    for (int j = 0; j < nj; ++j) {
+                        int i = j * WAVE + lane;
+                        if (i < n)
+                            X_(cand)[i] = X_(prox)[i] + q[i];
+                    }
                 }
                 PANTR_PHASE(PH_PSI_GRAD, cand.psi_x = pb.eval_psi_grad(X_(cand), G_(cand)));
                 cand.gamma = prox.gamma;
                 cand.L     = prox.L;
+                PANTR_FINE(14);
                 pb.prox_grad_step(cand.gamma, X_(cand), G_(cand), XH_(cand), P_(cand), cand.pTp,
                                   cand.gradTp);
                 settle_model();
             }
+            PANTR_FINE(15);
             if (q_finite && q_model < 0) {
                 ++st.n_psi_grad_psi;
                 ++st.n_prox_grad_step;
@@ -1286,7 +1603,11 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
                 double tr_eps = (1.0 + fabs(phi_k)) * P.TR_tolerance_factor;
                 rho    = ((phi_k - phi_n) + tr_eps) / (-q_model);
                 accept = rho >= P.ratio_threshold_acceptable;
-                double qn = __builtin_sqrt(pb.dot(q, q));
+                double qn;
+                if constexpr (NJ > 0)
+                    qn = __builtin_sqrt(qq_acc);
+                else
+                    qn = __builtin_sqrt(pb.dot(q, q));
                 double nr = rho >= P.ratio_threshold_good ? fmax(P.radius_factor_good * qn, radius)
                             : rho >= P.ratio_threshold_acceptable ? radius * P.radius_factor_acceptable
                                                                   : P.radius_factor_rejected * qn;
@@ -1314,6 +1635,7 @@ __device__ __forceinline__ InnerResult pantr_inner(PB &pb, const KernelParams &P
         pb.spec_exit();
 #ifdef PANTR_REST_TIMING
     PANTR_REGION(1);
+    PANTR_FINE(0);
     for (int i = 0; i < 4; ++i)
         st.phase_s[i] += rest_bucket_[i];
 #endif

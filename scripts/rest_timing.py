@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where a PANTR iteration's time outside the function evaluations goes (library built with
-`make phase EXTRA_HIPFLAGS=-DPANTR_REST_TIMING`).  Development aid."""
-import os, sys
+`make phase EXTRA_HIPFLAGS=-DPANTR_REST_TIMING`; with `-DPANTR_REST_SPLIT=<base>` on top of it the four fields
+hold pieces <base>..<base>+3 of the sixteen named in pantr_kernel.hip.h).  Development aid."""
+import os, re, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pantr-cdc2023-experiments_amd"))
@@ -10,6 +11,11 @@ from pantr_amd import workloads
 
 if "+rest-timing" not in pa.version():
     raise SystemExit(f"{pa.LIB_PATH} is not the rest-timing build ({pa.version()})")
+split = re.search(r"\+rest-split=(\d+)", pa.version())
+PIECES = ["swap + wait for the helper", "bound test", "progress check", "stop criterion",
+          "prox copy / adoption", "prox step", "request", "inactive set + rhs",
+          "CG start", "CG pass 1 + d'Bd", "CG pass 2", "CG rest + model value",
+          "full step", "candidate", "candidate's prox step", "ratio test + radius"]
 
 N = int(os.environ.get("HORIZON", "60"))
 for problem in sys.argv[1:] or ["quadcopter", "realistic_quadcopter", "hanging_chain"]:
@@ -25,6 +31,10 @@ for problem in sys.argv[1:] or ["quadcopter", "realistic_quadcopter", "hanging_c
     i = int(np.argmax(st["elapsed_s"])); s = st[i]; it = int(s["iterations"])
     ph = s["phase_s"]
     print(f"{problem} N={60 if problem == 'hanging_chain' else N} ({b.kernel_name()}), pass {b.last_kernel_ms():.2f} ms: slowest instance {i}: {s['elapsed_s']*1e3:.1f} ms, {it} iterations, {s['cg_iterations']} CG iterations")
-    print(f"   per iteration, us: evaluations {ph[0]/it*1e6:.1f} | end of the CG loop .. stop criterion {ph[1]/it*1e6:.1f} | prox iterate .. CG start {ph[2]/it*1e6:.1f} "
-          f"| CG algebra {ph[3]/it*1e6:.1f} ({ph[3]/max(int(s['cg_iterations']),1)*1e6:.2f} per CG iteration, two clock reads included)")
+    if split:
+        base = int(split.group(1))
+        print("   per iteration, us: " + " | ".join(f"[{base+k}] {PIECES[base+k]} {ph[k]/it*1e6:.2f}" for k in range(4)))
+    else:
+        print(f"   per iteration, us: evaluations {ph[0]/it*1e6:.1f} | end of the CG loop .. stop criterion {ph[1]/it*1e6:.1f} | prox iterate .. CG start {ph[2]/it*1e6:.1f} "
+              f"| CG algebra {ph[3]/it*1e6:.1f} ({ph[3]/max(int(s['cg_iterations']),1)*1e6:.2f} per CG iteration, two clock reads included)")
     b.close()
