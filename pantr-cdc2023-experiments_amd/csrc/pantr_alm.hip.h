@@ -94,7 +94,12 @@ struct ScalarALProblem {
     static constexpr int C_JP = 0, C_JV = C_JP + 3 * NAU, C_JA = C_JV + 3 * NAU, C_HAU = C_JA + 18,
                          C_HPP = C_HAU + NAU * NAU, NCOEF = C_HPP + 9, HNB = 18;
     static constexpr double cpv = M::c6 * 6.0, hvv = 2.0 * 1.0, hvvN = 2.0 * 25.0;
-    __host__ __device__ static int tape_pitch(int N) { return (N + 15) & ~15; }
+    /// Row pitch of the tape (doubles).  Up to 64 stages it is the constant FIXED_PITCH: the kernels that know
+    /// their elements per lane at compile time (NJ_ > 0: n = nu N <= 256) address the 118 rows with immediate
+    /// offsets from one base instead of a scalar address computation per row.
+    static constexpr int FIXED_PITCH = 64;
+    static_assert(NJ_ == 0 || NJ_ * WAVE <= nu * FIXED_PITCH, "NJ_ > 0 implies N <= FIXED_PITCH");
+    __host__ __device__ static int tape_pitch(int N) { return N <= FIXED_PITCH ? FIXED_PITCH : (N + 15) & ~15; }
     __host__ __device__ static size_t workspace_doubles(int N) { return (size_t)NCOEF * tape_pitch(N) + HNB; }
 
     static constexpr int CG_BASE = NUM_ITER_VEC; ///< all 20 vectors in LDS: iterates first, then the CG block
@@ -820,7 +825,10 @@ struct ScalarALProblem {
     __device__ __forceinline__ void eval_grad_xhat(const double *u, double *grad, int yh_slot) const {
         reverse<true>(u, mvec(MV_YH + yh_slot), grad);
         int pitch = tape_pitch(N);
-        asm volatile("" : "+s"(pitch)); // see hess_prod()
+        if constexpr (NJ_ > 0)
+            pitch = FIXED_PITCH;
+        else
+            asm volatile("" : "+s"(pitch)); // see hess_prod()
         // terminal block: lanes 0..2 seed the position directions of x_N, lanes 3..5 the attitude's
         if (lane < 6) {
             const int blk = lane < 3 ? 0 : 6, d = lane < 3 ? lane : lane + 3;
@@ -932,7 +940,10 @@ struct ScalarALProblem {
         // the row addresses are loop invariants of the whole solve: computed ahead they would occupy
         // (and spill) a few hundred registers for the lifetime of the kernel; they are scalar work of a
         // few dozen cycles per product instead
-        asm volatile("" : "+s"(pitch));
+        if constexpr (NJ_ > 0)
+            pitch = FIXED_PITCH; // (N <= 64) the rows are at compile-time offsets from the tape's base
+        else
+            asm volatile("" : "+s"(pitch));
         constexpr bool RATES_ARE_INPUTS = M::angles_are_integrated_inputs;
         constexpr int NJA = RATES_ARE_INPUTS ? 3 : 18, NJ = 6 * NAU, NH = NAU * NAU + 9;
         auto load_ja = [&](int k, double (&ja)[NJA]) {

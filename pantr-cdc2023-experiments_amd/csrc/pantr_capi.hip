@@ -29,6 +29,21 @@ namespace {
 
 /// Elements of an n-vector per lane that the quadcopter family's PANTR kernels know at compile time (n <= 256).
 constexpr int ALM_NJ = 4;
+/// The same for the hanging chain's PANTR kernels: instantiated for the horizons whose n = 3 N fills exactly
+/// CHAIN_NJ_A (N = 43..64: the bench batch) or CHAIN_NJ_B (N = 107..128: the stress batch) rows of 64; other
+/// horizons run the generic passes (last template argument 0).
+constexpr int CHAIN_NJ_A = 3, CHAIN_NJ_B = 6;
+template <class F>
+auto with_chain_nj(int nj, F &&f) {
+#ifdef PANTR_CHAIN_GENERIC_PASSES // development switch (A/B): every horizon through the generic passes
+    nj = 0;
+#endif
+    if (nj == CHAIN_NJ_A)
+        return f(std::integral_constant<int, CHAIN_NJ_A>{});
+    if (nj == CHAIN_NJ_B)
+        return f(std::integral_constant<int, CHAIN_NJ_B>{});
+    return f(std::integral_constant<int, 0>{});
+}
 
 thread_local std::string g_last_error;
 
@@ -65,6 +80,7 @@ struct pantr_batch {
     // device memory
     double *d_x0 = nullptr, *d_u = nullptr, *d_v = nullptr, *d_o1 = nullptr, *d_o2 = nullptr,
            *d_s = nullptr, *d_ws = nullptr, *d_trace = nullptr;
+    double *d_bounds = nullptr; ///< hanging chain: box C as two n_pad-vectors (lower, upper; padding 0), read by the PANTR kernels' element-wise passes
     double *d_lbfgs = nullptr; ///< L-BFGS rings of method=panoc/strucpanoc, allocated at the first such solve
     size_t lbfgs_doubles = 0;
     double *d_y = nullptr, *d_sig = nullptr, *d_om = nullptr, *d_uinit = nullptr; ///< m > 0 problems
@@ -319,6 +335,18 @@ size_t residency_lds(const pantr_batch *b, size_t dyn_bytes, size_t static_bytes
     return std::min(std::max(dyn_bytes, want), cu - static_bytes);
 }
 
+/// Box C as device vectors (the element-wise passes read their bounds like any other operand); after every
+/// change of b->box.
+int upload_bounds(pantr_batch *b) {
+    std::vector<double> h(2 * (size_t)b->npad, 0.0);
+    for (int i = 0; i < b->n; ++i) {
+        h[i]           = b->box.u_lb[i % b->nu];
+        h[b->npad + i] = b->box.u_ub[i % b->nu];
+    }
+    HIP_TRY(hipMemcpy(b->d_bounds, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    return PANTR_OK;
+}
+
 int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, double *d_y,
                  DeviceStats *d_stats, hipStream_t stream) {
     if (int rc = check_supported(b->opts))
@@ -388,25 +416,36 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
     a.trace = b->trace_instances > 0 ? b->d_trace : nullptr;
     a.order = b->have_order ? b->d_order : nullptr;
     a.prm   = to_kernel_params(b->opts, b->tick_s, b->box);
+    a.lbv = b->d_bounds; a.ubv = b->d_bounds + b->npad;
     if (method != 0 && b->lds_bytes + WaveProblem<ChainModel>::tape_lds_bytes() > 160 * 1024)
         return fail(PANTR_ERR_OUT_OF_RANGE, "horizon too long for method=panoc|strucpanoc: their vectors do not fit the 160 KiB LDS");
     HIP_TRY(hipEventRecord(b->ev_start, stream));
     if (method == 0 && use_speculation(b, B)) {
         const size_t lds = residency_lds(b, spec_lds_bytes(*b), 2 * SpecProblemT<ChainModel>::tape_lds_bytes() + sizeof(SpecBox));
-        if (b->opts.residency > 0)
-            if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(&pantr_solve_spec_kernel<ChainModel>), lds))
-                return rc;
-        hipLaunchKernelGGL(pantr_solve_spec_kernel<ChainModel>, dim3(B), dim3(2 * WAVE), lds, stream, a);
+        if (int rc = with_chain_nj(b->nj, [&](auto nj) {
+                constexpr int NJ = decltype(nj)::value;
+                if (b->opts.residency > 0)
+                    if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(&pantr_solve_spec_kernel<ChainModel, NJ>), lds))
+                        return rc;
+                hipLaunchKernelGGL((pantr_solve_spec_kernel<ChainModel, NJ>), dim3(B), dim3(2 * WAVE), lds, stream, a);
+                return 0;
+            }))
+            return rc;
     } else if (method == 0) {
         const size_t lds = residency_lds(b, b->lds_bytes_pantr, SolveProblemT<ChainModel, 0>::tape_lds_bytes());
-        if (b->opts.residency > 0)
-            if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(&pantr_solve_kernel<ChainModel, 0>), lds))
-                return rc;
-        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 0>), dim3(B), dim3(WAVE), lds, stream, a);
+        if (int rc = with_chain_nj(b->nj, [&](auto nj) {
+                constexpr int NJ = decltype(nj)::value;
+                if (b->opts.residency > 0)
+                    if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(&pantr_solve_kernel<ChainModel, 0, NJ>), lds))
+                        return rc;
+                hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 0, NJ>), dim3(B), dim3(WAVE), lds, stream, a);
+                return 0;
+            }))
+            return rc;
     } else if (method == 1)
-        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 1>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 1, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
     else
-        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 2>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 2, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev_stop, stream));
     b->timed = true;
@@ -709,14 +748,19 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
                 if (int rc = raise_dynamic_lds(k, b->lds_bytes_cmp))
                     return rc;
     } else {
-        if (int rc = raise_dynamic_lds((const void *)&pantr_solve_kernel<ChainModel, 0>, b->lds_bytes_pantr))
+        if (int rc = with_chain_nj(b->nj, [&](auto nj) {
+                constexpr int NJ = decltype(nj)::value;
+                if (int rc = raise_dynamic_lds((const void *)&pantr_solve_kernel<ChainModel, 0, NJ>, b->lds_bytes_pantr))
+                    return rc;
+                if (spec_lds_total(*b) <= 160 * 1024)
+                    if (int rc = raise_dynamic_lds((const void *)&pantr_solve_spec_kernel<ChainModel, NJ>, spec_lds_bytes(*b)))
+                        return rc;
+                return 0;
+            }))
             return rc;
-        if (spec_lds_total(*b) <= 160 * 1024)
-            if (int rc = raise_dynamic_lds((const void *)&pantr_solve_spec_kernel<ChainModel>, spec_lds_bytes(*b)))
-                return rc;
         if (b->lds_bytes + static_lds <= 160 * 1024) // else the comparators are refused at launch
-            for (const void *k : {(const void *)&pantr_solve_kernel<ChainModel, 1>,
-                                  (const void *)&pantr_solve_kernel<ChainModel, 2>})
+            for (const void *k : {(const void *)&pantr_solve_kernel<ChainModel, 1, 0>,
+                                  (const void *)&pantr_solve_kernel<ChainModel, 2, 0>})
                 if (int rc = raise_dynamic_lds(k, b->lds_bytes))
                     return rc;
         if (int rc = raise_dynamic_lds((const void *)&pantr_eval_kernel<ChainModel, 2>, eval_lds_bytes(*b)))
@@ -733,7 +777,10 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
         (rc = dev_alloc(b->d_o2, B * nv)) || (rc = dev_alloc(b->d_s, B * 4)) ||
         (rc = dev_alloc(b->d_ws, std::max<size_t>(B * b->ws_per_instance, 1))) || (rc = dev_alloc(b->d_stats, B)) ||
         (rc = dev_alloc(b->d_order, B)) || (rc = dev_alloc(b->d_y, B * mv)) || (rc = dev_alloc(b->d_sig, B * mv)) ||
-        (rc = dev_alloc(b->d_om, B * mv)) || (rc = dev_alloc(b->d_uinit, nv)))
+        (rc = dev_alloc(b->d_om, B * mv)) || (rc = dev_alloc(b->d_uinit, nv)) ||
+        (rc = dev_alloc(b->d_bounds, 2 * (size_t)b->npad)))
+        return rc;
+    if ((rc = upload_bounds(b.get())))
         return rc;
     HIP_TRY(hipMemcpy(b->d_uinit, b->u_guess.data(), (size_t)b->n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(b->d_ws, 0, std::max<size_t>(B * b->ws_per_instance, 1) * sizeof(double)));
@@ -750,7 +797,7 @@ void pantr_batch_destroy(pantr_batch_t *b) {
     for (void *p : {(void *)b->d_x0, (void *)b->d_u, (void *)b->d_v, (void *)b->d_o1, (void *)b->d_o2,
                     (void *)b->d_s, (void *)b->d_ws, (void *)b->d_trace, (void *)b->d_stats,
                     (void *)b->d_order, (void *)b->d_y, (void *)b->d_sig, (void *)b->d_om, (void *)b->d_uinit,
-                    (void *)b->d_lbfgs})
+                    (void *)b->d_lbfgs, (void *)b->d_bounds})
         if (p)
             (void)hipFree(p);
     if (b->ev_start)
@@ -948,6 +995,8 @@ int pantr_batch_create_from_files(const char *path, const char *formulation, int
     b->u_guess           = d.guess;
     b->penalty_alm_split = d.penalty_alm_split;
     HIP_TRY(hipMemcpy(b->d_uinit, b->u_guess.data(), (size_t)b->n * sizeof(double), hipMemcpyHostToDevice));
+    if (int rc = upload_bounds(b.get()))
+        return rc;
     *out = b.release();
     return PANTR_OK;
 }
@@ -1007,9 +1056,16 @@ const char *pantr_batch_kernel_name(const pantr_batch_t *b, int32_t B) {
             return realistic ? "pantr_alm_kernel<QuadModelT<true>, 0, 4>" : "pantr_alm_kernel<QuadModelT<false>, 0, 4>";
         return names[realistic ? 1 : 0][method];
     }
-    if (method == 0)
-        return use_speculation(b, B) ? "pantr_solve_spec_kernel<ChainModel>" : "pantr_solve_kernel<ChainModel, 0>";
-    return method == 1 ? "pantr_solve_kernel<ChainModel, 1>" : "pantr_solve_kernel<ChainModel, 2>";
+    // (the last template argument: the compile-time elements per lane, CHAIN_NJ_A | CHAIN_NJ_B, or 0 = generic passes)
+    if (method == 0) {
+        static const char *spec[3] = {"pantr_solve_spec_kernel<ChainModel, 0>", "pantr_solve_spec_kernel<ChainModel, 3>",
+                                      "pantr_solve_spec_kernel<ChainModel, 6>"};
+        static const char *solo[3] = {"pantr_solve_kernel<ChainModel, 0, 0>", "pantr_solve_kernel<ChainModel, 0, 3>",
+                                      "pantr_solve_kernel<ChainModel, 0, 6>"};
+        const int v = b->nj == CHAIN_NJ_A ? 1 : b->nj == CHAIN_NJ_B ? 2 : 0;
+        return use_speculation(b, B) ? spec[v] : solo[v];
+    }
+    return method == 1 ? "pantr_solve_kernel<ChainModel, 1, 0>" : "pantr_solve_kernel<ChainModel, 2, 0>";
 }
 
 // ---- the hot path ------------------------------------------------------------------------

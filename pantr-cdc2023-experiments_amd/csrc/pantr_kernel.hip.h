@@ -127,8 +127,96 @@ struct SolveArgs {
     DeviceStats *stats;    ///< [B]
     double *trace;         ///< [trace_instances][trace_cap][TRACE_COLS] or nullptr
     const int32_t *order;  ///< optional launch order (instance index per workgroup) or nullptr
+    const double *lbv, *ubv; ///< [npad] box C tiled over the horizon, padding 0 (the passes of the NJ > 0 kernels read them)
     KernelParams prm;
 };
+
+// ---------------------------------------------------------------------------------------
+// Element-wise passes with a compile-time number of elements per lane (PB::NJ > 0)
+// ---------------------------------------------------------------------------------------
+// A lone wavefront pays for every instruction and for every dependent LDS round trip.  The generic passes
+// (`for (j < nj) { i = 64 j + lane; if (i < n) ... }`) run one trip per element under an exec mask; with NJ
+// known at compile time and the padding of every vector kept at zero a pass is straight-line code: all of a
+// lane's elements are loaded first (one wait), the arithmetic of the NJ elements interleaves, the stores
+// follow.  Element by element and sum by sum the operations - and their order - are those of the generic
+// passes: a padding element contributes +0 to a sum (or is masked out), which changes no bit.
+template <int NJ>
+struct Owned {
+    double v[NJ];
+    // (the lane index passes through an empty asm: the address arithmetic of a pass stays at the pass instead of
+    // being hoisted out of the solver's loops into registers that then live - and spill - across the sweeps)
+    __device__ __forceinline__ static Owned load(const double *a, int lane) {
+        asm volatile("" : "+v"(lane));
+        Owned r;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            r.v[j] = a[j * WAVE + lane];
+        return r;
+    }
+    __device__ __forceinline__ void store(double *a, int lane) const {
+        asm volatile("" : "+v"(lane));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            a[j * WAVE + lane] = v[j];
+    }
+    __device__ __forceinline__ double &operator[](int j) { return v[j]; }
+    __device__ __forceinline__ const double &operator[](int j) const { return v[j]; }
+};
+/// Two / three wave_sum()s level by level side by side (the same sums: each chain is wave_sum's).
+__device__ __forceinline__ void wave_sum2(double &x, double &y) {
+    double a, b, c, d;
+    row_partner<true>(x, a, b);
+    row_partner<true>(y, c, d);
+    x = a + b;
+    y = c + d;
+    row_partner<false>(x, a, b);
+    row_partner<false>(y, c, d);
+    x = a + b;
+    y = c + d;
+    double px = dpp_partner<0x128>(x), py = dpp_partner<0x128>(y);
+    x = x + px;
+    y = y + py;
+    px = xor4_partner(x), py = xor4_partner(y);
+    x = x + px;
+    y = y + py;
+    px = dpp_partner<0x4E>(x), py = dpp_partner<0x4E>(y);
+    x = x + px;
+    y = y + py;
+    px = dpp_partner<0xB1>(x), py = dpp_partner<0xB1>(y);
+    x = x + px;
+    y = y + py;
+}
+__device__ __forceinline__ void wave_sum3(double &x, double &y, double &z) {
+    double a, b, c, d, e, f;
+    row_partner<true>(x, a, b);
+    row_partner<true>(y, c, d);
+    row_partner<true>(z, e, f);
+    x = a + b;
+    y = c + d;
+    z = e + f;
+    row_partner<false>(x, a, b);
+    row_partner<false>(y, c, d);
+    row_partner<false>(z, e, f);
+    x = a + b;
+    y = c + d;
+    z = e + f;
+    double px = dpp_partner<0x128>(x), py = dpp_partner<0x128>(y), pz = dpp_partner<0x128>(z);
+    x = x + px;
+    y = y + py;
+    z = z + pz;
+    px = xor4_partner(x), py = xor4_partner(y), pz = xor4_partner(z);
+    x = x + px;
+    y = y + py;
+    z = z + pz;
+    px = dpp_partner<0x4E>(x), py = dpp_partner<0x4E>(y), pz = dpp_partner<0x4E>(z);
+    x = x + px;
+    y = y + py;
+    z = z + pz;
+    px = dpp_partner<0xB1>(x), py = dpp_partner<0xB1>(y), pz = dpp_partner<0xB1>(z);
+    x = x + px;
+    y = y + py;
+    z = z + pz;
+}
 
 // ---------------------------------------------------------------------------------------
 // Speculation on a rejected candidate (two-wavefront workgroups; hanging chain, method = pantr)
@@ -165,7 +253,8 @@ enum : int { SPEC_EVAL = 1, SPEC_EXIT = 2, SPEC_MODEL = 3 };
 // Wave-cooperative problem functions of the single-shooting problem
 // ---------------------------------------------------------------------------------------
 /// DEPTH: how many stages ahead a Hessian-vector product requests its tape rows (1 | 2; hess_prod_tape).
-template <class M, bool ITER_GLOBAL = false, bool SPEC = false, int DEPTH = 1>
+/// NJ_: 0, or nj = npad / 64 known at compile time - the element-wise passes are then straight-line code (Owned<NJ>).
+template <class M, bool ITER_GLOBAL = false, bool SPEC = false, int DEPTH = 1, int NJ_ = 0>
 struct WaveProblem {
     static_assert(DEPTH == 1 || DEPTH == 2, "one or two stages ahead");
     static constexpr int PREFETCH_DEPTH = DEPTH;
@@ -224,6 +313,7 @@ struct WaveProblem {
     /// Exchange row of the component gather: XS_DOUBLES doubles of dynamic LDS behind the kernel's vectors.
     static constexpr int XS_DOUBLES = 32;
     double *xrow = nullptr;
+    const double *lbv = nullptr, *ubv = nullptr; ///< HBM, shared by the batch: box C as n_pad-vectors (SolveArgs)
     __device__ __forceinline__ double *xs() const { return xrow; }
     /// Iterate vector `slot` (0..11): HBM (ITER_GLOBAL) or the first twelve LDS slots.
     __device__ __forceinline__ double *ivec(int slot) const {
@@ -237,10 +327,14 @@ struct WaveProblem {
         if constexpr (!ITER_GLOBAL)
             return u;
         double *s = vec(S_STAGE);
-        for (int j = 0; j < nj; ++j) { // each lane copies the elements it owns (and wrote)
-            int i = j * WAVE + L.l;
-            if (i < n)
-                s[i] = u[i];
+        if constexpr (NJ_ > 0) {
+            Owned<NJ_>::load(u, L.l).store(s, L.l); // (the loads of a lane's elements in flight together)
+        } else {
+            for (int j = 0; j < nj; ++j) { // each lane copies the elements it owns (and wrote)
+                int i = j * WAVE + L.l;
+                if (i < n)
+                    s[i] = u[i];
+            }
         }
         return s;
     }
@@ -285,7 +379,8 @@ struct WaveProblem {
 
     // ---- speculation: the main wavefront's side (no-ops without a mailbox) ---------------------
     static constexpr bool HAS_SPEC = SPEC; ///< only the two-wavefront kernel instantiates the hooks
-    static constexpr int NJ = 0;           ///< elements per lane known at compile time (Owned<NJ>): not here
+    static constexpr int NJ = NJ_;         ///< elements per lane known at compile time (Owned<NJ>), or 0
+    static_assert(NJ_ == 0 || ITER_GLOBAL, "the compile-time passes are those of method = pantr");
     static_assert(!SPEC || ITER_GLOBAL, "speculation needs the iterates in HBM");
     /// Post "evaluate psi, the bound test and grad_L + tape at ivec(xh_slot)"; the helper starts at once.
     __device__ __forceinline__ void spec_request(int xh_slot, double psi_x, double gradTp, double pTp, double Lip,
@@ -379,10 +474,14 @@ struct WaveProblem {
     __device__ __forceinline__ void spec_adopt(double *grad) const {
         wave_sync();
         const double *Gh = helper_G();
-        for (int j = 0; j < nj; ++j) {
-            int i = j * WAVE + L.l;
-            if (i < n)
-                grad[i] = Gh[i];
+        if constexpr (NJ_ > 0) {
+            Owned<NJ_>::load(Gh, L.l).store(grad, L.l); // (the helper's gradient vector: padding never written, zero)
+        } else {
+            for (int j = 0; j < nj; ++j) {
+                int i = j * WAVE + L.l;
+                if (i < n)
+                    grad[i] = Gh[i];
+            }
         }
         tape_cur = 1 - tape_cur;
         const_cast<WaveProblem *>(this)->tape = tape_buf(tape_cur);
@@ -661,9 +760,13 @@ struct WaveProblem {
         State s_t{0.0, 0.0};
         auto stage_fwd = [&](int k, char *cur, char *nxt) {
             wait_vmem(); // stage k's rows have landed in `cur`
+            // the stage input is read BEFORE the next stage's transfers are requested: an LDS read behind an LDS-DMA
+            // request gets a full s_waitcnt vmcnt(0) from the compiler whenever it cannot tell the vector from the
+            // landing buffers - the request just made would be waited for, stage after stage (+13 % per product when
+            // it happened; scripts/check_vmem_counts.py looks for that pattern in the compiled kernels)
+            const double uc_t = M::load_input(L, v + M::nu * k);
             if (k + 1 < N)
                 M::prefetch_fwd(L, tape + (size_t)(k + 1) * M::TAPE_D4_PER_STAGE, nxt);
-            const double uc_t = M::load_input(L, v + M::nu * k);
             M::xt_store(L, Xt + (size_t)k * M::XT_DOUBLES, s_t);
             s_t = M::rk4_tan(L, cur, s_t, uc_t, st + (size_t)k * M::ST_D4_PER_STAGE, xs());
         };
@@ -722,22 +825,37 @@ struct WaveProblem {
     }
 
     // ---- vector helpers over the LDS vectors: lane l owns i = l, l+64, ... ------------------
+    using OV = Owned<(NJ_ > 0 ? NJ_ : 1)>;
     __device__ __forceinline__ double dot(const double *a, const double *b) const {
         double acc = 0.0;
-        for (int j = 0; j < nj; ++j) {
-            int i = j * WAVE + L.l;
-            if (i < n)
-                acc = acc + a[i] * b[i];
+        if constexpr (NJ_ > 0) {
+            const OV av = OV::load(a, L.l), bv = OV::load(b, L.l);
+#pragma unroll
+            for (int j = 0; j < NJ_; ++j)
+                acc = acc + av[j] * bv[j];
+        } else {
+            for (int j = 0; j < nj; ++j) {
+                int i = j * WAVE + L.l;
+                if (i < n)
+                    acc = acc + a[i] * b[i];
+            }
         }
         return uniform(wave_sum(acc));
     }
     /// dot(a, mask ? b : 0)
     __device__ __forceinline__ double dot_masked(const double *a, const double *b, uint32_t mask) const {
         double acc = 0.0;
-        for (int j = 0; j < nj; ++j) {
-            int i = j * WAVE + L.l;
-            if (i < n)
-                acc = acc + a[i] * ((mask >> j) & 1u ? b[i] : 0.0);
+        if constexpr (NJ_ > 0) {
+            const OV av = OV::load(a, L.l), bv = OV::load(b, L.l);
+#pragma unroll
+            for (int j = 0; j < NJ_; ++j)
+                acc = acc + av[j] * ((mask >> j) & 1u ? bv[j] : 0.0);
+        } else {
+            for (int j = 0; j < nj; ++j) {
+                int i = j * WAVE + L.l;
+                if (i < n)
+                    acc = acc + a[i] * ((mask >> j) & 1u ? b[i] : 0.0);
+            }
         }
         return uniform(wave_sum(acc));
     }
@@ -757,6 +875,24 @@ struct WaveProblem {
                                                    double *xh, double *p, double &pTp,
                                                    double &gradTp) const {
         double a1 = 0.0, a2 = 0.0;
+        if constexpr (NJ_ > 0) {
+            const OV xv = OV::load(x, L.l), gv = OV::load(grad, L.l), lo = OV::load(lbv, L.l), hi = OV::load(ubv, L.l);
+            OV pv, xhv;
+#pragma unroll
+            for (int j = 0; j < NJ_; ++j) { // (padding: x = grad = lb = ub = 0, so p = 0 and xhat = 0)
+                double t = (-gamma) * gv[j];
+                pv[j]    = fmin(fmax(t, lo[j] - xv[j]), hi[j] - xv[j]);
+                xhv[j]   = xv[j] + pv[j];
+                a1       = a1 + pv[j] * pv[j];
+                a2       = a2 + pv[j] * gv[j];
+            }
+            pv.store(p, L.l);
+            xhv.store(xh, L.l);
+            wave_sum2(a1, a2);
+            pTp    = uniform(a1);
+            gradTp = uniform(a2);
+            return;
+        }
         for (int j = 0; j < nj; ++j) {
             int i = j * WAVE + L.l;
             if (i < n) {
@@ -777,6 +913,16 @@ struct WaveProblem {
     /// || Pi_C(x - grad) - x ||_inf  (ProjGradUnitNorm)
     __device__ __forceinline__ double proj_grad_unit_norm(const double *x, const double *grad) const {
         double r = 0.0;
+        if constexpr (NJ_ > 0) {
+            const OV xv = OV::load(x, L.l), gv = OV::load(grad, L.l), lo = OV::load(lbv, L.l), hi = OV::load(ubv, L.l);
+#pragma unroll
+            for (int j = 0; j < NJ_; ++j) {
+                double t  = (-1.0) * gv[j];
+                double pi = fmin(fmax(t, lo[j] - xv[j]), hi[j] - xv[j]);
+                r         = fmax(r, fabs(pi));
+            }
+            return uniform(wave_max(r));
+        }
         for (int j = 0; j < nj; ++j) {
             int i = j * WAVE + L.l;
             if (i < n) {
@@ -795,6 +941,18 @@ struct WaveProblem {
                                                       int &nJ) const {
         uint32_t mask = 0;
         int cnt       = 0;
+        if constexpr (NJ_ > 0) {
+            const OV xv = OV::load(x, L.l), gv = OV::load(grad, L.l), lo = OV::load(lbv, L.l), hi = OV::load(ubv, L.l);
+#pragma unroll
+            for (int j = 0; j < NJ_; ++j) { // (padding: 0 < 0 is false)
+                double xfw = xv[j] - gamma * gv[j];
+                bool in    = lo[j] < xfw && xfw < hi[j];
+                mask |= (in ? 1u : 0u) << j;
+                cnt += __builtin_popcountll(__ballot(in ? 1 : 0));
+            }
+            nJ = cnt;
+            return mask;
+        }
         for (int j = 0; j < nj; ++j) {
             int i   = j * WAVE + L.l;
             bool in = false;
@@ -810,89 +968,6 @@ struct WaveProblem {
         return mask;
     }
 };
-
-// ---------------------------------------------------------------------------------------
-// Element-wise passes with a compile-time number of elements per lane (PB::NJ > 0)
-// ---------------------------------------------------------------------------------------
-// A lone wavefront pays for every instruction and for every dependent LDS round trip.  The generic passes
-// (`for (j < nj) { i = 64 j + lane; if (i < n) ... }`) run one trip per element under an exec mask; with NJ
-// known at compile time and the padding of every vector kept at zero a pass is straight-line code: all of a
-// lane's elements are loaded first (one wait), the arithmetic of the NJ elements interleaves, the stores
-// follow.  Element by element and sum by sum the operations - and their order - are those of the generic
-// passes: a padding element contributes +0 to a sum (or is masked out), which changes no bit.
-template <int NJ>
-struct Owned {
-    double v[NJ];
-    __device__ __forceinline__ static Owned load(const double *a, int lane) {
-        Owned r;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            r.v[j] = a[j * WAVE + lane];
-        return r;
-    }
-    __device__ __forceinline__ void store(double *a, int lane) const {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            a[j * WAVE + lane] = v[j];
-    }
-    __device__ __forceinline__ double &operator[](int j) { return v[j]; }
-    __device__ __forceinline__ const double &operator[](int j) const { return v[j]; }
-};
-/// Two / three wave_sum()s level by level side by side (the same sums: each chain is wave_sum's).
-__device__ __forceinline__ void wave_sum2(double &x, double &y) {
-    double a, b, c, d;
-    row_partner<true>(x, a, b);
-    row_partner<true>(y, c, d);
-    x = a + b;
-    y = c + d;
-    row_partner<false>(x, a, b);
-    row_partner<false>(y, c, d);
-    x = a + b;
-    y = c + d;
-    double px = dpp_partner<0x128>(x), py = dpp_partner<0x128>(y);
-    x = x + px;
-    y = y + py;
-    px = xor4_partner(x), py = xor4_partner(y);
-    x = x + px;
-    y = y + py;
-    px = dpp_partner<0x4E>(x), py = dpp_partner<0x4E>(y);
-    x = x + px;
-    y = y + py;
-    px = dpp_partner<0xB1>(x), py = dpp_partner<0xB1>(y);
-    x = x + px;
-    y = y + py;
-}
-__device__ __forceinline__ void wave_sum3(double &x, double &y, double &z) {
-    double a, b, c, d, e, f;
-    row_partner<true>(x, a, b);
-    row_partner<true>(y, c, d);
-    row_partner<true>(z, e, f);
-    x = a + b;
-    y = c + d;
-    z = e + f;
-    row_partner<false>(x, a, b);
-    row_partner<false>(y, c, d);
-    row_partner<false>(z, e, f);
-    x = a + b;
-    y = c + d;
-    z = e + f;
-    double px = dpp_partner<0x128>(x), py = dpp_partner<0x128>(y), pz = dpp_partner<0x128>(z);
-    x = x + px;
-    y = y + py;
-    z = z + pz;
-    px = xor4_partner(x), py = xor4_partner(y), pz = xor4_partner(z);
-    x = x + px;
-    y = y + py;
-    z = z + pz;
-    px = dpp_partner<0x4E>(x), py = dpp_partner<0x4E>(y), pz = dpp_partner<0x4E>(z);
-    x = x + px;
-    y = y + py;
-    z = z + pz;
-    px = dpp_partner<0xB1>(x), py = dpp_partner<0xB1>(y), pz = dpp_partner<0xB1>(z);
-    x = x + px;
-    y = y + py;
-    z = z + pz;
-}
 
 struct IterateRef {
     int base; ///< first of 4 consecutive vector slots: x, xhat, grad, p
@@ -1681,10 +1756,10 @@ __device__ __forceinline__ InnerResult inner_solve(PB &pb, const KernelParams &P
 /// costs some (67.6 -> 74.9 ms on the 600-instance bench batch): one stage ahead.  profiles/r04_prefetch_depth.txt.
 constexpr int CHAIN_SOLVE_PREFETCH_DEPTH = 2;
 constexpr int CHAIN_SPEC_PREFETCH_DEPTH  = 1;
-template <class M, int METHOD>
-using SolveProblemT = WaveProblem<M, METHOD == 0, false, METHOD == 0 ? CHAIN_SOLVE_PREFETCH_DEPTH : 1>;
-template <class M>
-using SpecProblemT = WaveProblem<M, true, true, CHAIN_SPEC_PREFETCH_DEPTH>;
+template <class M, int METHOD, int NJ = 0>
+using SolveProblemT = WaveProblem<M, METHOD == 0, false, METHOD == 0 ? CHAIN_SOLVE_PREFETCH_DEPTH : 1, NJ>;
+template <class M, int NJ = 0>
+using SpecProblemT = WaveProblem<M, true, true, CHAIN_SPEC_PREFETCH_DEPTH, NJ>;
 
 /// One instance, start to finish, on the calling wavefront (the body of both solve kernels).
 template <int METHOD, class PB, class M>
@@ -1735,7 +1810,7 @@ __device__ __forceinline__ void solve_chain_instance(const SolveArgs &a, PB &pb,
     }
 }
 
-template <class M, int METHOD>
+template <class M, int METHOD, int NJ = 0>
 __global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // <= 256 VGPRs: two wavefronts per SIMD (uncapped it would take 260)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
@@ -1745,7 +1820,7 @@ __global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // 
     const long long t_start = wall_clock64(); // constant-rate clock, P.tick_s seconds per tick
     typename M::Lane L(lane);
 
-    using PB = SolveProblemT<M, METHOD>; // PANTR: iterates in HBM; the comparators: everything in LDS
+    using PB = SolveProblemT<M, METHOD, NJ>; // PANTR: iterates in HBM; the comparators: everything in LDS
     __shared__ __attribute__((aligned(16))) char tape_buf0[PB::LANDING_BYTES];
     __shared__ __attribute__((aligned(16))) char tape_buf1[PB::LANDING_BYTES];
     PB pb{L, a.prm.box, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, tape_buf0, tape_buf1};
@@ -1756,6 +1831,7 @@ __global__ __launch_bounds__(WAVE, 2) void pantr_solve_kernel(SolveArgs a) { // 
     pb.x0 = M::load_x0(L, a.x0 + (size_t)inst * M::nx);
     pb.bind_workspace(a.ws, inst);
     pb.xrow = lds + PB::LDS_SLOTS * a.npad;
+    pb.lbv = a.lbv; pb.ubv = a.ubv;
     solve_chain_instance<METHOD, PB, M>(a, pb, L, lane, inst, t_start, lds);
 }
 
@@ -1768,7 +1844,7 @@ __host__ __device__ constexpr size_t spec_lds_doubles(size_t npad) {
     using PB = SpecProblemT<M>;
     return (PB::LDS_SLOTS + PB::HELPER_SLOTS) * npad + 2 * PB::XS_DOUBLES;
 }
-template <class M>
+template <class M, int NJ = 0>
 __global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
@@ -1783,7 +1859,7 @@ __global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs
     __shared__ __attribute__((aligned(16))) char helper_buf0[SpecProblemT<M>::LANDING_BYTES];
     __shared__ __attribute__((aligned(16))) char helper_buf1[SpecProblemT<M>::LANDING_BYTES];
     __shared__ SpecBox box;
-    using PB = SpecProblemT<M>;
+    using PB = SpecProblemT<M, NJ>;
     if (threadIdx.x == 0) {
         box.req_seq = 0;
         box.done_seq = 0;
@@ -1802,6 +1878,7 @@ __global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs
         pb.spec   = &box;
         pb.spec_tick_s = a.prm.tick_s;
         pb.spec_patience_s = a.prm.spec_patience_s;
+        pb.lbv = a.lbv; pb.ubv = a.ubv;
     };
     if (wave == 1) {
         double *my = lds + PB::LDS_SLOTS * a.npad + PB::XS_DOUBLES;

@@ -76,7 +76,7 @@ def test_bench_line_contract():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.01 < rf["frac"] < 1.0
-    assert rf["kernel"] == "pantr_solve_spec_kernel<ChainModel>" and 0 < rf["kernel_ms"] <= d["ms_per_step"] * 1.01
+    assert rf["kernel"] == "pantr_solve_spec_kernel<ChainModel, 3>" and 0 < rf["kernel_ms"] <= d["ms_per_step"] * 1.01
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
     src = rf["traffic_source"]
     assert (rf["traffic"] is None) == ("refused" in src)                        # a figure only with its provenance

@@ -143,7 +143,7 @@ def test_longest_horizon_through_the_solve_kernel(rng):
     N = 682
     x0s, u0s = disturbed_state()[None, :], np.zeros((1, NU * N))
     b = pa.PantrBatch("hanging_chain", N, 1, opts=tuple(pa.DODO_PANTR_OPTS) + ("solver.max_iter=2",))
-    assert b.kernel_name() == "pantr_solve_kernel<ChainModel, 0>"      # (the two-wavefront kernel's LDS does not fit)
+    assert b.kernel_name() == "pantr_solve_kernel<ChainModel, 0, 0>"   # (the two-wavefront kernel's LDS does not fit; generic passes)
     u, st = b.solve(x0s, u0s)
     b.close()
     u_o, st_o, _ = ob.solve(N, x0s[0], u0s[0], ob.dodo_params(max_iter=2))
@@ -234,7 +234,7 @@ def test_config5_stress_horizon_120():
 
 def test_config5_full_launch_through_the_one_wavefront_kernel():
     """BASELINE.json configs[4] as bench.py launches it: all 1024 instances of N=120 in ONE launch, which
-    `speculation=auto` sends to pantr_solve_kernel<ChainModel, 0> (one wavefront per instance, tape rows requested
+    `speculation=auto` sends to pantr_solve_kernel<ChainModel, 0, 6> (one wavefront per instance, tape rows requested
     two stages ahead, four instances per compute unit - the memory system under load).  All 1024 are certified;
     32 of them, spread over the launch, equal the oracle's solve bit for bit, counters included; a second launch
     reproduces the first."""
@@ -243,7 +243,7 @@ def test_config5_full_launch_through_the_one_wavefront_kernel():
     w = workloads.stress_batch(1024)
     N, B = 120, 1024
     batch = pa.PantrBatch("hanging_chain", N, B, opts=w["opts"])
-    assert batch.kernel_name(B) == "pantr_solve_kernel<ChainModel, 0>"
+    assert batch.kernel_name(B) == "pantr_solve_kernel<ChainModel, 0, 6>"   # (n = 360: six elements per lane at compile time)
     u, st = batch.solve(w["x0"], w["u0"])
     u2, st2 = batch.solve(w["x0"], w["u0"])
     batch.close()
@@ -484,23 +484,23 @@ def test_residency_caps_workgroups_per_cu_and_changes_nothing_else():
 def test_kernel_name_follows_method_speculation_and_batch_size():
     """pantr_batch_kernel_name: what measurement code names its dominant kernel with."""
     b = pa.PantrBatch("hanging_chain", 60, 1024, opts=pa.DODO_PANTR_OPTS)
-    assert b.kernel_name(600) == "pantr_solve_spec_kernel<ChainModel>"      # auto: small batches speculate
-    assert b.kernel_name(1024) == "pantr_solve_kernel<ChainModel, 0>"       # auto: large ones do not
+    assert b.kernel_name(600) == "pantr_solve_spec_kernel<ChainModel, 3>"   # auto: small batches speculate (n = 180: three elements per lane)
+    assert b.kernel_name(1024) == "pantr_solve_kernel<ChainModel, 0, 3>"    # auto: large ones do not
     lds_auto, ws = b.footprint()
     assert b.footprint(1024) == (lds_auto, ws) and b.footprint(600)[0] > lds_auto   # the figure follows the kernel of B
     b.forget_buffers()
     b.close()
     b = pa.PantrBatch("hanging_chain", 60, 600, opts=tuple(pa.DODO_PANTR_OPTS) + ("speculation=off",))
-    assert b.kernel_name() == "pantr_solve_kernel<ChainModel, 0>"
+    assert b.kernel_name() == "pantr_solve_kernel<ChainModel, 0, 3>"
     lds_off, _ = b.footprint()
     b.close()
     b = pa.PantrBatch("hanging_chain", 60, 600, opts=tuple(pa.DODO_PANTR_OPTS) + ("speculation=on",))
-    assert b.kernel_name() == "pantr_solve_spec_kernel<ChainModel>"
+    assert b.kernel_name() == "pantr_solve_spec_kernel<ChainModel, 3>"
     lds_on, _ = b.footprint()
     b.close()
     assert lds_off == lds_auto < lds_on <= 160 * 1024 // 4   # (1024 instances: one wavefront each; four two-wavefront workgroups fit a CU)
     b = pa.PantrBatch("hanging_chain", 60, 8, opts=pa.DODO_OPTS["panoc"])
-    assert b.kernel_name() == "pantr_solve_kernel<ChainModel, 1>"
+    assert b.kernel_name() == "pantr_solve_kernel<ChainModel, 1, 0>"
     b.close()
     b = pa.PantrBatch("realistic_quadcopter", 12, 2)
     assert b.kernel_name() == "pantr_alm_spec_kernel<QuadModelT<true>, 4>"       # auto, a small batch (n <= 256: four elements per lane)

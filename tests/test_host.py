@@ -316,7 +316,8 @@ def test_eval_wrappers_validate_shapes():
 def test_explicit_vmcnt_waits_are_covered_in_the_compiled_kernel():
     """scripts/check_vmem_counts.py: every `s_waitcnt vmcnt(n)` of the two-stages-ahead product sweeps is preceded,
     in the compiled one-wavefront kernel, by at least n vector-memory instructions since the previous such wait
-    (what makes leaving n operations in flight safe)."""
+    (what makes leaving n operations in flight safe); and no stage loop of a product, in any of the hanging chain's
+    PANTR kernels, waits for tape rows it has only just requested."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_vmem_counts.py"), pa.LIB_PATH],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
