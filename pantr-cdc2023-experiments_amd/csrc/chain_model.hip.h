@@ -313,6 +313,12 @@ struct ChainModel {
             lds_dma_row<1024>(src, buf);
         }
     }
+    /// The M rows of a stage alone, to their place in the landing buffer (WaveProblem::prime_d1).
+    __device__ static __forceinline__ void prefetch_m(const Lane &L, const double4 *tape_stage, char *buf) {
+        const char *src = reinterpret_cast<const char *>(tape_stage) + L.l * 16;
+        lds_dma_row<2048>(src, buf);
+        lds_dma_row<3072>(src, buf);
+    }
     template <bool GROUP = false>
     __device__ static __forceinline__ void prefetch_rev(const Lane &L, const double4 *tape_stage,
                                                         const double4 *st_stage, char *buf) {

@@ -22,6 +22,7 @@
 #pragma once
 #include "wave_math.hip.h"
 #include <stdint.h>
+#include <type_traits>
 
 namespace pantr {
 
@@ -751,6 +752,18 @@ struct WaveProblem {
     // One stage ahead: a full wait at every stage start.  The two landing buffers are distinct __shared__ objects
     // and the stage loops are unrolled by two, so every LDS read names a buffer no transfer is writing (otherwise
     // the compiler drains the transfers in flight with vmcnt(0) before each read and the prefetch hides nothing).
+    /// What a product one stage ahead wants in flight before it starts (requested by the product before it, so that
+    /// the CG algebra in between covers the trip, or at the start of the first product on a new tape): the K rows of
+    /// stage 0 and the M rows of stage N - 1 - the adjoint sweep starts at that stage, in the landing buffer the
+    /// forward sweep's last stage used: K is there already, M arrives meanwhile (that part of both buffers is idle
+    /// during the forward sweep), the tangent spring vectors are written there directly and the tangent-state
+    /// component stays in a register.  The first adjoint stage then reads nothing from HBM (it used to wait for
+    /// 5 KiB requested only after the forward sweep: two exposed trips per product).
+    __device__ __forceinline__ char *last_stage_buf() const { return ((N - 1) & 1) ? tbuf1 : tbuf0; }
+    __device__ __forceinline__ void prime_d1() const {
+        M::prefetch_fwd(L, tape, tbuf0);
+        M::prefetch_m(L, tape + (size_t)(N - 1) * M::TAPE_D4_PER_STAGE, last_stage_buf());
+    }
     __device__ __forceinline__ void hess_prod_tape_d1(const double *v, double *Hv) const {
         wave_sync();
 #ifdef PANTR_PHASE_TIMING
@@ -758,35 +771,57 @@ struct WaveProblem {
 #endif
         // ---- forward tangent sweep ----
         State s_t{0.0, 0.0};
-        auto stage_fwd = [&](int k, char *cur, char *nxt) {
+        double xt_last = 0.0; // what xt_store() would write for stage N - 1 (and this lane read back)
+        auto stage_fwd = [&](int k, char *cur, char *nxt, auto last) {
+            constexpr bool LAST = decltype(last)::value;
             wait_vmem(); // stage k's rows have landed in `cur`
             // the stage input is read BEFORE the next stage's transfers are requested: an LDS read behind an LDS-DMA
             // request gets a full s_waitcnt vmcnt(0) from the compiler whenever it cannot tell the vector from the
             // landing buffers - the request just made would be waited for, stage after stage (+13 % per product when
             // it happened; scripts/check_vmem_counts.py looks for that pattern in the compiled kernels)
             const double uc_t = M::load_input(L, v + M::nu * k);
-            if (k + 1 < N)
+            if constexpr (!LAST) {
                 M::prefetch_fwd(L, tape + (size_t)(k + 1) * M::TAPE_D4_PER_STAGE, nxt);
-            M::xt_store(L, Xt + (size_t)k * M::XT_DOUBLES, s_t);
-            s_t = M::rk4_tan(L, cur, s_t, uc_t, st + (size_t)k * M::ST_D4_PER_STAGE, xs());
+                M::xt_store(L, Xt + (size_t)k * M::XT_DOUBLES, s_t);
+            } else {
+                xt_last = L.end ? s_t.x : s_t.v;
+            }
+            // the last stage writes its tangent spring vectors where the adjoint sweep's first stage reads them
+            double4 *st_k = LAST ? reinterpret_cast<double4 *>(cur + M::TAPE_STAGE_BYTES) : st + (size_t)k * M::ST_D4_PER_STAGE;
+            s_t = M::rk4_tan(L, cur, s_t, uc_t, st_k, xs());
         };
         if (!primed)
-            M::prefetch_fwd(L, tape, tbuf0);
-        for (int k = 0; k < N; k += 2) {
-            stage_fwd(k, tbuf0, tbuf1);
-            if (k + 1 < N)
-                stage_fwd(k + 1, tbuf1, tbuf0);
+            prime_d1();
+        {
+            constexpr std::false_type F{};
+            constexpr std::true_type T{};
+            int k = 0;
+            for (; k + 2 < N; k += 2) {
+                stage_fwd(k, tbuf0, tbuf1, F);
+                stage_fwd(k + 1, tbuf1, tbuf0, F);
+            }
+            if (k + 2 == N) {
+                stage_fwd(k, tbuf0, tbuf1, F);
+                stage_fwd(k + 1, tbuf1, tbuf0, T);
+            } else {
+                stage_fwd(k, tbuf0, tbuf1, T);
+            }
         }
-        wave_sync();
+        // (LDS accesses of a wavefront execute in order, and its vector-memory operations do: the tangent tape rows
+        // the adjoint sweep requests were stored at least a stage earlier by this wavefront - no wait for them here)
+        wave_sync_self();
 #ifdef PANTR_PHASE_TIMING
         fwd_cycles += clock64() - hv_t0_;
 #endif
         // ---- second-order adjoint sweep (even stages land in tbuf0, odd ones in tbuf1) ----
         State lam_t{0.0, 0.0};
         M::cost_grad_x_add_tan(L, L.end ? s_t.x : s_t.v, lam_t);
-        double xt = 0.0, xt_n = M::xt_load(L, Xt + (size_t)(N - 1) * M::XT_DOUBLES);
+        double xt = 0.0, xt_n = xt_last;
+        bool first = true; // stage N - 1 finds its rows in LDS
         auto stage_rev = [&](int k, char *cur, char *nxt) {
-            wait_vmem(); // stage k's rows and Xt row have landed
+            if (!first)
+                wait_vmem(); // stage k's rows and Xt row have landed
+            first = false;
             xt = xt_n;
             double uc_t = M::load_input(L, v + M::nu * k);
             if (k > 0) { // one stage ahead
@@ -802,10 +837,7 @@ struct WaveProblem {
             M::cost_grad_x_add_tan(L, xt, lam_t);
         };
         int k = N - 1;
-        if (k & 1) {
-            M::prefetch_rev(L, tape + (size_t)k * M::TAPE_D4_PER_STAGE, st + (size_t)k * M::ST_D4_PER_STAGE, tbuf1);
-        } else {
-            M::prefetch_rev(L, tape + (size_t)k * M::TAPE_D4_PER_STAGE, st + (size_t)k * M::ST_D4_PER_STAGE, tbuf0);
+        if (!(k & 1)) {
             stage_rev(k, tbuf0, tbuf1);
             --k;
         }
@@ -814,7 +846,7 @@ struct WaveProblem {
             stage_rev(k - 1, tbuf0, tbuf1);
         }
         wave_sync();
-        M::prefetch_fwd(L, tape, tbuf0); // for the next product (the CG algebra runs meanwhile)
+        prime_d1(); // for the next product (the CG algebra runs meanwhile)
         primed = true;
     }
     __device__ __forceinline__ void hess_prod_tape(const double *v, double *Hv) const {

@@ -308,6 +308,15 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+/// The same among the lanes of ONE wavefront only (nothing another wavefront reads is being published): a
+/// wavefront's LDS accesses execute in order and so do its vector-memory operations, so nothing is waited for -
+/// the fences keep the compiler from moving accesses across.
+__device__ __forceinline__ void wave_sync_self() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 /// LDS-DMA (gfx950 global_load_lds_dwordx4): every lane fetches 16 bytes from its own global
 /// address and the wavefront's 1 KiB lands contiguously at the wave-uniform LDS address
 /// `lds_row` (+ lane*16), without passing through VGPRs.  Completion is tracked by vmcnt.
