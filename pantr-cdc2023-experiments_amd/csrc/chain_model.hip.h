@@ -313,11 +313,21 @@ struct ChainModel {
             lds_dma_row<1024>(src, buf);
         }
     }
-    /// The M rows of a stage alone, to their place in the landing buffer (WaveProblem::prime_d1).
+    /// The M rows of a stage alone, to their place in the landing buffer (WaveProblem::prime_d1, prime).
+    template <bool GROUP = false>
     __device__ static __forceinline__ void prefetch_m(const Lane &L, const double4 *tape_stage, char *buf) {
         const char *src = reinterpret_cast<const char *>(tape_stage) + L.l * 16;
-        lds_dma_row<2048>(src, buf);
-        lds_dma_row<3072>(src, buf);
+        if constexpr (GROUP) {
+            lds_dma_rows<2>(src + 2048, buf + 2048);
+        } else {
+            lds_dma_row<2048>(src, buf);
+            lds_dma_row<3072>(src, buf);
+        }
+    }
+    /// The tangent tape and the tangent-state row of a stage alone, to their places (two transfers, as asm groups).
+    __device__ static __forceinline__ void prefetch_st_xt(const Lane &L, const double4 *st_stage, const double *xt_row, char *buf) {
+        lds_dma_rows<1>(reinterpret_cast<const char *>(st_stage) + L.l * 16, buf + TAPE_STAGE_BYTES);
+        lds_dma_256(reinterpret_cast<const char *>(xt_row) + L.l * 4, buf + LDS_STAGE_BYTES);
     }
     template <bool GROUP = false>
     __device__ static __forceinline__ void prefetch_rev(const Lane &L, const double4 *tape_stage,

@@ -645,8 +645,14 @@ struct WaveProblem {
         const long long hv_t0_ = clock64();
 #endif
         // ---- forward tangent sweep ----
+        // The adjoint sweep below starts where this one ends, and its first two stages find their rows in LDS:
+        // K from this sweep, M requested a product ahead (prime), the tangent spring vectors and the tangent-state
+        // row of stage N - 1 written by the last stage straight into its landing buffer, those of stage N - 2
+        // requested by the last stage (they were stored a stage earlier).  Requested after the sweep they cost every
+        // product two exposed trips to HBM - 2 to 4 us in a launch that loads the memory system.
         State s_t{0.0, 0.0};
-        auto stage_fwd = [&](int k, char *cur, char *nxt2) {
+        auto stage_fwd = [&](int k, char *cur, char *nxt2, char *prev, auto last) {
+            constexpr bool LAST = decltype(last)::value;
             // stage k's K rows have landed in `cur`; in flight behind them may be: stage k+1's rows (two
             // operations, issued at the start of stage k-1) and the five stores stage k-1 issued after them
             if (k == 0) {
@@ -654,27 +660,51 @@ struct WaveProblem {
                     wait_vmem_but<2>(); // stage 1's rows
                 else
                     wait_vmem();
-            } else if (k + 1 < N) {
+            } else if (!LAST) {
                 wait_vmem_but<7>();
             } else {
                 wait_vmem_but<5>(); // the last stage: nothing was requested after its rows but stage k-1's stores
             }
-            if (k + 2 < N)
-                M::template prefetch_fwd<true>(L, tape + (size_t)(k + 2) * M::TAPE_D4_PER_STAGE, nxt2);
+            if constexpr (!LAST) {
+                if (k + 2 < N)
+                    M::template prefetch_fwd<true>(L, tape + (size_t)(k + 2) * M::TAPE_D4_PER_STAGE, nxt2);
+            } else if (k > 0) { // the tangent tape and tangent-state row of stage N - 2, for the adjoint sweep's second stage
+                M::prefetch_st_xt(L, st + (size_t)(k - 1) * M::ST_D4_PER_STAGE, Xt + (size_t)(k - 1) * M::XT_DOUBLES, prev);
+            }
             const double uc_t = M::load_input(L, v + M::nu * k);
-            M::xt_store(L, Xt + (size_t)k * M::XT_DOUBLES, s_t);
-            s_t = M::rk4_tan(L, cur, s_t, uc_t, st + (size_t)k * M::ST_D4_PER_STAGE, xs());
+            double4 *st_k;
+            if constexpr (!LAST) {
+                M::xt_store(L, Xt + (size_t)k * M::XT_DOUBLES, s_t);
+                st_k = st + (size_t)k * M::ST_D4_PER_STAGE;
+            } else {
+                M::xt_store(L, reinterpret_cast<double *>(cur + M::LDS_STAGE_BYTES), s_t);
+                st_k = reinterpret_cast<double4 *>(cur + M::TAPE_STAGE_BYTES);
+            }
+            s_t = M::rk4_tan(L, cur, s_t, uc_t, st_k, xs());
         };
         if (!primed)
             prime();
-        for (int k = 0; k < N; k += 3) {
-            stage_fwd(k, tbuf0, tbuf2);
-            if (k + 1 < N)
-                stage_fwd(k + 1, tbuf1, tbuf0);
-            if (k + 2 < N)
-                stage_fwd(k + 2, tbuf2, tbuf1);
+        {
+            constexpr std::false_type F{};
+            constexpr std::true_type T{};
+            const int NL = N - 1; // the last stage by itself: its landing buffer is a constant in each of the three cases
+            for (int k = 0; k < NL; k += 3) {
+                stage_fwd(k, tbuf0, tbuf2, tbuf2, F);
+                if (k + 1 < NL)
+                    stage_fwd(k + 1, tbuf1, tbuf0, tbuf0, F);
+                if (k + 2 < NL)
+                    stage_fwd(k + 2, tbuf2, tbuf1, tbuf1, F);
+            }
+            if (NL % 3 == 0)
+                stage_fwd(NL, tbuf0, tbuf2, tbuf2, T);
+            else if (NL % 3 == 1)
+                stage_fwd(NL, tbuf1, tbuf0, tbuf0, T);
+            else
+                stage_fwd(NL, tbuf2, tbuf1, tbuf1, T);
         }
-        wave_sync();
+        // (nothing to wait for here: a wavefront's LDS accesses execute in order, and so do its vector-memory
+        // operations - the rows the adjoint sweep requests were stored by this wavefront at least a stage earlier)
+        wave_sync_self();
 #ifdef PANTR_PHASE_TIMING
         fwd_cycles += clock64() - hv_t0_;
 #endif
@@ -687,12 +717,18 @@ struct WaveProblem {
             M::prefetch_rev_xt(L, tape + (size_t)k * M::TAPE_D4_PER_STAGE, st + (size_t)k * M::ST_D4_PER_STAGE,
                                               Xt + (size_t)k * M::XT_DOUBLES, buf);
         };
+        bool first = true;
         auto stage_rev = [&](int k, char *cur, char *nxt2) {
-            // stage k's rows have landed; behind them may be stage k-1's (six transfers, the youngest operations)
-            if (k >= 1)
-                wait_vmem_but<6>();
-            else
-                wait_vmem();
+            // stage k's rows have landed; behind them may be stage k-1's: the six transfers stage k+1 requested, the
+            // youngest operations (stage N - 2: the two the forward sweep's last stage requested are older than the
+            // six of stage N - 3).  Stage N - 1 waits for nothing: see above.
+            if (!first) {
+                if (k >= 1)
+                    wait_vmem_but<6>();
+                else
+                    wait_vmem();
+            }
+            first = false;
             const double xt = M::xt_lds(L, cur);
             double uc_t = M::load_input(L, v + M::nu * k);
             if (k > 1) // two stages ahead
@@ -704,22 +740,8 @@ struct WaveProblem {
             lam_t = sbar_t;
             M::cost_grad_x_add_tan(L, xt, lam_t);
         };
-        // the first two stages' rows, the older request first (every request names its buffer: the compiler
-        // must see which landing buffer an LDS read can not be waiting for)
-        int k = N - 1;
-        auto first_rows = [&](char *b_last, char *b_before) {
-            rows_rev(k, b_last);
-            asm volatile("" ::: "memory");
-            if (k > 0)
-                rows_rev(k - 1, b_before);
-        };
-        if (k % 3 == 2)
-            first_rows(tbuf2, tbuf1);
-        else if (k % 3 == 1)
-            first_rows(tbuf1, tbuf0);
-        else
-            first_rows(tbuf0, tbuf2);
         // down to a multiple of three by hand, then three stages per trip
+        int k = N - 1;
         if (k % 3 == 2) {
             stage_rev(k, tbuf2, tbuf0);
             --k;
@@ -741,8 +763,25 @@ struct WaveProblem {
         prime(); // for the next product (the CG algebra runs meanwhile)
         primed = true;
     }
-    /// Request the K rows of the first two stages (stage 0's first).
+    /// What a product two stages ahead wants in flight before it starts: the M rows of the last two stages (where the
+    /// adjoint sweep starts; the oldest requests), then the K rows of stages 0 and 1 (the youngest two: stage 0's
+    /// wait leaves them in flight).
     __device__ __forceinline__ void prime() const {
+        // (a branch per buffer, not a selected address: every transfer names its landing buffer as a constant - with
+        // a selected one the compiler lost track of what the stage loops' LDS accesses can alias: 960 bytes of scratch)
+        auto m_rows = [&](int k) {
+            const double4 *rows = tape + (size_t)k * M::TAPE_D4_PER_STAGE;
+            if (k % 3 == 0)
+                M::template prefetch_m<true>(L, rows, tbuf0);
+            else if (k % 3 == 1)
+                M::template prefetch_m<true>(L, rows, tbuf1);
+            else
+                M::template prefetch_m<true>(L, rows, tbuf2);
+        };
+        m_rows(N - 1);
+        if (N > 1)
+            m_rows(N - 2);
+        asm volatile("" ::: "memory");
         M::template prefetch_fwd<true>(L, tape, tbuf0);
         asm volatile("" ::: "memory");
         if (N > 1)
@@ -759,10 +798,12 @@ struct WaveProblem {
     /// during the forward sweep), the tangent spring vectors are written there directly and the tangent-state
     /// component stays in a register.  The first adjoint stage then reads nothing from HBM (it used to wait for
     /// 5 KiB requested only after the forward sweep: two exposed trips per product).
-    __device__ __forceinline__ char *last_stage_buf() const { return ((N - 1) & 1) ? tbuf1 : tbuf0; }
     __device__ __forceinline__ void prime_d1() const {
         M::prefetch_fwd(L, tape, tbuf0);
-        M::prefetch_m(L, tape + (size_t)(N - 1) * M::TAPE_D4_PER_STAGE, last_stage_buf());
+        if ((N - 1) & 1) // (a branch per buffer, not a selected address: every transfer names its landing buffer)
+            M::prefetch_m(L, tape + (size_t)(N - 1) * M::TAPE_D4_PER_STAGE, tbuf1);
+        else
+            M::prefetch_m(L, tape + (size_t)(N - 1) * M::TAPE_D4_PER_STAGE, tbuf0);
     }
     __device__ __forceinline__ void hess_prod_tape_d1(const double *v, double *Hv) const {
         wave_sync();

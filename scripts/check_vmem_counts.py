@@ -79,34 +79,73 @@ def check_waits_behind_transfers(asm, kernel):
     return 1 if bad or not any(inner) else 0
 
 
-def check(asm, kernel):
+def parse(asm, kernel):
     m = re.search(r"^[0-9a-f]+ <%s>:\n(.*?)(?=^[0-9a-f]+ <)" % re.escape(kernel), asm, re.S | re.M)
     if not m:
         raise SystemExit("kernel not found: " + kernel)
-    ins = [l.split("//")[0].strip() for l in m.group(1).splitlines() if l.startswith("\t")]
+    lines = [l for l in m.group(1).splitlines() if l.startswith("\t")]
+    ins = [l.split("//")[0].strip() for l in lines]
+    addr = [int(l.split("//")[-1].strip().split(":")[0], 16) if "//" in l else -1 for l in lines]
+    return ins, addr
+
+
+def predecessors(ins, addr):
+    """preds[i]: the instructions control can come from (fall-through and branches)."""
+    index = {a: i for i, a in enumerate(addr)}
+    preds = [[] for _ in ins]
+    for i, l in enumerate(ins):
+        b = re.match(r"(s_cbranch_\w+|s_branch) (\d+)", l)
+        if b:
+            off = int(b.group(2))
+            off -= 65536 if off >= 32768 else 0
+            j = index.get(addr[i] + 4 + 4 * off)
+            if j is not None:
+                preds[j].append(i)
+        if i + 1 < len(ins) and not l.startswith(("s_branch", "s_endpgm")):
+            preds[i + 1].append(i)
+    return preds
+
+
+def check(asm, kernel):
+    """Every explicit wait vmcnt(n), n >= 5, inside the product sweeps: at least n vector-memory instructions stand
+    between it and the explicit wait before it - walked backwards through the control-flow graph (the sweeps' last
+    stages are peeled, so the instruction before in the file need not be the instruction before in time), taking at
+    every join the predecessor with more of them: a request under `if (k + 2 < N)` counts as made, as it did when
+    this check scanned the instructions in file order (which branch conditions exclude each other it cannot know)."""
+    ins, addr = parse(asm, kernel)
+    preds = predecessors(ins, addr)
     explicit = {"s_waitcnt vmcnt(2)", "s_waitcnt vmcnt(5)", "s_waitcnt vmcnt(6)", "s_waitcnt vmcnt(7)"}
     vmem = re.compile(r"^(global_load_lds_|global_store_|global_load_|scratch_)")
-    checked, bad, last, count, dma = 0, 0, None, 0, 0
-    for i, l in enumerate(ins):
-        if vmem.match(l):
-            count += 1
-            dma += l.startswith("global_load_lds_")
-        if l in explicit:
-            n = int(l[-2])
-            # (two explicit waits back to back are the two arms of one `if`: the second sees what the first saw)
-            if last is not None and i - last <= 12:
-                count, dma = prev_count, prev_dma
-            # the sweeps' waits stand between LDS-DMA transfers; the compiler's own partial waits for the loads of an
-            # element-wise pass (vmcnt(6), vmcnt(5), ... as the values are consumed) have none since the wait before
-            if dma == 0:
-                prev_count, prev_dma, last, count, dma = count, dma, i, 0, 0
-                continue
-            if n >= 5 and last is not None:
-                checked += 1
-                if count < n:
-                    bad += 1
-                    print(f"instruction {i}: {l} after only {count} vector-memory instructions since the previous explicit wait")
-            prev_count, prev_dma, last, count, dma = count, dma, i, 0, 0
+    checked = bad = 0
+    for w, l in enumerate(ins):
+        if l not in explicit or int(l[-2]) < 5:
+            continue
+        n = int(l[-2])
+        # the compiler's own partial waits for the loads of an element-wise pass (vmcnt(6), vmcnt(5), ... as the values
+        # are consumed) are not the sweeps': those stand among LDS-DMA transfers
+        if not any(x.startswith("global_load_lds_") for x in ins[max(0, w - 400):w + 400]):
+            continue
+        # ... nor is one that continues a descending run vmcnt(n + 1), vmcnt(n), ...: the loads of a pass being consumed
+        back = [x for x in ins[max(0, w - 6):w] if x.startswith("s_waitcnt vmcnt(") or vmem.match(x)]
+        if back and re.fullmatch(r"s_waitcnt vmcnt\((\d+)\)", back[-1]) and int(back[-1][16:-1]) > n:
+            continue
+        best, seen, stack = 0, set(), [(p, 0) for p in preds[w]]
+        while stack and best < n:
+            i, c = stack.pop()
+            while True:
+                if vmem.match(ins[i]):
+                    c += 1
+                best = max(best, c)
+                if c >= n or (i, c) in seen or ins[i] in explicit or ins[i] == "s_waitcnt vmcnt(0)" or not preds[i]:
+                    break
+                seen.add((i, c))
+                for p in preds[i][1:]:
+                    stack.append((p, c))
+                i = preds[i][0]
+        checked += 1
+        if best < n:
+            bad += 1
+            print(f"instruction {w}: {l} with at most {best} vector-memory instructions since the explicit wait before it")
     print(f"{LIB} {kernel[30:-16]}: {checked} explicit waits of the two-stages-ahead sweeps checked, {bad} not covered")
     return 1 if bad or checked < 6 else 0
 
