@@ -98,6 +98,26 @@ def test_longest_realistic_quadcopter_horizon_solves_like_the_oracle():
     assert np.array_equal(u[0], u_o) and np.array_equal(y[0], y_o)
 
 
+@pytest.mark.parametrize("spec", ["on", "off"])
+def test_generic_passes_beyond_n_256_solve_like_the_oracle(rng, spec):
+    """n = 280 (quadcopter, N = 70): more than four elements per lane, so both ALM kernels of method=pantr run their
+    generic element-wise passes (last template argument 0; up to n = 256 the passes are straight-line code on four
+    elements per lane, which every other solve test of this file exercises)."""
+    problem, N, B = "quadcopter", 70, 2
+    b = pa.PantrBatch(problem, N, B, opts=quad_opts(problem) + [f"speculation={spec}"])
+    assert b.kernel_name() == ("pantr_alm_spec_kernel<QuadModelT<false>, 0>" if spec == "on" else "pantr_alm_kernel<QuadModelT<false>, 0, 0>")
+    x0 = np.vstack([ob.quad_initial_state(), ob.quad_initial_state() + 0.02 * rng.standard_normal((B - 1, 9))])
+    u0 = np.tile(ob.quad_initial_guess(N), (B, 1))
+    u, y, st = b.solve_al(x0, u0)
+    b.close()
+    for i in range(B):
+        u_o, y_o, st_o = ob.quad_solve(problem, N, x0[i], u0[i])
+        assert st["status"][i] == st_o["status"] == 1
+        for key in ("outer_iterations", "iterations", "cg_iterations", "n_hess_psi_prod", "n_hess_psi_prod_calls", "n_psi", "n_grad_L"):
+            assert st[key][i] == st_o[key], key
+        assert np.array_equal(u[i], u_o) and np.array_equal(y[i], y_o)
+
+
 @pytest.mark.parametrize("problem", ["quadcopter", "realistic_quadcopter"])
 @pytest.mark.parametrize("N", [1, 2])
 def test_smallest_horizons_solve_like_the_oracle(rng, problem, N):
