@@ -53,8 +53,12 @@ struct AlmSolveArgs {
 /// Wave-cooperative single-shooting problem with an augmented-Lagrangian term, scalar model M.
 /// NJ_: 0, or the number of elements of an n-vector every lane owns (nj, known at compile time: the element-wise
 /// passes of the solver are then straight-line code, Owned<NJ> in pantr_kernel.hip.h).
-template <class M, bool SPEC = false, int NJ_ = 0>
+/// SHORT_: which tape product the instantiation carries - 0: hess_prod()'s general routine (lane = stage), 1: the one
+/// for horizons of up to 16 stages (hess_prod_short(); quadcopter), 2: both, chosen by the horizon (the evaluation
+/// kernel).  Solve kernels carry one: a second routine in the same kernel moves the first one's registers.
+template <class M, bool SPEC = false, int NJ_ = 0, int SHORT_ = 0>
 struct ScalarALProblem {
+    static_assert(SHORT_ == 0 || M::angles_are_integrated_inputs, "hess_prod_short() is quadcopter's");
     static constexpr int nx = M::nx, nu = M::nu, nc = M::nc;
     static constexpr bool HAS_SPEC = SPEC; ///< a helper wavefront evaluates ahead (pantr_alm_spec_kernel; SpecBox)
     static constexpr int NJ = NJ_;
@@ -935,6 +939,15 @@ struct ScalarALProblem {
     /// trig store (W): all rebuilt by the next forward sweep before anything reads them (a product only
     /// ever follows the recording at the same point).
     __device__ __forceinline__ void hess_prod(const double *, const double *v, double *Hv) const {
+        if constexpr (SHORT_ == 1) {
+            hess_prod_short(v, Hv);
+            return;
+        } else if constexpr (SHORT_ == 2) {
+            if (N <= SHORT_STAGES) {
+                hess_prod_short(v, Hv);
+                return;
+            }
+        }
         wave_sync();
         int pitch = tape_pitch(N);
         // the row addresses are loop invariants of the whole solve: computed ahead they would occupy
@@ -1128,6 +1141,132 @@ struct ScalarALProblem {
         }
         wave_sync();
     }
+    /// The product for horizons of up to 16 stages (quadcopter; BASELINE.json configs[0] is N = 12), where lane = stage
+    /// leaves three quarters of the wavefront idle: lane = (row r, stage k), k = lane & 15, and row r < 3 works on
+    /// component r of every 3-vector (row 3 shadows row 2 and stores nothing but the thrust entry).  One running sum
+    /// inside the rows (four DPP levels) then serves all three components - 6 scans of 4 levels instead of 18 of 6 -,
+    /// a lane evaluates one row of Jp, Jv, Hpp and two of the seven rows of T instead of all of them, and reads a
+    /// third of the tape rows; the components of a vector reach the other rows through permlane swaps (three
+    /// gathers).  Every value is computed by the expression hess_prod() below uses for it, and the in-row sums are the
+    /// additions of wave_running_sum() on lanes 0..15: same bits (tests/test_gpu_quadcopter.py at N = 1, 7, 12).
+    static constexpr int SHORT_STAGES = 16;
+    __device__ __forceinline__ void hess_prod_short(const double *v, double *Hv) const {
+        wave_sync();
+        constexpr int pitch = FIXED_PITCH; // (N <= 16 < 64)
+        const int r = lane >> 4, kk = lane & 15, i = r < 3 ? r : 2;
+        const bool on = kk < N, row = r < 3;
+        auto T = [&](int c, int k) { return tape[(size_t)c * pitch + k]; };
+        // ---- forward: stage kk ----
+        // (the tape entries of a half into registers first, as in hess_prod(): requested together, one wait)
+        {
+            const int k = on ? kk : N - 1; // idle lanes shadow the last stage; they add 0 and store nothing
+            double jp[NAU], jv[NAU];
+#pragma unroll
+            for (int e = 0; e < NAU; ++e) {
+                jp[e] = T(C_JP + NAU * i + e, k);
+                jv[e] = T(C_JV + NAU * i + e, k);
+            }
+            const double cw = T(C_JA + 6 * i + 3 + i, k);
+            double z[NAU];
+            z[3] = v[nu * k]; z[4] = v[nu * k + 1]; z[5] = v[nu * k + 2]; z[6] = v[nu * k + 3];
+            const double zi = i == 0 ? z[4] : i == 1 ? z[5] : z[6];
+            const double sa = row_running_sum(on ? cw * zi : 0.0);
+            const double at = 0.0 + row_from_prev(sa); // a'_i of this stage: what the stages before add up to
+            rows_gather3(at, z[0], z[1], z[2]);
+            double rp = jp[0] * z[0], rv = jv[0] * z[0];
+#pragma unroll
+            for (int e = 1; e < NAU; ++e) {
+                rp = __builtin_fma(jp[e], z[e], rp);
+                rv = __builtin_fma(jv[e], z[e], rv);
+            }
+            const double sv = row_running_sum(on ? rv : 0.0);
+            const double vt = 0.0 + row_from_prev(sv);
+            const double sp = row_running_sum(on ? __builtin_fma(cpv, vt, rp) : 0.0);
+            const double pt = 0.0 + row_from_prev(sp);
+            if (on && row) {
+                Xt[k * nx + i]     = pt;
+                Xt[k * nx + 3 + i] = vt;
+                Xt[k * nx + 6 + i] = at;
+                if (kk == N - 1) { // x'_N: the totals
+                    Xt[N * nx + i]     = 0.0 + sp;
+                    Xt[N * nx + 3 + i] = 0.0 + sv;
+                    Xt[N * nx + 6 + i] = 0.0 + sa;
+                }
+            }
+        }
+        wave_sync();
+        // ---- lam'_N, component i ----
+        double lp, lv, la;
+        {
+            const double *HN = tape + (size_t)NCOEF * pitch;
+            const double *xN = Xt + N * nx;
+            lp = HN[3 * i] * xN[0];
+            lp = __builtin_fma(HN[3 * i + 1], xN[1], lp);
+            lp = __builtin_fma(HN[3 * i + 2], xN[2], lp);
+            lv = hvvN * xN[3 + i];
+            la = HN[9 + 3 * i] * xN[6];
+            la = __builtin_fma(HN[9 + 3 * i + 1], xN[7], la);
+            la = __builtin_fma(HN[9 + 3 * i + 2], xN[8], la);
+        }
+        // ---- backward: stage N - 1 - kk ----
+        {
+            const int k = on ? N - 1 - kk : 0;
+            // rows r (attitude row of rows 0..2, the thrust row of row 3) and 4 + i (rate row) of Hau, the matching
+            // columns of Jp and Jv, row i of Hpp
+            double ha[NAU], hw[NAU], pa[3], pw[3], va[3], vw[3], hp[3];
+#pragma unroll
+            for (int e = 0; e < NAU; ++e) {
+                ha[e] = T(C_HAU + NAU * r + e, k);
+                hw[e] = T(C_HAU + NAU * (4 + i) + e, k);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                pa[j] = T(C_JP + NAU * j + r, k);
+                pw[j] = T(C_JP + NAU * j + 4 + i, k);
+                va[j] = T(C_JV + NAU * j + r, k);
+                vw[j] = T(C_JV + NAU * j + 4 + i, k);
+                hp[j] = T(C_HPP + 3 * i + j, k);
+            }
+            const double cw = T(C_JA + 6 * i + 3 + i, k);
+            double z[NAU], xp[3], lpn[3], lvn[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                xp[j] = Xt[k * nx + j];
+                z[j]  = Xt[k * nx + 6 + j];
+            }
+            const double xv = Xt[k * nx + 3 + i];
+            z[3] = v[nu * k]; z[4] = v[nu * k + 1]; z[5] = v[nu * k + 2]; z[6] = v[nu * k + 3];
+            double q = hp[0] * xp[0];
+            q        = __builtin_fma(hp[1], xp[1], q);
+            q        = __builtin_fma(hp[2], xp[2], q);
+            const double lpn_i = lp + row_from_prev(row_running_sum(on ? q : 0.0)); // lp of stage k + 1
+            const double lvn_i = lv + row_from_prev(row_running_sum(on ? __builtin_fma(cpv, lpn_i, hvv * xv) : 0.0));
+            rows_gather3(lpn_i, lpn[0], lpn[1], lpn[2]);
+            rows_gather3(lvn_i, lvn[0], lvn[1], lvn[2]);
+            // a row of T = Hau (a', v_k) + Jp' lp+ + Jv' lv+
+            auto Trow = [&](const double (&h)[NAU], const double (&jpc)[3], const double (&jvc)[3]) {
+                double t = h[0] * z[0];
+#pragma unroll
+                for (int e = 1; e < NAU; ++e)
+                    t = __builtin_fma(h[e], z[e], t);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    t = __builtin_fma(jpc[j], lpn[j], t);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    t = __builtin_fma(jvc[j], lvn[j], t);
+                return t;
+            };
+            const double Ta = Trow(ha, pa, va), Tw = Trow(hw, pw, vw);
+            if (on && !row)
+                Hv[nu * k] = Ta; // T[3]
+            const double lan = la + row_from_prev(row_running_sum(on ? Ta : 0.0));
+            if (on && row)
+                Hv[nu * k + 1 + i] = __builtin_fma(cw, lan, Tw);
+        }
+        wave_sync();
+    }
+
     // ---- speculation on a rejected candidate (SPEC: two-wavefront workgroups, pantr_alm_spec_kernel) ----
     // As for the chain (pantr_kernel.hip.h, SpecBox): while the solver wavefront runs the CG loop and
     // evaluates the candidate, the helper evaluates what a rejection needs next - psi(xhat) of the prox
@@ -1561,7 +1700,7 @@ __device__ __forceinline__ double *alm_bind(PB &pb, const AlmSolveArgs &a, doubl
 }
 
 /// ALM outer loop (m > 0) around the inner solver METHOD names, one wavefront per instance.
-template <class M, int METHOD, int NJ = 0>
+template <class M, int METHOD, int NJ = 0, int SHORT = 0>
 __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
@@ -1569,7 +1708,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
     if (inst >= a.B)
         return;
     const long long t_start = wall_clock64();
-    using PB = ScalarALProblem<M, false, NJ>;
+    using PB = ScalarALProblem<M, false, NJ, SHORT>;
     PB pb;
     double *x0_lds = alm_bind<M, METHOD>(pb, a, lds, lane, inst);
     pb.tape = a.ws + (size_t)inst * PB::workspace_doubles(a.N);
@@ -1583,7 +1722,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_kernel(AlmSolveArgs a) {
 /// method = pantr with a helper wavefront per instance (ScalarALProblem: speculation).  Wavefront 0 is
 /// the solver of pantr_alm_kernel<M, 0>; wavefront 1 serves its requests on LDS of its own behind the
 /// solver's (helper_lds_doubles) and on the instance's second tape buffer.
-template <class M, int NJ = 0>
+template <class M, int NJ = 0, int SHORT = 0>
 __global__ __launch_bounds__(2 * WAVE) void pantr_alm_spec_kernel(AlmSolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
@@ -1592,7 +1731,7 @@ __global__ __launch_bounds__(2 * WAVE) void pantr_alm_spec_kernel(AlmSolveArgs a
         return;
     const long long t_start = wall_clock64();
     __shared__ SpecBox box;
-    using PB = ScalarALProblem<M, true, NJ>;
+    using PB = ScalarALProblem<M, true, NJ, SHORT>;
     PB pb;
     double *x0_lds = alm_bind<M, 0>(pb, a, lds, lane, inst);
     const size_t solver_doubles = PB::lds_doubles(a.N, a.npad, a.mpad, false);
@@ -1659,7 +1798,7 @@ __global__ __launch_bounds__(WAVE) void pantr_alm_eval_kernel(AlmEvalArgs a) {
     const int lane = threadIdx.x, inst = blockIdx.x;
     if (inst >= a.B)
         return;
-    using PB = ScalarALProblem<M>;
+    using PB = ScalarALProblem<M, false, 0, M::angles_are_integrated_inputs ? 2 : 0>; // (both products, by the horizon)
     PB pb;
     pb.lane = lane; pb.box = &a.box; pb.lds = lds; pb.N = a.N; pb.n = a.n; pb.npad = a.npad; pb.nj = a.nj;
     pb.m = a.m; pb.mpad = a.mpad; pb.mj = a.mj;

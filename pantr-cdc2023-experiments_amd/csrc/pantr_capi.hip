@@ -29,6 +29,8 @@ namespace {
 
 /// Elements of an n-vector per lane that the quadcopter family's PANTR kernels know at compile time (n <= 256).
 constexpr int ALM_NJ = 4;
+/// quadcopter: horizons up to this run the kernels that carry the tape product for short horizons (lane = (component, stage)).
+constexpr int ALM_SHORT_STAGES = ScalarALProblem<QuadModelT<false>>::SHORT_STAGES;
 /// The same for the hanging chain's PANTR kernels: instantiated for the horizons whose n = 3 N fills exactly
 /// CHAIN_NJ_A (N = 43..64: the bench batch) or CHAIN_NJ_B (N = 107..128: the stress batch) rows of 64; other
 /// horizons run the generic passes (last template argument 0).
@@ -387,21 +389,34 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
         with_quad_model(b, [&](auto model) {
             using M = decltype(model);
             const bool fixed_nj = b->nj == ALM_NJ;
+            // quadcopter up to 16 stages: the kernels with the product for short horizons (hess_prod_short)
+            constexpr bool HAS_SHORT = M::angles_are_integrated_inputs;
+            const bool short_horizon = HAS_SHORT && b->N <= ALM_SHORT_STAGES;
             if (method == 0 && use_alm_speculation(b, B)) {
+                if constexpr (HAS_SHORT)
+                    if (short_horizon) {
+                        hipLaunchKernelGGL((pantr_alm_spec_kernel<M, ALM_NJ, 1>), dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
+                        return 0;
+                    }
                 if (fixed_nj)
-                    hipLaunchKernelGGL((pantr_alm_spec_kernel<M, ALM_NJ>), dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
+                    hipLaunchKernelGGL((pantr_alm_spec_kernel<M, ALM_NJ, 0>), dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
                 else
-                    hipLaunchKernelGGL((pantr_alm_spec_kernel<M, 0>), dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
+                    hipLaunchKernelGGL((pantr_alm_spec_kernel<M, 0, 0>), dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
             } else if (method == 0) {
+                if constexpr (HAS_SHORT)
+                    if (short_horizon) {
+                        hipLaunchKernelGGL((pantr_alm_kernel<M, 0, ALM_NJ, 1>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+                        return 0;
+                    }
                 if (fixed_nj)
-                    hipLaunchKernelGGL((pantr_alm_kernel<M, 0, ALM_NJ>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+                    hipLaunchKernelGGL((pantr_alm_kernel<M, 0, ALM_NJ, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
                 else
-                    hipLaunchKernelGGL((pantr_alm_kernel<M, 0, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+                    hipLaunchKernelGGL((pantr_alm_kernel<M, 0, 0, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
             }
             else if (method == 1)
-                hipLaunchKernelGGL((pantr_alm_kernel<M, 1>), dim3(B), dim3(WAVE), b->lds_bytes_cmp, stream, a);
+                hipLaunchKernelGGL((pantr_alm_kernel<M, 1, 0, 0>), dim3(B), dim3(WAVE), b->lds_bytes_cmp, stream, a);
             else
-                hipLaunchKernelGGL((pantr_alm_kernel<M, 2>), dim3(B), dim3(WAVE), b->lds_bytes_cmp, stream, a);
+                hipLaunchKernelGGL((pantr_alm_kernel<M, 2, 0, 0>), dim3(B), dim3(WAVE), b->lds_bytes_cmp, stream, a);
             return 0;
         });
         HIP_TRY(hipGetLastError());
@@ -725,19 +740,21 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
     if ((b->al() ? b->lds_bytes : b->lds_bytes_pantr) + static_lds > 160 * 1024)
         return fail(PANTR_ERR_OUT_OF_RANGE, "decision vectors do not fit the 160 KiB LDS");
     if (b->al()) {
-        for (const void *k : {(const void *)&pantr_alm_kernel<QuadModelT<false>, 0, 0>,
-                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 0, 0>,
-                              (const void *)&pantr_alm_kernel<QuadModelT<false>, 0, ALM_NJ>,
-                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 0, ALM_NJ>,
+        for (const void *k : {(const void *)&pantr_alm_kernel<QuadModelT<false>, 0, 0, 0>,
+                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 0, 0, 0>,
+                              (const void *)&pantr_alm_kernel<QuadModelT<false>, 0, ALM_NJ, 0>,
+                              (const void *)&pantr_alm_kernel<QuadModelT<true>, 0, ALM_NJ, 0>,
+                              (const void *)&pantr_alm_kernel<QuadModelT<false>, 0, ALM_NJ, 1>,
                               (const void *)&pantr_alm_eval_kernel<QuadModelT<false>>,
                               (const void *)&pantr_alm_eval_kernel<QuadModelT<true>>})
             if (int rc = raise_dynamic_lds(k, b->lds_bytes))
                 return rc;
         if (alm_spec_lds_bytes(*b) + sizeof(SpecBox) <= 160 * 1024)
-            for (const void *k : {(const void *)&pantr_alm_spec_kernel<QuadModelT<false>, 0>,
-                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<true>, 0>,
-                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<false>, ALM_NJ>,
-                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<true>, ALM_NJ>})
+            for (const void *k : {(const void *)&pantr_alm_spec_kernel<QuadModelT<false>, 0, 0>,
+                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<true>, 0, 0>,
+                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<false>, ALM_NJ, 0>,
+                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<true>, ALM_NJ, 0>,
+                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<false>, ALM_NJ, 1>})
                 if (int rc = raise_dynamic_lds(k, alm_spec_lds_bytes(*b)))
                     return rc;
         if (b->lds_bytes_cmp <= 160 * 1024) // else the comparators are refused at launch
@@ -1044,16 +1061,22 @@ const char *pantr_batch_kernel_name(const pantr_batch_t *b, int32_t B) {
     const int method = static_cast<int>(b->opts.method);
     if (b->al()) {
         const bool realistic = b->problem == ProblemId::RealisticQuadcopter;
-        // (the last template argument: the compile-time elements per lane, ALM_NJ, or 0 = generic passes)
+        // (template arguments behind the model and the method: the compile-time elements per lane - ALM_NJ, or 0 = generic
+        // passes -, then 1 for the kernels with the product for short horizons, quadcopter up to ALM_SHORT_STAGES stages)
         static const char *names[2][3] = {
-            {"pantr_alm_kernel<QuadModelT<false>, 0, 0>", "pantr_alm_kernel<QuadModelT<false>, 1, 0>", "pantr_alm_kernel<QuadModelT<false>, 2, 0>"},
-            {"pantr_alm_kernel<QuadModelT<true>, 0, 0>", "pantr_alm_kernel<QuadModelT<true>, 1, 0>", "pantr_alm_kernel<QuadModelT<true>, 2, 0>"}};
-        const bool fixed_nj = b->nj == ALM_NJ;
-        if (use_alm_speculation(b, B))
-            return realistic ? (fixed_nj ? "pantr_alm_spec_kernel<QuadModelT<true>, 4>" : "pantr_alm_spec_kernel<QuadModelT<true>, 0>")
-                             : (fixed_nj ? "pantr_alm_spec_kernel<QuadModelT<false>, 4>" : "pantr_alm_spec_kernel<QuadModelT<false>, 0>");
+            {"pantr_alm_kernel<QuadModelT<false>, 0, 0, 0>", "pantr_alm_kernel<QuadModelT<false>, 1, 0, 0>", "pantr_alm_kernel<QuadModelT<false>, 2, 0, 0>"},
+            {"pantr_alm_kernel<QuadModelT<true>, 0, 0, 0>", "pantr_alm_kernel<QuadModelT<true>, 1, 0, 0>", "pantr_alm_kernel<QuadModelT<true>, 2, 0, 0>"}};
+        const bool fixed_nj = b->nj == ALM_NJ, short_horizon = !realistic && b->N <= ALM_SHORT_STAGES;
+        if (use_alm_speculation(b, B)) {
+            if (short_horizon)
+                return "pantr_alm_spec_kernel<QuadModelT<false>, 4, 1>";
+            return realistic ? (fixed_nj ? "pantr_alm_spec_kernel<QuadModelT<true>, 4, 0>" : "pantr_alm_spec_kernel<QuadModelT<true>, 0, 0>")
+                             : (fixed_nj ? "pantr_alm_spec_kernel<QuadModelT<false>, 4, 0>" : "pantr_alm_spec_kernel<QuadModelT<false>, 0, 0>");
+        }
+        if (method == 0 && short_horizon)
+            return "pantr_alm_kernel<QuadModelT<false>, 0, 4, 1>";
         if (method == 0 && fixed_nj)
-            return realistic ? "pantr_alm_kernel<QuadModelT<true>, 0, 4>" : "pantr_alm_kernel<QuadModelT<false>, 0, 4>";
+            return realistic ? "pantr_alm_kernel<QuadModelT<true>, 0, 4, 0>" : "pantr_alm_kernel<QuadModelT<false>, 0, 4, 0>";
         return names[realistic ? 1 : 0][method];
     }
     // (the last template argument: the compile-time elements per lane, CHAIN_NJ_A | CHAIN_NJ_B, or 0 = generic passes)

@@ -184,6 +184,15 @@ __device__ __forceinline__ double wave_running_sum(double x) {
     x = x + dpp_move_rows<0x143, 0xC>(x);
     return x;
 }
+/// The same inside every 16-lane row by itself: the first four levels of wave_running_sum() - for lanes 0..15 the
+/// very additions of wave_running_sum() when lanes 16..63 hold zeros (its last two levels then add nothing to row 0).
+__device__ __forceinline__ double row_running_sum(double x) {
+    x = x + dpp_move<0x111>(x);
+    x = x + dpp_move<0x112>(x);
+    x = x + dpp_move<0x114>(x);
+    x = x + dpp_move<0x118>(x);
+    return x;
+}
 /// Like dpp_move_rows, but a lane without a source (outside ROW_MASK, or shifted in from outside its
 /// row) keeps `old`.
 template <int CTRL, int ROW_MASK>
@@ -270,6 +279,14 @@ __device__ __forceinline__ void row_partner(double v, double &a, double &b) {
         a = __hiloint2double(h[0], l[0]);
         b = __hiloint2double(h[1], l[1]);
     }
+}
+/// Rows 0, 1, 2 of the wavefront hold x0, x1, x2 at the same position of their 16 lanes: all three, on every row
+/// (v_permlane16_swap pairs rows (0,1) and (2,3), v_permlane32_swap rows (0,2) and (1,3); row 3's value is dropped).
+__device__ __forceinline__ void rows_gather3(double v, double &c0, double &c1, double &c2) {
+    double even, odd, c3;
+    row_partner<false>(v, even, odd); // rows 0,1: (row 0, row 1); rows 2,3: (row 2, row 3)
+    row_partner<true>(even, c0, c2);  // row 0's and row 2's value, on all rows
+    row_partner<true>(odd, c1, c3);   // row 1's (and row 3's)
 }
 /// Value of lane ^ 4: four lanes up for lanes with bit 2 clear, four lanes down for the others.
 __device__ __forceinline__ double xor4_partner(double v) {

@@ -8,7 +8,7 @@ import pantr_amd as pa
 L = pa.lib()
 rng = np.random.default_rng(0)
 PROBLEM = sys.argv[1] if len(sys.argv) > 1 else "quadcopter"
-for N in (20, 60):
+for N in (12, 16, 20, 60):
     for B in (1, 60):
         b = pa.PantrBatch(PROBLEM, N, B)
         n, m = 4 * N, 4 * N + 4

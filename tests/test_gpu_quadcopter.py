@@ -105,7 +105,7 @@ def test_generic_passes_beyond_n_256_solve_like_the_oracle(rng, spec):
     elements per lane, which every other solve test of this file exercises)."""
     problem, N, B = "quadcopter", 70, 2
     b = pa.PantrBatch(problem, N, B, opts=quad_opts(problem) + [f"speculation={spec}"])
-    assert b.kernel_name() == ("pantr_alm_spec_kernel<QuadModelT<false>, 0>" if spec == "on" else "pantr_alm_kernel<QuadModelT<false>, 0, 0>")
+    assert b.kernel_name() == ("pantr_alm_spec_kernel<QuadModelT<false>, 0, 0>" if spec == "on" else "pantr_alm_kernel<QuadModelT<false>, 0, 0, 0>")
     x0 = np.vstack([ob.quad_initial_state(), ob.quad_initial_state() + 0.02 * rng.standard_normal((B - 1, 9))])
     u0 = np.tile(ob.quad_initial_guess(N), (B, 1))
     u, y, st = b.solve_al(x0, u0)
