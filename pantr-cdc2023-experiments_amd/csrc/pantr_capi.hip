@@ -395,7 +395,7 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
             if (method == 0 && use_alm_speculation(b, B)) {
                 if constexpr (HAS_SHORT)
                     if (short_horizon) {
-                        hipLaunchKernelGGL((pantr_alm_spec_kernel<M, ALM_NJ, 1>), dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
+                        hipLaunchKernelGGL((pantr_alm_spec_kernel<M, 1, 1>), dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
                         return 0;
                     }
                 if (fixed_nj)
@@ -405,7 +405,7 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
             } else if (method == 0) {
                 if constexpr (HAS_SHORT)
                     if (short_horizon) {
-                        hipLaunchKernelGGL((pantr_alm_kernel<M, 0, ALM_NJ, 1>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+                        hipLaunchKernelGGL((pantr_alm_kernel<M, 0, 1, 1>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
                         return 0;
                     }
                 if (fixed_nj)
@@ -708,7 +708,9 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
     b->nj   = (b->n + WAVE - 1) / WAVE;
     // the quadcopter family up to n = 256: every lane owns ALM_NJ elements of every vector (padding included), a
     // compile-time constant of the PANTR kernels - their element-wise passes are straight-line code (Owned<NJ>)
-    if (id != ProblemId::HangingChain && b->nj <= ALM_NJ)
+    // (quadcopter up to ALM_SHORT_STAGES stages, n <= 64: one element per lane, the kernels for short horizons)
+    const bool short_quad = id == ProblemId::Quadcopter && horizon <= ALM_SHORT_STAGES;
+    if (id != ProblemId::HangingChain && b->nj <= ALM_NJ && !short_quad)
         b->nj = ALM_NJ;
     b->npad = b->nj * WAVE;
     b->mj   = (b->m + WAVE - 1) / WAVE;
@@ -744,7 +746,7 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
                               (const void *)&pantr_alm_kernel<QuadModelT<true>, 0, 0, 0>,
                               (const void *)&pantr_alm_kernel<QuadModelT<false>, 0, ALM_NJ, 0>,
                               (const void *)&pantr_alm_kernel<QuadModelT<true>, 0, ALM_NJ, 0>,
-                              (const void *)&pantr_alm_kernel<QuadModelT<false>, 0, ALM_NJ, 1>,
+                              (const void *)&pantr_alm_kernel<QuadModelT<false>, 0, 1, 1>,
                               (const void *)&pantr_alm_eval_kernel<QuadModelT<false>>,
                               (const void *)&pantr_alm_eval_kernel<QuadModelT<true>>})
             if (int rc = raise_dynamic_lds(k, b->lds_bytes))
@@ -754,7 +756,7 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
                                   (const void *)&pantr_alm_spec_kernel<QuadModelT<true>, 0, 0>,
                                   (const void *)&pantr_alm_spec_kernel<QuadModelT<false>, ALM_NJ, 0>,
                                   (const void *)&pantr_alm_spec_kernel<QuadModelT<true>, ALM_NJ, 0>,
-                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<false>, ALM_NJ, 1>})
+                                  (const void *)&pantr_alm_spec_kernel<QuadModelT<false>, 1, 1>})
                 if (int rc = raise_dynamic_lds(k, alm_spec_lds_bytes(*b)))
                     return rc;
         if (b->lds_bytes_cmp <= 160 * 1024) // else the comparators are refused at launch
@@ -1069,12 +1071,12 @@ const char *pantr_batch_kernel_name(const pantr_batch_t *b, int32_t B) {
         const bool fixed_nj = b->nj == ALM_NJ, short_horizon = !realistic && b->N <= ALM_SHORT_STAGES;
         if (use_alm_speculation(b, B)) {
             if (short_horizon)
-                return "pantr_alm_spec_kernel<QuadModelT<false>, 4, 1>";
+                return "pantr_alm_spec_kernel<QuadModelT<false>, 1, 1>";
             return realistic ? (fixed_nj ? "pantr_alm_spec_kernel<QuadModelT<true>, 4, 0>" : "pantr_alm_spec_kernel<QuadModelT<true>, 0, 0>")
                              : (fixed_nj ? "pantr_alm_spec_kernel<QuadModelT<false>, 4, 0>" : "pantr_alm_spec_kernel<QuadModelT<false>, 0, 0>");
         }
         if (method == 0 && short_horizon)
-            return "pantr_alm_kernel<QuadModelT<false>, 0, 4, 1>";
+            return "pantr_alm_kernel<QuadModelT<false>, 0, 1, 1>";
         if (method == 0 && fixed_nj)
             return realistic ? "pantr_alm_kernel<QuadModelT<true>, 0, 4, 0>" : "pantr_alm_kernel<QuadModelT<false>, 0, 4, 0>";
         return names[realistic ? 1 : 0][method];

@@ -509,7 +509,7 @@ def test_kernel_name_follows_method_speculation_and_batch_size():
     assert b.kernel_name() == "pantr_alm_kernel<QuadModelT<true>, 0, 4, 0>"
     b.close()
     b = pa.PantrBatch("quadcopter", 12, 2)
-    assert b.kernel_name() == "pantr_alm_spec_kernel<QuadModelT<false>, 4, 1>"      # up to 16 stages: the product for short horizons
+    assert b.kernel_name() == "pantr_alm_spec_kernel<QuadModelT<false>, 1, 1>"      # up to 16 stages: one element per lane, the product for short horizons
     b.close()
     b = pa.PantrBatch("quadcopter", 70, 2, opts=tuple(pa.DODO_PANTR_OPTS) + ("speculation=off",))
     assert b.kernel_name() == "pantr_alm_kernel<QuadModelT<false>, 0, 0, 0>"         # n = 280: the generic passes
