@@ -322,7 +322,12 @@ bool use_speculation(const pantr_batch *b, int32_t B) {
     if (b->opts.speculation == 1)
         return true;
     const size_t per_cu = std::min<size_t>(3, (160 * 1024) / wg_lds);
-    return (size_t)B <= per_cu * (size_t)b->num_cus;
+    // ... and while the launch does not load the memory system: a product streams its tape stage by stage, the
+    // two-wavefront kernel requests one stage ahead and the one-wavefront kernel two, which is what counts once
+    // many tapes stream at once - measured at N = 120: 256 instances 303 ms against 356, 512 instances 425 against 393
+    // (N = 60, 600 instances: 62 against 73).  The bound: instances x stages, per compute unit.
+    const size_t stage_streams = (size_t)B * (size_t)b->N;
+    return (size_t)B <= per_cu * (size_t)b->num_cus && stage_streams <= (size_t)176 * (size_t)b->num_cus;
 }
 
 /// `residency=k`: the dynamic LDS a launch asks for so that at most k workgroups fit the 160 KiB of a
