@@ -499,6 +499,10 @@ def test_kernel_name_follows_method_speculation_and_batch_size():
     lds_on, _ = b.footprint()
     b.close()
     assert lds_off == lds_auto < lds_on <= 160 * 1024 // 4   # (1024 instances: one wavefront each; four two-wavefront workgroups fit a CU)
+    b = pa.PantrBatch("hanging_chain", 120, 1024, opts=pa.DODO_PANTR_OPTS)
+    assert b.kernel_name(256) == "pantr_solve_spec_kernel<ChainModel, 6>"   # auto: two per CU would fit up to 512 instances ...
+    assert b.kernel_name(512) == "pantr_solve_kernel<ChainModel, 0, 6>"     # ... but 512 x 120 stages load the memory system
+    b.close()
     b = pa.PantrBatch("hanging_chain", 60, 8, opts=pa.DODO_OPTS["panoc"])
     assert b.kernel_name() == "pantr_solve_kernel<ChainModel, 1, 0>"
     b.close()
