@@ -242,6 +242,42 @@ int pantr_batch_mpc_record(pantr_batch_t *b, int32_t B, int32_t num_sim, int32_t
                            const double *x_init, const double *u_dist, double *states, double *inputs,
                            pantr_stats_t *stats, double *guesses_u, double *guesses_y, double *multipliers);
 
+/* ---- the reference's generated problem library as a cross-checker ---------------------------
+ * load_benchmark_casadi_problem (drivers/casadi-dll-wrapper.cpp:25-67) opens
+ * "<dir>/<name>_<formulation>_<N>.so", the C code alpaqa.casadi_generator.generate_casadi_problem
+ * emits (problems/generate_problem.py:55-61), through alpaqa::CasADiProblem / libcasadi.  The generated
+ * C has a calling convention of its own that needs neither (int f(const double **arg, double **res,
+ * long long *iw, double *w, int mem), f_work, f_n_in/out, f_sparsity_in/out; host/casadi_dll.hpp): these
+ * entry points open such a file on the HOST and evaluate its functions - to compare them with the device
+ * functions, never to solve with them.  No device is needed for open / function_info / call.
+ * Errors: the file cannot be opened -> PANTR_ERR_RUNTIME; a function it does not export ->
+ * PANTR_ERR_OUT_OF_RANGE (the reference: std::out_of_range, casadi-dll-wrapper.cpp:104-106); argument
+ * counts or sizes that do not fit -> PANTR_ERR_INVALID_ARGUMENT. */
+typedef struct pantr_casadi_dll pantr_casadi_dll_t;
+int pantr_casadi_dll_open(const char *so_path, pantr_casadi_dll_t **out);
+void pantr_casadi_dll_close(pantr_casadi_dll_t *d);
+/* Counts, sizes (nonzeros per input / output, -1 where the library exports no pattern; at most `cap`
+ * entries are written to each array) and work sizes {sz_arg, sz_res, sz_iw, sz_w} of function `name`. */
+int pantr_casadi_dll_function_info(pantr_casadi_dll_t *d, const char *name, int32_t *n_in, int32_t *n_out,
+                                   int64_t *nnz_in, int64_t *nnz_out, int32_t cap, int64_t work[4]);
+/* One call: args[n_in] (NULL entry = zeros), res[n_out] (NULL entry = output not wanted). */
+int pantr_casadi_dll_call(pantr_casadi_dll_t *d, const char *name, int32_t n_in, const double *const *args,
+                          int32_t n_out, double *const *res);
+
+/* Compare the generated library's psi, psi_grad_psi, hess_psi_prod and g with this handle's device
+ * functions on `samples` seeded points (x = u inside box C around the initial guess, p = the initial
+ * state perturbed, y, Sigma > 0 and v random, zl / zu = the handle's box D), inputs in the order
+ * formulation.hpp:88-97 builds them: (x, p, y, Sigma, [s = 1,] zl, zu[, v]); whether psi and
+ * psi_grad_psi take the scale s is read off their n_in.  max_rel_err[PANTR_DLL_CHECK_FIELDS] receives,
+ * per quantity, max over the samples of ||dll - device||_inf / max(||dll||_inf, 1e-300):
+ *   [0] psi (psi_grad_psi's value), [1] grad psi, [2] hess_psi_prod, [3] g, [4] yhat (psi's 2nd output);
+ * -1 where the library has no such function (first-order formulations carry no hess_psi_prod) or the
+ * problem no such quantity (m = 0: g, yhat).  The bar of BASELINE.json's north_star is 1e-10.
+ * A library generated for other sizes (n, m, nx from its sparsity patterns) is refused
+ * (PANTR_ERR_INVALID_ARGUMENT), not mis-fed. */
+#define PANTR_DLL_CHECK_FIELDS 5
+int pantr_batch_check_casadi_dll(pantr_batch_t *b, const char *so_path, int32_t samples, double *max_rel_err);
+
 /* ---- misc -------------------------------------------------------------------------------- */
 const char *pantr_last_error(void);
 /* Library name and version; any build switch that changes what is computed or reported is

@@ -4,6 +4,7 @@
 #include "../../include/pantr_mi355x.h"
 #include "../host/params.hpp"
 #include "../host/problem_data.hpp"
+#include "../host/casadi_dll.hpp"
 #include "chain_model.hip.h"
 #include "pantr_kernel.hip.h"
 #include "pantr_alm.hip.h"
@@ -17,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -1491,6 +1493,165 @@ int pantr_batch_mpc_record(pantr_batch_t *b, int32_t B, int32_t num_sim, int32_t
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     return PANTR_OK;
+}
+
+} // extern "C"
+
+// ---- the reference's generated problem library as a cross-checker (host/casadi_dll.hpp) ----------
+struct pantr_casadi_dll {
+    host::CasadiDll dll;
+    explicit pantr_casadi_dll(const char *path) : dll(path) {}
+};
+
+namespace {
+/// C++ exceptions of the loader -> the error codes of this ABI (the reference lets them propagate).
+template <class F>
+int dll_guard(F &&f) {
+    try {
+        return f();
+    } catch (const std::out_of_range &e) {
+        return fail(PANTR_ERR_OUT_OF_RANGE, e.what());
+    } catch (const std::invalid_argument &e) {
+        return fail(PANTR_ERR_INVALID_ARGUMENT, e.what());
+    } catch (const std::exception &e) {
+        return fail(PANTR_ERR_RUNTIME, e.what());
+    }
+}
+} // namespace
+
+extern "C" {
+
+int pantr_casadi_dll_open(const char *so_path, pantr_casadi_dll_t **out) {
+    if (!so_path || !out)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    return dll_guard([&] {
+        *out = new pantr_casadi_dll(so_path);
+        return PANTR_OK;
+    });
+}
+
+void pantr_casadi_dll_close(pantr_casadi_dll_t *d) { delete d; }
+
+int pantr_casadi_dll_function_info(pantr_casadi_dll_t *d, const char *name, int32_t *n_in, int32_t *n_out,
+                                   int64_t *nnz_in, int64_t *nnz_out, int32_t cap, int64_t work[4]) {
+    if (!d || !name)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    return dll_guard([&] {
+        host::CasadiFunction &f = d->dll.function(name);
+        if (n_in)
+            *n_in = (int32_t)f.n_in;
+        if (n_out)
+            *n_out = (int32_t)f.n_out;
+        for (int32_t i = 0; nnz_in && i < cap && i < f.n_in; ++i)
+            nnz_in[i] = f.nnz_in[i];
+        for (int32_t j = 0; nnz_out && j < cap && j < f.n_out; ++j)
+            nnz_out[j] = f.nnz_out[j];
+        if (work) {
+            work[0] = f.sz_arg; work[1] = f.sz_res; work[2] = f.sz_iw; work[3] = f.sz_w;
+        }
+        return PANTR_OK;
+    });
+}
+
+int pantr_casadi_dll_call(pantr_casadi_dll_t *d, const char *name, int32_t n_in, const double *const *args,
+                          int32_t n_out, double *const *res) {
+    if (!d || !name || (n_in > 0 && !args) || (n_out > 0 && !res) || n_in < 0 || n_out < 0)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    return dll_guard([&] {
+        d->dll.function(name).call(std::vector<const double *>(args, args + n_in),
+                                   std::vector<double *>(res, res + n_out));
+        return PANTR_OK;
+    });
+}
+
+int pantr_batch_check_casadi_dll(pantr_batch_t *b, const char *so_path, int32_t samples, double *max_rel_err) {
+    if (!b || !so_path || !max_rel_err)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null argument");
+    if (samples < 1)
+        return fail(PANTR_ERR_OUT_OF_RANGE, "samples must be >= 1");
+    return dll_guard([&]() -> int {
+        const int n = b->n, m = b->m, nx = b->nx;
+        host::CasadiProblemFunctions dll(so_path, n, m, nx); // refuses a library of other sizes
+        // ---- the sample points (fixed seed: the same points in every run) ----
+        std::vector<double> Clb(n), Cub(n), Dlb(std::max(m, 1)), Dub(std::max(m, 1));
+        pantr_batch_get_box_C(b, Clb.data(), Cub.data());
+        if (m > 0)
+            pantr_batch_get_box_D(b, Dlb.data(), Dub.data());
+        std::mt19937_64 rng(12345);
+        std::uniform_real_distribution<double> U(-1.0, 1.0);
+        const size_t S = (size_t)samples;
+        std::vector<double> X0(S * nx), Uv(S * n), V(S * n), Y(S * std::max(m, 1)), Sig(S * std::max(m, 1));
+        for (size_t s = 0; s < S; ++s) {
+            for (int l = 0; l < nx; ++l) // the initial state, perturbed (chain: well inside the spring lengths)
+                X0[s * nx + l] = b->x_init[l] + 0.02 * U(rng);
+            for (int i = 0; i < n; ++i) { // around the initial guess, inside box C
+                const double lo = std::isfinite(Clb[i]) ? Clb[i] : b->u_guess[i] - 1.0,
+                             hi = std::isfinite(Cub[i]) ? Cub[i] : b->u_guess[i] + 1.0;
+                const double x = b->u_guess[i] + 0.3 * (hi - lo) * U(rng);
+                Uv[s * n + i]  = std::fmin(std::fmax(x, lo), hi);
+                V[s * n + i]   = U(rng);
+            }
+            for (int j = 0; j < m; ++j) {
+                Y[s * m + j]   = U(rng);
+                Sig[s * m + j] = 1.0 + 49.5 * (1.0 + U(rng)); // 1 .. 100
+            }
+        }
+        // ---- the device side, in chunks of the handle's batch size ----
+        std::vector<double> psi_d(S), grad_d(S * n), Hv_d(S * n), g_d(S * std::max(m, 1)), yhat_d(S * std::max(m, 1));
+        for (size_t s0 = 0; s0 < S; s0 += (size_t)b->maxB) {
+            const int32_t B = (int32_t)std::min<size_t>(b->maxB, S - s0);
+            const double *x0 = &X0[s0 * nx], *u = &Uv[s0 * n], *v = &V[s0 * n];
+            int rc;
+            if (m == 0) {
+                if ((rc = pantr_batch_eval_psi_grad_psi(b, B, x0, u, &psi_d[s0], &grad_d[s0 * n])) ||
+                    (rc = pantr_batch_eval_hess_psi_prod(b, B, x0, u, v, &Hv_d[s0 * n])))
+                    return rc;
+            } else {
+                const double *y = &Y[s0 * m], *sg = &Sig[s0 * m];
+                if ((rc = pantr_batch_eval_psi_grad_psi_al(b, B, x0, u, y, sg, &psi_d[s0], &grad_d[s0 * n], &yhat_d[s0 * m])) ||
+                    (rc = pantr_batch_eval_hess_psi_prod_al(b, B, x0, u, y, sg, v, &Hv_d[s0 * n])) ||
+                    (rc = pantr_batch_eval_g(b, B, x0, u, &g_d[s0 * m])))
+                    return rc;
+            }
+        }
+        // ---- the generated library, point by point ----
+        auto rel = [](const double *ref, const double *got, int len) {
+            double num = 0, den = 0;
+            for (int i = 0; i < len; ++i) {
+                const double d = std::fabs(ref[i] - got[i]);
+                num = d > num || d != d ? d : num; // (a NaN on either side is an error of NaN)
+                den = std::fmax(den, std::fabs(ref[i]));
+            }
+            return num / std::fmax(den, 1e-300);
+        };
+        double err[PANTR_DLL_CHECK_FIELDS] = {0, 0, dll.has_hess_psi_prod() ? 0.0 : -1.0,
+                                              (m > 0 && dll.has_g()) ? 0.0 : -1.0, m > 0 ? 0.0 : -1.0};
+        auto worst = [](double &acc, double e) { acc = (e > acc || e != e) ? e : acc; };
+        std::vector<double> grad(n), Hv(n), g(std::max(m, 1)), yhat(std::max(m, 1));
+        for (size_t s = 0; s < S; ++s) {
+            const double *x = &Uv[s * n], *p = &X0[s * nx], *y = m ? &Y[s * m] : nullptr, *sg = m ? &Sig[s * m] : nullptr,
+                         *zl = m ? Dlb.data() : nullptr, *zu = m ? Dub.data() : nullptr;
+            const double psi = dll.eval_psi_grad_psi(x, p, y, sg, zl, zu, grad.data());
+            worst(err[0], rel(&psi, &psi_d[s], 1));
+            worst(err[1], rel(grad.data(), &grad_d[s * n], n));
+            if (dll.has_hess_psi_prod()) {
+                dll.eval_hess_psi_prod(x, p, y, sg, 1.0, zl, zu, &V[s * n], Hv.data());
+                worst(err[2], rel(Hv.data(), &Hv_d[s * n], n));
+            }
+            if (m > 0) {
+                if (dll.has_g()) {
+                    dll.eval_g(x, p, g.data());
+                    worst(err[3], rel(g.data(), &g_d[s * m], m));
+                }
+            }
+            const double psi2 = dll.eval_psi(x, p, y, sg, zl, zu, m ? yhat.data() : nullptr);
+            worst(err[0], rel(&psi2, &psi_d[s], 1));
+            if (m > 0)
+                worst(err[4], rel(yhat.data(), &yhat_d[s * m], m));
+        }
+        std::copy(err, err + PANTR_DLL_CHECK_FIELDS, max_rel_err);
+        return PANTR_OK;
+    });
 }
 
 } // extern "C"

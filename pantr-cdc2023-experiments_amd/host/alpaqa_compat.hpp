@@ -17,8 +17,11 @@
 #include "../../include/pantr_mi355x.h"
 #include "params.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <iostream>
 #include <memory>
 #include <ostream>
 #include <span>
@@ -303,6 +306,67 @@ class PANOCSolver {
     Direction direction;
 };
 
+/// solver.print_interval (mpc-driver.cpp:52): the per-iteration values alpaqa's solvers print while they run -
+/// here the rows of the device trace (pantr_batch_get_trace), printed after the solve in a fixed table, every
+/// `interval`-th iteration and the last one.  One row per iteration k, the values AT THE START of iteration k
+/// (eps, psi, ||p||, gamma, phi_gamma of the current iterate) and of the step taken in it (|J|, CG iterations,
+/// q_model, rho, accepted / rejected, the radius after its update) - the quantities alpaqa's PANTR progress
+/// lines show (phi_gamma, psi, ||p||, gamma, Delta, eps; ||q|| and ||grad psi|| are not traced), so a reference
+/// run with the same print_interval can be laid next to this one iteration by iteration.
+/// `rows`: [cap][11] doubles (include/pantr_mi355x.h); a row never written has gamma = 0.
+inline void print_iterates(std::ostream &os, bool pantr, const double *rows, int cap, int interval, int precision,
+                           const char *note, const pantr_stats_t &stats) {
+    int count = 0;
+    while (count < cap && rows[(size_t)count * 11 + 3] != 0)
+        ++count;
+    const int w = precision + 8;
+    auto num = [&](double v) {
+        char buf[64];
+        std::snprintf(buf, sizeof buf, "%+*.*e", w, precision, v);
+        return std::string(buf);
+    };
+    auto head = [&](const char *h) {
+        char buf[64];
+        std::snprintf(buf, sizeof buf, "%*s", w, h);
+        return std::string(buf);
+    };
+    const char *tag = pantr ? "[PANTR] " : "[PANOC] ";
+    os << tag << "  iter " << head("phi_gamma") << ' ' << head("psi") << ' ' << head("||p||") << ' ' << head("gamma")
+       << ' ' << head("eps");
+    if (pantr)
+        os << ' ' << head("Delta") << ' ' << head("rho") << ' ' << head("q_model") << "  |J|   cg";
+    else
+        os << ' ' << head("tau") << " lbfgs";
+    os << (note ? note : "") << '\n';
+    for (int k = 0; k < count; ++k) {
+        if (k % interval != 0 && k != count - 1)
+            continue;
+        const double *r = rows + (size_t)k * 11;
+        char it[16];
+        std::snprintf(it, sizeof it, "%6d ", k);
+        os << tag << it << num(pantr ? r[7] : r[5]) << ' ' << num(r[1]) << ' ' << num(r[2]) << ' ' << num(r[3]) << ' '
+           << num(r[0]);
+        if (pantr) {
+            char jc[32];
+            std::snprintf(jc, sizeof jc, " %4d %4d", (int)r[8], (int)r[9]);
+            os << ' ' << num(r[4]) << ' ' << num(r[5]) << ' ' << num(r[6]) << jc
+               << (r[10] != 0 ? "  accepted" : "  rejected");
+        } else {
+            char lb[32];
+            std::snprintf(lb, sizeof lb, " %5d", (int)r[6]);
+            os << ' ' << num(r[4]) << lb;
+        }
+        os << '\n';
+    }
+    if (count == cap)
+        os << tag << "(trace full: " << cap << " iterations kept)\n";
+    // the exit: the iterate the stop criterion accepted takes no step and has no row
+    os << tag << "  exit " << enum_name(static_cast<SolverStatus>(stats.status)) << " after " << stats.iterations
+       << " iterations" << (note ? " (all inner solves)" : "") << ", eps = " << num(stats.eps) << ", psi = "
+       << num(stats.final_psi) << ", gamma = " << num(stats.final_gamma) << '\n';
+    os.flush();
+}
+
 template <class InnerSolverT>
 class ALMSolver {
   public:
@@ -327,7 +391,21 @@ class ALMSolver {
             throw std::invalid_argument("ALMSolver: y has the wrong dimension");
         push_options(problem.get());
         pantr_stats_t s{};
+        // solver.print_interval: trace this solve on the device and print its rows afterwards (print_iterates)
+        const int interval = inner_solver.params.print_interval;
+        const int cap      = interval > 0 ? std::min<int>(inner_solver.params.max_iter, 100000) + 1 : 0;
+        if (interval > 0)
+            check(pantr_batch_set_trace(problem.get(), 1, cap)); // (also clears the rows of the solve before)
         check(pantr_batch_solve(problem.get(), 1, problem.param.data(), x.data(), y.data(), &s));
+        if (interval > 0) {
+            std::vector<double> rows((size_t)cap * 11);
+            check(pantr_batch_get_trace(problem.get(), rows.data()));
+            pantr::host::SolverOptions o;
+            inner_solver.to_options(o);
+            print_iterates(std::cout, o.method == pantr::host::Method::PANTR, rows.data(), cap, interval,
+                           inner_solver.params.print_precision,
+                           problem.get_m() > 0 ? "   (first inner solve of the ALM)" : nullptr, s);
+        }
         problem.evaluations->add(s);
         return convert(s);
     }

@@ -9,7 +9,9 @@
 // GPU (batch of one instance per MPC step, since step i+1 depends on step i).  Extension:
 // `replay=true` re-solves all recorded steps of the finished closed loop as ONE batch and checks
 // that the batched solutions equal the sequential ones (the replay batching of BASELINE.json
-// configs[1]); `device=<k>` picks the GPU.
+// configs[1]); `device=<k>` picks the GPU; `check_dll=true` compares the generated problem library
+// next to <path> with the device functions before solving; `solver.print_interval=<k>` (mpc-driver.cpp:52)
+// prints every k-th iterate of each solve from the device trace.
 #include "alpaqa_compat.hpp"
 #include "results.hpp"
 
@@ -186,6 +188,35 @@ int main(int argc, char *argv[]) try {
                           ? Problem{Problem::FromFiles{}, path.string(), formulation, horizon, instances,
                                     static_cast<int>(device)}
                           : Problem{name, horizon, instances, static_cast<int>(device)};
+
+    // check_dll=true: the reference's generated problem library `<dir>/<name>_<formulation>_<N>.so`
+    // (casadi-dll-wrapper.cpp:29-31) is opened on the host through the generated code's own C convention and its
+    // psi / psi_grad_psi / hess_psi_prod / g are compared with the device functions this driver solves with
+    // (pantr_batch_check_casadi_dll; bar 1e-10, BASELINE.json north_star).  The library is never solved with.
+    bool check_dll = false;
+    alpaqa::params::set_params(check_dll, "check_dll", extra_opts);
+    if (check_dll) {
+        length_t samples = 8;
+        alpaqa::params::set_params(samples, "check_dll_samples", extra_opts);
+        double err[PANTR_DLL_CHECK_FIELDS];
+        alpaqa::check(pantr_batch_check_casadi_dll(problem.get(), full_path.c_str(), static_cast<int32_t>(samples), err));
+        static const char *names[PANTR_DLL_CHECK_FIELDS] = {"psi", "grad_psi", "hess_psi_prod", "g", "yhat"};
+        bool ok = true;
+        std::cout << "check_dll: " << full_path.string() << " against the device functions, " << samples
+                  << " points, max relative difference\n";
+        for (int i = 0; i < PANTR_DLL_CHECK_FIELDS; ++i) {
+            std::cout << "check_dll:   " << names[i] << std::string(14 - std::string(names[i]).size(), ' ');
+            if (err[i] == -1.0)
+                std::cout << "(not in this library / problem)\n";
+            else
+                std::cout << err[i] << (err[i] <= 1e-10 ? "" : "   > 1e-10") << '\n';
+            ok = ok && (err[i] == -1.0 || err[i] <= 1e-10);
+        }
+        std::cout << "check_dll: the generated functions and the device functions "
+                  << (ok ? "agree to 1e-10" : "DIFFER") << std::endl;
+        if (!ok)
+            throw std::runtime_error("check_dll: the generated functions and the device functions DIFFER");
+    }
 
     std::string_view solver_name = "fbetrust"; // mpc-driver.cpp:359
     alpaqa::params::set_params(solver_name, "method", extra_opts);

@@ -98,6 +98,8 @@ EXPORTS = (
     "pantr_problem_data_get", "pantr_problem_dims", "pantr_problem_defaults", "pantr_batch_eval_g",
     "pantr_batch_mpc_record", "pantr_device_copy_bandwidth", "pantr_source_hash", "pantr_stats_size",
     "pantr_batch_kernel_name",
+    "pantr_casadi_dll_open", "pantr_casadi_dll_close", "pantr_casadi_dll_function_info", "pantr_casadi_dll_call",
+    "pantr_batch_check_casadi_dll",
 )
 
 
@@ -182,6 +184,12 @@ def lib():
         L.pantr_problem_data_get.argtypes = [vp, C.POINTER(_i32), vp, vp, vp, vp, vp, vp, C.POINTER(_i32)]
         L.pantr_problem_dims.argtypes = [cp, _i32] + [C.POINTER(_i32)] * 6
         L.pantr_problem_defaults.argtypes = [cp, _i32, vp, vp, vp, vp, vp, vp]
+        L.pantr_casadi_dll_open.argtypes = [cp, C.POINTER(vp)]
+        L.pantr_casadi_dll_close.argtypes = [vp]
+        L.pantr_casadi_dll_close.restype = None
+        L.pantr_casadi_dll_function_info.argtypes = [vp, cp, C.POINTER(_i32), C.POINTER(_i32), vp, vp, _i32, vp]
+        L.pantr_casadi_dll_call.argtypes = [vp, cp, _i32, vp, _i32, vp]
+        L.pantr_batch_check_casadi_dll.argtypes = [vp, cp, _i32, vp]
         _lib = L
     return _lib
 
@@ -285,6 +293,45 @@ def load_problem_files(path, formulation, horizon):
         lib().pantr_problem_data_destroy(h)
 
 
+DLL_CHECK_FIELDS = ("psi", "grad_psi", "hess_psi_prod", "g", "yhat")
+
+
+class CasadiDll:
+    """A CasADi-generated problem library "<dir>/<name>_<formulation>_<N>.so" (what
+    drivers/casadi-dll-wrapper.cpp:25-67 loads through alpaqa::CasADiProblem), opened on the host through
+    the generated code's own C convention (host/casadi_dll.hpp).  A cross-checker of the device functions
+    (PantrBatch.check_casadi_dll), never part of a solve.  No device needed."""
+
+    def __init__(self, so_path):
+        self._h = C.c_void_p()
+        _check(lib().pantr_casadi_dll_open(os.fspath(so_path).encode(), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pantr_casadi_dll_close(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def function_info(self, name, cap=16):
+        """dict(n_in, n_out, nnz_in, nnz_out, work=(sz_arg, sz_res, sz_iw, sz_w)) of a generated function."""
+        n_in, n_out = _i32(), _i32()
+        nnz_in, nnz_out, work = np.full(cap, -2, np.int64), np.full(cap, -2, np.int64), np.zeros(4, np.int64)
+        _check(lib().pantr_casadi_dll_function_info(self._h, name.encode(), C.byref(n_in), C.byref(n_out),
+                                                    _ptr(nnz_in), _ptr(nnz_out), cap, _ptr(work)))
+        return dict(n_in=n_in.value, n_out=n_out.value, nnz_in=nnz_in[:n_in.value].tolist(),
+                    nnz_out=nnz_out[:n_out.value].tolist(), work=tuple(int(w) for w in work))
+
+    def call(self, name, args, out_sizes):
+        """Evaluate `name` at `args` (arrays or scalars; None = zeros); returns the outputs as arrays."""
+        ins = [None if a is None else np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64) for a in args]
+        outs = [np.zeros(max(int(k), 1)) for k in out_sizes]
+        pa = (C.c_void_p * max(len(ins), 1))(*[None if a is None or a.size == 0 else a.ctypes.data for a in ins])
+        pr = (C.c_void_p * max(len(outs), 1))(*[o.ctypes.data for o in outs])
+        _check(lib().pantr_casadi_dll_call(self._h, name.encode(), len(ins), pa, len(outs), pr))
+        return [o[:int(k)] for o, k in zip(outs, out_sizes)]
+
+
 class PantrBatch:
     """A problem (name, horizon) with device resources for up to max_instances solves."""
 
@@ -324,6 +371,14 @@ class PantrBatch:
         v = _dbl()
         _check(lib().pantr_batch_get_param(self._h, key.encode(), C.byref(v)))
         return v.value
+
+    def check_casadi_dll(self, so_path, samples=8):
+        """Compare the generated library's psi / psi_grad_psi / hess_psi_prod / g with this handle's device
+        functions on `samples` seeded points (pantr_batch_check_casadi_dll): dict quantity -> max relative
+        error (None where the library or the problem has no such quantity).  The bar is 1e-10."""
+        err = np.zeros(len(DLL_CHECK_FIELDS))
+        _check(lib().pantr_batch_check_casadi_dll(self._h, os.fspath(so_path).encode(), samples, _ptr(err)))
+        return {k: (None if e == -1.0 else float(e)) for k, e in zip(DLL_CHECK_FIELDS, err)}
 
     # ---- problem data --------------------------------------------------------------------
     def box_C(self):

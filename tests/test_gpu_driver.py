@@ -190,3 +190,49 @@ def test_driver_uses_sidecar_files_next_to_the_problem_path(tmp_path):
     assert np.array_equal(res["inputs"].T, inputs[:, 0]) and np.array_equal(res["states"].T, states[:, 0])
     assert np.all(np.abs(inputs[:, 0]) <= bound) and np.any(np.abs(inputs[:, 0]) == bound)
     assert np.all(res["runtimes"] > 0)
+
+
+def test_driver_print_interval_prints_the_device_iterates(tmp_path):
+    """solver.print_interval=k (mpc-driver.cpp:52): the rows of the device trace in a fixed table, one line per
+    k-th iteration (and the last) of every solve; at full precision they are the oracle's per-iteration trace."""
+    import common
+    N = 10
+    opts = list(pa.DODO_PANTR_OPTS) + list(pa.DODO_HANGING_CHAIN_OPTS)
+    cmd = [DRIVER, "hanging_chain", str(N), "ss2p", "method=pantr", "num_sim=1", "results_name=r",
+           "solver.print_precision=16"] + opts
+
+    def tables(stdout):
+        out, cur = [], None
+        for ln in stdout.splitlines():
+            if not ln.startswith("[PANTR]"):
+                continue
+            f = ln.split()
+            if f[1] == "iter":
+                cur = []
+                out.append(cur)
+            elif f[1] == "exit":
+                cur.append(("exit", f[2], int(f[4])))
+            else:
+                cur.append((int(f[1]), [float(x) for x in f[2:10]], int(f[10]), int(f[11]), f[12]))
+        return out
+
+    r = subprocess.run(cmd + ["solver.print_interval=1"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    t = tables(r.stdout)
+    assert len(t) == 2                                          # the untimed first solve (:158) and the one MPC step
+    x0 = common.disturbed_state()
+    _, st, tr = ob.solve(N, x0, np.zeros(3 * N), trace_cap=500)
+    rows, last = t[0][:-1], t[0][-1]
+    assert last == ("exit", "Converged", st["iterations"]) and len(rows) == st["iterations"] == len(tr)
+    for (k, v, nJ, cg, acc), o in zip(rows, tr):
+        # table: phi_gamma psi ||p|| gamma eps Delta rho q_model | trace: eps psi pnorm gamma radius rho q_model fbe nJ cg accepted
+        want = [o[7], o[1], o[2], o[3], o[0], o[4], o[5], o[6]]
+        assert np.array_equal(np.array(v), np.array(want), equal_nan=True), (k, v, want)
+        assert (nJ, cg, acc) == (int(o[8]), int(o[9]), "accepted" if o[10] else "rejected")
+    assert [row[0] for row in rows] == list(range(len(rows)))
+    r = subprocess.run(cmd + ["solver.print_interval=4"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    its = [row[0] for row in tables(r.stdout)[0][:-1]]
+    assert its == sorted(set(list(range(0, len(rows), 4)) + [len(rows) - 1]))
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=300)   # default 0: silent
+    assert r.returncode == 0 and "[PANTR]" not in r.stdout
