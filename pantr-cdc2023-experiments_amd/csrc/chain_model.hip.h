@@ -303,11 +303,13 @@ struct ChainModel {
     /// write each (wave_math.hip.h, lds_dma_rows) - the sweeps that wait for their rows with explicit vmcnt counts
     /// (two stages ahead) use these; the one-stage-ahead sweeps keep the builtin form, whose transfers the
     /// compiler schedules among the stage's other instructions.
+    static constexpr int FWD_ROW_TRANSFERS = 2; ///< vector-memory operations of prefetch_fwd (the K rows: 2 KiB)
+    static constexpr int REV_ROW_TRANSFERS = 6; ///< of prefetch_rev_xt (K, M: 4; d_t rows: 1; tangent-state row: 1)
     template <bool GROUP = false>
     __device__ static __forceinline__ void prefetch_fwd(const Lane &L, const double4 *tape_stage, char *buf) {
         const char *src = reinterpret_cast<const char *>(tape_stage) + L.l * 16;
         if constexpr (GROUP) {
-            lds_dma_rows<2>(src, buf);
+            lds_dma_rows<FWD_ROW_TRANSFERS>(src, buf);
         } else {
             lds_dma_row<0>(src, buf);
             lds_dma_row<1024>(src, buf);
@@ -351,6 +353,7 @@ struct ChainModel {
     static constexpr int LDS_STAGE_BYTES_XT = LDS_STAGE_BYTES + XT_DOUBLES * 8;
     __device__ static __forceinline__ void prefetch_rev_xt(const Lane &L, const double4 *tape_stage, const double4 *st_stage,
                                                            const double *xt_row, char *buf) {
+        static_assert(REV_ROW_TRANSFERS == 4 + 1 + 1, "prefetch_rev<true>: lds_dma_rows<4> + lds_dma_rows<1>; then one lds_dma_256");
         prefetch_rev<true>(L, tape_stage, st_stage, buf);
         lds_dma_256(reinterpret_cast<const char *>(xt_row) + L.l * 4, buf + LDS_STAGE_BYTES);
     }
@@ -471,6 +474,165 @@ struct ChainModel {
         fc_adj_tan2(L, buf, 1, 0, kbv2, kbv1, xs, G2, G1);
         const double kbx1 = __builtin_fma(hTs, G2, sgx);
         const double m1   = L.mass_l * kbx1;
+        sbar_t = {(((mu_t.x + G4) + G3) + G2) + G1, (((mu_t.v + m4) + m3) + m2) + m1};
+        ubar_t = ((sgx + kbx3) + kbx2) + kbx1;
+    }
+
+    // ---- the tangent sweeps with both substage chains SIDE BY SIDE (round 5) ---------------------------------
+    // A lone wavefront is bound by the instructions it issues (5-6 cycles each), and the
+    // instructions above use 30 of their 64 lanes.  The two independent substage chains of a stage - forward
+    // (1, 3) and (2, 4), adjoint (3, 1) and (4, 2) - are the same program on different data, so here the lower
+    // half of the wavefront evaluates one chain and the upper half the other WITH THE SAME INSTRUCTIONS:
+    //     lane = 32 chain + 10 component + point            (lanes 30, 31 of a half idle)
+    // Within a half the ten points of a component are contiguous, so the neighbouring point is the neighbouring
+    // lane of the wavefront (DPP wave_shr:1 / wave_shl:1); what lies beyond a component's ends - the anchor
+    // before point 0, the lane after the end point - is masked by a lane constant inside an fma, which leaves
+    // the arithmetic as it is (fma(-1, b, a) is a - b in one rounding; fma(-0, b, a) is a for finite b).  The
+    // components of a point are 10 lanes apart: gathered through an LDS row (one write, three reads; a lone
+    // chain has nothing to fill a gather's latency with, and ds_bpermute is no faster:
+    // scripts/microbench/hv_pair_ab.hip).  Both halves carry the full tangent state; once per stage they
+    // exchange their two accelerations (adjoint: their two G) with v_permlane32_swap and form the Runge-Kutta
+    // combination by the expressions of rk4_tan / rk4_adj_tan above.  Same operations on the same operands:
+    // same bits (the microbenchmark compares the two forms; the parity tests run this one).  Per stage
+    // 528 + 750 cycles against 711 + 949 for the interleaved form on a lone wavefront; two WAVEFRONTS with one
+    // chain each lose (730 + 1033: an exchange through LDS and s_barrier costs 200 cycles a stage).
+    struct PairLane {
+        int l, h, c, p, q; ///< lane, chain (half), component, point, compact slot 3p+c (idle lanes: 31)
+        bool active, mass, end, hi;
+        double inv_m_l, mass_l, nend_l, nfirst_l; ///< nfirst_l: 0 on point 0 (and idle lanes), 1 elsewhere
+        int k_off;  ///< byte offset in a landing buffer of this lane's spring block in the K row of the chain's FIRST forward substage
+        int e8[DIM]; ///< byte offsets of the three entries of row c inside a spring block
+        int st_off; ///< byte offset in a tangent-tape stage of this lane's d_t slot, first forward substage (the second: + 512)
+        int dt_off; ///< byte offset in a landing buffer of this point's d_t triple, first ADJOINT substage (the second: - 512)
+        int xs_w, xs_r; ///< doubles: own slot / first component of the point in the exchange row of this half
+        __device__ explicit PairLane(int lane) {
+            l  = lane;
+            h  = lane >> 5;
+            hi = h != 0;
+            const int r = lane & 31;
+            active = r < DIM * NP;
+            c      = active ? r / NP : 0;
+            p      = active ? r % NP : NB;
+            mass   = active && p < NB;
+            end    = active && p == NB;
+            inv_m_l  = mass ? inv_m : 0.0;
+            mass_l   = mass ? 1.0 : 0.0;
+            nend_l   = end ? 0.0 : 1.0;
+            nfirst_l = (active && p > 0) ? 1.0 : 0.0;
+            q        = active ? DIM * p + c : 31;
+            // forward substages (0-based): first = h, second = 2 + h; adjoint: first = 2 + h, second = h
+            k_off = h * 512 + spring_base(p) * 8;
+            for (int k = 0; k < DIM; ++k)
+                e8[k] = sym(c, k) * 8;
+            st_off = h * 256 + q * 8;
+            dt_off = TAPE_STAGE_BYTES + (2 + h) * 256 + DIM * p * 8;
+            xs_w   = 32 * h + q;
+            xs_r   = 32 * h + DIM * p;
+        }
+    };
+    static constexpr int PAIR_XS_DOUBLES = 64; ///< exchange rows of the pair gather: 32 doubles per half
+    /// st stores of a forward stage: one per substage PAIR (each stores both chains' d_t)
+    static constexpr int PAIR_ST_STORES_PER_STAGE = 2;
+    __device__ static __forceinline__ double lane_above(double v) { return dpp_move<0x130>(v); } // wave_shl:1
+    __device__ static __forceinline__ double lds_at(const char *base, int off) {
+        return *reinterpret_cast<const double *>(base + off);
+    }
+    __device__ static __forceinline__ Comps comps_pair(const PairLane &L, double v, double *xs) {
+        xs[L.xs_w] = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double *s = xs + L.xs_r;
+        return {s[0], s[1], s[2]};
+    }
+    __device__ static __forceinline__ double load_input(const PairLane &L, const double *u_k) { return u_k[L.c]; }
+    __device__ static __forceinline__ void store_input_grad(const PairLane &L, double *g_k, double g) {
+        if (L.end && !L.hi)
+            g_k[L.c] = g;
+    }
+    /// (both halves store the same value to the same slot)
+    __device__ static __forceinline__ void xt_store(const PairLane &L, double *row, const State &s_t) {
+        row[L.q] = L.end ? s_t.x : s_t.v;
+    }
+    __device__ static __forceinline__ double xt_load(const PairLane &L, const double *row) { return row[L.q]; }
+    __device__ static __forceinline__ double xt_lds(const PairLane &L, const char *buf) {
+        return reinterpret_cast<const double *>(buf + LDS_STAGE_BYTES)[L.q];
+    }
+    __device__ static __forceinline__ void cost_grad_x_add_tan(const PairLane &L, double xt, State &lam_t) {
+        lam_t.x = L.end ? __builtin_fma(c2a, xt, lam_t.x) : lam_t.x;
+        lam_t.v = L.mass ? __builtin_fma(c2b, xt, lam_t.v) : lam_t.v;
+    }
+    /// fc_tan2's expressions, one substage of each chain: K at buf + koff (+ e8[.]), d_t to st_stage + st_off.
+    __device__ static __forceinline__ double fc_tan_pair(const PairLane &L, const char *buf, int koff, int st_off, double x,
+                                                         char *st_stage, double *xs) {
+        const double d = __builtin_fma(-L.nfirst_l, lane_below(x), x); // x - prev (point 0: the anchor at the origin)
+        *reinterpret_cast<double *>(st_stage + st_off) = d;            // idle lanes: slot 31
+        const char *kb = buf + koff;
+        const double K0 = lds_at(kb, L.e8[0]), K1 = lds_at(kb, L.e8[1]), K2 = lds_at(kb, L.e8[2]);
+        const Comps c = comps_pair(L, d, xs);
+        double F = K0 * c.c0;
+        F        = __builtin_fma(K1, c.c1, F);
+        F        = __builtin_fma(K2, c.c2, F);
+        return L.inv_m_l * (lane_above(F) - F);
+    }
+    /// fc_adj_tan2's expressions, one substage of each chain.
+    __device__ static __forceinline__ double fc_adj_tan_pair(const PairLane &L, const char *buf, int koff, int dt_off, double kv,
+                                                             double *xs) {
+        const double lF = inv_m * (L.nfirst_l * lane_below(kv) - kv);
+        const char *kb = buf + koff;
+        const double K0 = lds_at(kb, L.e8[0]), K1 = lds_at(kb, L.e8[1]), K2 = lds_at(kb, L.e8[2]);
+        const double M0 = lds_at(kb, 2048 + L.e8[0]), M1 = lds_at(kb, 2048 + L.e8[1]), M2 = lds_at(kb, 2048 + L.e8[2]);
+        const double D0 = lds_at(buf, dt_off), D1 = lds_at(buf, dt_off + 8), D2 = lds_at(buf, dt_off + 16);
+        const Comps c = comps_pair(L, lF, xs);
+        double ld = K0 * c.c0;
+        ld        = __builtin_fma(K1, c.c1, ld);
+        ld        = __builtin_fma(K2, c.c2, ld);
+        ld        = __builtin_fma(M0, D0, ld);
+        ld        = __builtin_fma(M1, D1, ld);
+        ld        = __builtin_fma(M2, D2, ld);
+        return __builtin_fma(-L.nend_l, lane_above(ld), ld);
+    }
+    /// rk4_tan with the chains side by side: the lower half evaluates substages (1, 3), the upper (2, 4).
+    __device__ static __forceinline__ State rk4_tan(const PairLane &L, const char *buf, const State &s_in, double uc_t,
+                                                    double4 *st_stage, double *xs) {
+        char *st = reinterpret_cast<char *>(st_stage);
+        const double x = s_in.x, v = L.end ? uc_t : s_in.v;
+        const double x2  = __builtin_fma(hTs, v, x);
+        const double af  = fc_tan_pair(L, buf, L.k_off, L.st_off, L.hi ? x2 : x, st, xs);             // a1 | a2
+        const double kxf = __builtin_fma(hTs, af, v);                                                 // kx2 | kx3
+        const double xs2 = __builtin_fma(L.hi ? Ts : hTs, kxf, x);                                    // x3 | x4
+        const double as  = fc_tan_pair(L, buf, L.k_off + 1024, L.st_off + 512, xs2, st, xs);          // a3 | a4
+        double a1, a2, a3, a4;
+        row_partner<true>(af, a1, a2); // the lower half's and the upper half's value, on every lane
+        row_partner<true>(as, a3, a4);
+        const double kx2 = __builtin_fma(hTs, a1, v), kx3 = __builtin_fma(hTs, a2, v);
+        const double kx4 = __builtin_fma(Ts, a3, v);
+        double tx = __builtin_fma(2.0, kx2, v), tv = __builtin_fma(2.0, a2, a1);
+        tx        = __builtin_fma(2.0, kx3, tx);
+        tv        = __builtin_fma(2.0, a3, tv);
+        tx        = tx + kx4;
+        tv        = tv + a4;
+        return {__builtin_fma(c6, tx, x), __builtin_fma(c6, tv, v)};
+    }
+    /// rk4_adj_tan with the chains side by side: the lower half evaluates substages (3, 1), the upper (4, 2) - each
+    /// half meets the d_t it stored in the forward sweep.
+    __device__ static __forceinline__ void rk4_adj_tan(const PairLane &L, const char *buf, const State &mu_t, State &sbar_t,
+                                                       double &ubar_t, double *xs) {
+        const double sgx = c6 * mu_t.x, sgv = c6 * mu_t.v;
+        const double sgx2 = 2.0 * sgx, sgv2 = 2.0 * sgv;
+        const double m4   = L.mass_l * sgx;
+        const double kbv3 = __builtin_fma(Ts, m4, sgv2);
+        const double Gf   = fc_adj_tan_pair(L, buf, L.k_off + 1024, L.dt_off, L.hi ? sgv : kbv3, xs); // G3 | G4
+        const double kbx  = __builtin_fma(L.hi ? Ts : hTs, Gf, sgx2);                                 // kbx2 | kbx3
+        const double mm   = L.mass_l * kbx;
+        const double kvs  = __builtin_fma(hTs, mm, L.hi ? sgv2 : sgv);                                // kbv1 | kbv2
+        const double Gs   = fc_adj_tan_pair(L, buf, L.k_off, L.dt_off - 512, kvs, xs);                // G1 | G2
+        double G3, G4, G1, G2;
+        row_partner<true>(Gf, G3, G4);
+        row_partner<true>(Gs, G1, G2);
+        const double kbx3 = __builtin_fma(Ts, G4, sgx2), kbx2 = __builtin_fma(hTs, G3, sgx2);
+        const double kbx1 = __builtin_fma(hTs, G2, sgx);
+        const double m3 = L.mass_l * kbx3, m2 = L.mass_l * kbx2, m1 = L.mass_l * kbx1;
         sbar_t = {(((mu_t.x + G4) + G3) + G2) + G1, (((mu_t.v + m4) + m3) + m2) + m1};
         ubar_t = ((sgx + kbx3) + kbx2) + kbx1;
     }

@@ -312,7 +312,7 @@ struct WaveProblem {
     static constexpr int HELPER_SLOTS = S_GSTAGE + 1;
     __device__ __forceinline__ double *vec(int slot) const { return lds + slot * npad; }
     /// Exchange row of the component gather: XS_DOUBLES doubles of dynamic LDS behind the kernel's vectors.
-    static constexpr int XS_DOUBLES = 32;
+    static constexpr int XS_DOUBLES = M::PAIR_XS_DOUBLES; // 32 doubles per half of the wavefront (comps_pair)
     double *xrow = nullptr;
     const double *lbv = nullptr, *ubv = nullptr; ///< HBM, shared by the batch: box C as n_pad-vectors (SolveArgs)
     __device__ __forceinline__ double *xs() const { return xrow; }
@@ -632,62 +632,117 @@ struct WaveProblem {
     // Here stage k's rows land in buffer k mod 3 and are requested while stage k -+ 2 computes.  s_waitcnt
     // vmcnt(n) leaves the n youngest vector-memory operations of the wavefront in flight (they complete in
     // order on this target), so each stage start names what may stay behind: the next stage's rows and the
-    // stores the previous stage issued after requesting them - counted from the source below (forward: two
-    // LDS-DMA operations, then five stores per stage; adjoint: six LDS-DMA operations);
-    // scripts/check_vmem_counts.py verifies the counts in the compiled code.  A smaller n is always safe.
+    // stores the previous stage issued after requesting them - FWD_ROW_TRANSFERS, FWD_STAGE_STORES and
+    // REV_ROW_TRANSFERS below, each defined next to the code that issues the operations it counts;
+    // scripts/check_vmem_counts.py verifies the counts in the compiled code on every path (the Makefile runs it on
+    // every library it links and fails the build otherwise).  A smaller n is always safe; -DPANTR_VMCNT_CONSERVATIVE
+    // turns every one of these waits into vmcnt(0).
     template <int N_>
     __device__ static __forceinline__ void wait_vmem_but() {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+        // expcnt(6) never waits (no exports in a compute kernel) and the compiler never writes it: it MARKS the waits
+        // of these sweeps in the machine code, which is how scripts/check_vmem_counts.py tells them from the compiler's
+#ifdef PANTR_VMCNT_CONSERVATIVE // build switch: every explicit wait of the sweeps below as a full one (always safe)
+        asm volatile("s_waitcnt vmcnt(0) expcnt(6)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(%0) expcnt(6)" ::"n"(N_) : "memory");
+#endif
+    }
+    /// The lanes the tangent sweeps run on: both substage chains side by side (chain_model.hip.h, PairLane), or -
+    /// -DPANTR_CHAIN_ROW_PRODUCT, the form of rounds 2-4 kept for A/B - interleaved on the rows of `Lane`.
+#ifdef PANTR_CHAIN_ROW_PRODUCT
+    using TanLane = Lane;
+    static constexpr int TAN_ST_STORES = 4; ///< d_t stores of a forward stage: one per substage
+#else
+    using TanLane = typename M::PairLane;
+    static constexpr int TAN_ST_STORES = M::PAIR_ST_STORES_PER_STAGE; ///< one per substage pair
+#endif
+    // What the waits of the two-stages-ahead sweeps may leave in flight, from ONE place: the vector-memory operations
+    // a stage issues behind its request (the model names what its functions issue).
+    static constexpr int FWD_STAGE_STORES  = TAN_ST_STORES + 1;     ///< + the tangent-state row (xt_store)
+    static constexpr int FWD_ROW_TRANSFERS = M::FWD_ROW_TRANSFERS;  ///< prefetch_fwd<true>: the K rows of a stage
+    static constexpr int REV_ROW_TRANSFERS = M::REV_ROW_TRANSFERS;  ///< prefetch_rev_xt: K, M, d_t rows and the tangent-state row
+    /// The lanes of a product, built where the product starts (the lane index passes through an empty asm: the lane
+    /// constants are then recomputed per product - a few dozen integer operations - instead of living in registers,
+    /// and spilling, through the whole solve).
+    __device__ __forceinline__ TanLane tan_lane() const {
+#ifdef PANTR_CHAIN_ROW_PRODUCT
+        return L;
+#else
+        int lane = L.l;
+        asm volatile("" : "+v"(lane));
+        return TanLane(lane);
+#endif
     }
     __device__ __forceinline__ void hess_prod_tape_d2(const double *v, double *Hv) const {
         wave_sync();
 #ifdef PANTR_PHASE_TIMING
         const long long hv_t0_ = clock64();
 #endif
+        const TanLane T = tan_lane();
+        // Control flow of both sweeps (round 5): a stage body issues the same number of vector-memory operations behind
+        // its wait whatever k is - where a forward stage has nothing to request it requests something useful to the
+        // adjoint sweep instead, and the adjoint stages that request nothing (1 and 0) are bodies of their own.  The
+        // marked waits are then right on every path the machine code's control-flow graph has, not only on the paths the
+        // values of k allow: scripts/check_vmem_counts.py takes the minimum over all of them.
         // ---- forward tangent sweep ----
         // The adjoint sweep below starts where this one ends, and its first two stages find their rows in LDS:
         // K from this sweep, M requested a product ahead (prime), the tangent spring vectors and the tangent-state
-        // row of stage N - 1 written by the last stage straight into its landing buffer, those of stage N - 2
-        // requested by the last stage (they were stored a stage earlier).  Requested after the sweep they cost every
-        // product two exposed trips to HBM - 2 to 4 us in a launch that loads the memory system.
+        // row of stage N - 1 written by the last stage straight into its landing buffer.
         State s_t{0.0, 0.0};
         auto stage_fwd = [&](int k, char *cur, char *nxt2, char *prev, auto last) {
             constexpr bool LAST = decltype(last)::value;
-            // stage k's K rows have landed in `cur`; in flight behind them may be: stage k+1's rows (two
-            // operations, issued at the start of stage k-1) and the five stores stage k-1 issued after them
-            if (k == 0) {
-                if (N > 1)
-                    wait_vmem_but<2>(); // stage 1's rows
+            // stage k's K rows have landed in `cur`; in flight behind them may be: stage k+1's rows (FWD_ROW_TRANSFERS
+            // operations, issued at the start of stage k-1) and the FWD_STAGE_STORES stores stage k-1 issued after them
+            if constexpr (!LAST) {
+                if (k == 0)
+                    wait_vmem_but<FWD_ROW_TRANSFERS>(); // stage 1's rows (a stage that is not the last: N > 1)
                 else
-                    wait_vmem();
-            } else if (!LAST) {
-                wait_vmem_but<7>();
+                    wait_vmem_but<FWD_ROW_TRANSFERS + FWD_STAGE_STORES>();
             } else {
-                wait_vmem_but<5>(); // the last stage: nothing was requested after its rows but stage k-1's stores
+                if (k == 0)
+                    wait_vmem(); // N = 1
+                else
+                    wait_vmem_but<FWD_STAGE_STORES>(); // nothing was requested after its rows but stage k-1's stores
             }
             if constexpr (!LAST) {
-                if (k + 2 < N)
+                // FWD_ROW_TRANSFERS operations either way: the K rows of stage k + 2, or - stage N - 2, which has none
+                // to ask for - the tangent tape and tangent-state row of stage N - 3 (k - 1) for the adjoint sweep, to
+                // their place in that stage's buffer, which is `nxt2` (the adjoint sweep asks for them again with the
+                // rest of the stage's rows; N = 2: of stage 0, not yet written - nobody reads that buffer)
+                static_assert(FWD_ROW_TRANSFERS == 2, "prefetch_st_xt issues two operations, like prefetch_fwd");
+                if (k + 2 < N) {
                     M::template prefetch_fwd<true>(L, tape + (size_t)(k + 2) * M::TAPE_D4_PER_STAGE, nxt2);
-            } else if (k > 0) { // the tangent tape and tangent-state row of stage N - 2, for the adjoint sweep's second stage
-                M::prefetch_st_xt(L, st + (size_t)(k - 1) * M::ST_D4_PER_STAGE, Xt + (size_t)(k - 1) * M::XT_DOUBLES, prev);
+                } else {
+                    const int kk = k > 0 ? k - 1 : 0;
+                    M::prefetch_st_xt(L, st + (size_t)kk * M::ST_D4_PER_STAGE, Xt + (size_t)kk * M::XT_DOUBLES, nxt2);
+                }
+            } else {
+                // all rows of stage N - 2 for the adjoint sweep's second stage (its K and M rows are in LDS already:
+                // they come again, so that the adjoint sweep's first stage, too, has REV_ROW_TRANSFERS operations
+                // behind it; N = 1: of stage 0 itself, into a buffer nobody reads)
+                const int kk = k > 0 ? k - 1 : 0;
+                M::prefetch_rev_xt(L, tape + (size_t)kk * M::TAPE_D4_PER_STAGE, st + (size_t)kk * M::ST_D4_PER_STAGE,
+                                   Xt + (size_t)kk * M::XT_DOUBLES, prev);
             }
-            const double uc_t = M::load_input(L, v + M::nu * k);
+            const double uc_t = M::load_input(T, v + M::nu * k);
             double4 *st_k;
             if constexpr (!LAST) {
-                M::xt_store(L, Xt + (size_t)k * M::XT_DOUBLES, s_t);
+                M::xt_store(T, Xt + (size_t)k * M::XT_DOUBLES, s_t);
                 st_k = st + (size_t)k * M::ST_D4_PER_STAGE;
             } else {
-                M::xt_store(L, reinterpret_cast<double *>(cur + M::LDS_STAGE_BYTES), s_t);
+                M::xt_store(T, reinterpret_cast<double *>(cur + M::LDS_STAGE_BYTES), s_t);
                 st_k = reinterpret_cast<double4 *>(cur + M::TAPE_STAGE_BYTES);
             }
-            s_t = M::rk4_tan(L, cur, s_t, uc_t, st_k, xs());
+            s_t = M::rk4_tan(T, cur, s_t, uc_t, st_k, xs());
         };
         if (!primed)
             prime();
         {
             constexpr std::false_type F{};
-            constexpr std::true_type T{};
+            constexpr std::true_type LASTT{};
             const int NL = N - 1; // the last stage by itself: its landing buffer is a constant in each of the three cases
+            // three stages per trip, straight through (a lone wavefront pays some twenty cycles for every taken branch:
+            // one stage per trip with a three-way branch on k mod 3 cost the memory-bound launches 6-9 %)
             for (int k = 0; k < NL; k += 3) {
                 stage_fwd(k, tbuf0, tbuf2, tbuf2, F);
                 if (k + 1 < NL)
@@ -696,11 +751,11 @@ struct WaveProblem {
                     stage_fwd(k + 2, tbuf2, tbuf1, tbuf1, F);
             }
             if (NL % 3 == 0)
-                stage_fwd(NL, tbuf0, tbuf2, tbuf2, T);
+                stage_fwd(NL, tbuf0, tbuf2, tbuf2, LASTT);
             else if (NL % 3 == 1)
-                stage_fwd(NL, tbuf1, tbuf0, tbuf0, T);
+                stage_fwd(NL, tbuf1, tbuf0, tbuf0, LASTT);
             else
-                stage_fwd(NL, tbuf2, tbuf1, tbuf1, T);
+                stage_fwd(NL, tbuf2, tbuf1, tbuf1, LASTT);
         }
         // (nothing to wait for here: a wavefront's LDS accesses execute in order, and so do its vector-memory
         // operations - the rows the adjoint sweep requests were stored by this wavefront at least a stage earlier)
@@ -712,52 +767,53 @@ struct WaveProblem {
         // buffer k mod 3; nothing here loads into registers from HBM, so every wait of the sweep is one of the
         // explicit ones below ----
         State lam_t{0.0, 0.0};
-        M::cost_grad_x_add_tan(L, L.end ? s_t.x : s_t.v, lam_t);
-        auto rows_rev = [&](int k, char *buf) {
-            M::prefetch_rev_xt(L, tape + (size_t)k * M::TAPE_D4_PER_STAGE, st + (size_t)k * M::ST_D4_PER_STAGE,
-                                              Xt + (size_t)k * M::XT_DOUBLES, buf);
-        };
-        bool first = true;
-        auto stage_rev = [&](int k, char *cur, char *nxt2) {
-            // stage k's rows have landed; behind them may be stage k-1's: the six transfers stage k+1 requested, the
-            // youngest operations (stage N - 2: the two the forward sweep's last stage requested are older than the
-            // six of stage N - 3).  Stage N - 1 waits for nothing: see above.
-            if (!first) {
-                if (k >= 1)
-                    wait_vmem_but<6>();
-                else
-                    wait_vmem();
-            }
-            first = false;
-            const double xt = M::xt_lds(L, cur);
-            double uc_t = M::load_input(L, v + M::nu * k);
-            if (k > 1) // two stages ahead
-                rows_rev(k - 2, nxt2);
+        M::cost_grad_x_add_tan(T, T.end ? s_t.x : s_t.v, lam_t);
+        // `tail`: 0 = a stage k >= 2 (it asks for the rows of stage k - 2), 1 = stage 1, 2 = stage 0 (nothing left to ask
+        // for; stage 0 is followed by nothing: a full wait) - stages 1 and 0 always sit in tbuf1 and tbuf0
+        auto stage_rev = [&](int k, char *cur, char *nxt2, auto tail) {
+            constexpr int TAIL = decltype(tail)::value;
+            // stage k's rows have landed; behind them may be stage k-1's: the REV_ROW_TRANSFERS operations the stage
+            // before this one issued, the youngest (stage N - 1: those the forward sweep's last stage issued - it needs
+            // nothing from them, the wait passes)
+            if constexpr (TAIL == 2)
+                wait_vmem();
+            else
+                wait_vmem_but<REV_ROW_TRANSFERS>();
+            const double xt = M::xt_lds(T, cur);
+            double uc_t = M::load_input(T, v + M::nu * k);
+            if constexpr (TAIL == 0) // two stages ahead
+                M::prefetch_rev_xt(L, tape + (size_t)(k - 2) * M::TAPE_D4_PER_STAGE, st + (size_t)(k - 2) * M::ST_D4_PER_STAGE,
+                                   Xt + (size_t)(k - 2) * M::XT_DOUBLES, nxt2);
             State sbar_t;
             double ubar_t;
-            M::rk4_adj_tan(L, cur, lam_t, sbar_t, ubar_t, xs());
-            M::store_input_grad(L, Hv + M::nu * k, __builtin_fma(M::c2g, uc_t, ubar_t));
+            M::rk4_adj_tan(T, cur, lam_t, sbar_t, ubar_t, xs());
+            M::store_input_grad(T, Hv + M::nu * k, __builtin_fma(M::c2g, uc_t, ubar_t));
             lam_t = sbar_t;
-            M::cost_grad_x_add_tan(L, xt, lam_t);
+            M::cost_grad_x_add_tan(T, xt, lam_t);
         };
-        // down to a multiple of three by hand, then three stages per trip
-        int k = N - 1;
-        if (k % 3 == 2) {
-            stage_rev(k, tbuf2, tbuf0);
-            --k;
-        }
-        if (k >= 0 && k % 3 == 1) {
-            stage_rev(k, tbuf1, tbuf2);
-            --k;
-        }
-        if (k >= 0) { // k % 3 == 0
-            stage_rev(k, tbuf0, tbuf1);
-            --k;
-        }
-        for (; k >= 2; k -= 3) {
-            stage_rev(k, tbuf2, tbuf0);
-            stage_rev(k - 1, tbuf1, tbuf2);
-            stage_rev(k - 2, tbuf0, tbuf1);
+        {
+            constexpr std::integral_constant<int, 0> MID{};
+            int k = N - 1;
+            // down to k = 2 (mod 3) by hand, then three stages per trip while all three ask for rows (k - 2 >= 2),
+            // then stage 2 and the two stages that ask for nothing
+            if (k >= 2 && k % 3 == 1) {
+                stage_rev(k, tbuf1, tbuf2, MID);
+                --k;
+            }
+            if (k >= 2 && k % 3 == 0) {
+                stage_rev(k, tbuf0, tbuf1, MID);
+                --k;
+            }
+            for (; k >= 5; k -= 3) {
+                stage_rev(k, tbuf2, tbuf0, MID);
+                stage_rev(k - 1, tbuf1, tbuf2, MID);
+                stage_rev(k - 2, tbuf0, tbuf1, MID);
+            }
+            if (k >= 2) // k == 2
+                stage_rev(2, tbuf2, tbuf0, MID);
+            if (N >= 2)
+                stage_rev(1, tbuf1, tbuf2, std::integral_constant<int, 1>{});
+            stage_rev(0, tbuf0, tbuf1, std::integral_constant<int, 2>{});
         }
         wave_sync();
         prime(); // for the next product (the CG algebra runs meanwhile)
@@ -810,6 +866,7 @@ struct WaveProblem {
 #ifdef PANTR_PHASE_TIMING
         const long long hv_t0_ = clock64();
 #endif
+        const TanLane T = tan_lane();
         // ---- forward tangent sweep ----
         State s_t{0.0, 0.0};
         double xt_last = 0.0; // what xt_store() would write for stage N - 1 (and this lane read back)
@@ -820,16 +877,16 @@ struct WaveProblem {
             // request gets a full s_waitcnt vmcnt(0) from the compiler whenever it cannot tell the vector from the
             // landing buffers - the request just made would be waited for, stage after stage (+13 % per product when
             // it happened; scripts/check_vmem_counts.py looks for that pattern in the compiled kernels)
-            const double uc_t = M::load_input(L, v + M::nu * k);
+            const double uc_t = M::load_input(T, v + M::nu * k);
             if constexpr (!LAST) {
                 M::prefetch_fwd(L, tape + (size_t)(k + 1) * M::TAPE_D4_PER_STAGE, nxt);
-                M::xt_store(L, Xt + (size_t)k * M::XT_DOUBLES, s_t);
+                M::xt_store(T, Xt + (size_t)k * M::XT_DOUBLES, s_t);
             } else {
-                xt_last = L.end ? s_t.x : s_t.v;
+                xt_last = T.end ? s_t.x : s_t.v;
             }
             // the last stage writes its tangent spring vectors where the adjoint sweep's first stage reads them
             double4 *st_k = LAST ? reinterpret_cast<double4 *>(cur + M::TAPE_STAGE_BYTES) : st + (size_t)k * M::ST_D4_PER_STAGE;
-            s_t = M::rk4_tan(L, cur, s_t, uc_t, st_k, xs());
+            s_t = M::rk4_tan(T, cur, s_t, uc_t, st_k, xs());
         };
         if (!primed)
             prime_d1();
@@ -856,7 +913,7 @@ struct WaveProblem {
 #endif
         // ---- second-order adjoint sweep (even stages land in tbuf0, odd ones in tbuf1) ----
         State lam_t{0.0, 0.0};
-        M::cost_grad_x_add_tan(L, L.end ? s_t.x : s_t.v, lam_t);
+        M::cost_grad_x_add_tan(T, T.end ? s_t.x : s_t.v, lam_t);
         double xt = 0.0, xt_n = xt_last;
         bool first = true; // stage N - 1 finds its rows in LDS
         auto stage_rev = [&](int k, char *cur, char *nxt) {
@@ -864,18 +921,18 @@ struct WaveProblem {
                 wait_vmem(); // stage k's rows and Xt row have landed
             first = false;
             xt = xt_n;
-            double uc_t = M::load_input(L, v + M::nu * k);
+            double uc_t = M::load_input(T, v + M::nu * k);
             if (k > 0) { // one stage ahead
                 M::prefetch_rev(L, tape + (size_t)(k - 1) * M::TAPE_D4_PER_STAGE,
                                 st + (size_t)(k - 1) * M::ST_D4_PER_STAGE, nxt);
-                xt_n = M::xt_load(L, Xt + (size_t)(k - 1) * M::XT_DOUBLES);
+                xt_n = M::xt_load(T, Xt + (size_t)(k - 1) * M::XT_DOUBLES);
             }
             State sbar_t;
             double ubar_t;
-            M::rk4_adj_tan(L, cur, lam_t, sbar_t, ubar_t, xs());
-            M::store_input_grad(L, Hv + M::nu * k, __builtin_fma(M::c2g, uc_t, ubar_t));
+            M::rk4_adj_tan(T, cur, lam_t, sbar_t, ubar_t, xs());
+            M::store_input_grad(T, Hv + M::nu * k, __builtin_fma(M::c2g, uc_t, ubar_t));
             lam_t = sbar_t;
-            M::cost_grad_x_add_tan(L, xt, lam_t);
+            M::cost_grad_x_add_tan(T, xt, lam_t);
         };
         int k = N - 1;
         if (!(k & 1)) {

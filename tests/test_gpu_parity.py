@@ -28,7 +28,9 @@ def rng():
     return np.random.default_rng(20231003)
 
 
-@pytest.mark.parametrize("N", [1, 2, 7, 21, 22, 60, 682])  # 682: the longest horizon a handle accepts (n = 2046)
+# 1..5, 7: every way the stage loops of the products end (landing buffers in rotation, first and last stages by
+# themselves); 682: the longest horizon a handle accepts (n = 2046)
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 7, 21, 22, 60, 682])
 def test_psi_grad_hess_prod_match_oracle(rng, N):
     B = 5 if N < 600 else 2
     with_batch = pa.PantrBatch("hanging_chain", N, B)

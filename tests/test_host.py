@@ -314,13 +314,60 @@ def test_eval_wrappers_validate_shapes():
 
 
 def test_explicit_vmcnt_waits_are_covered_in_the_compiled_kernel():
-    """scripts/check_vmem_counts.py: every `s_waitcnt vmcnt(n)` of the two-stages-ahead product sweeps is preceded,
-    in the compiled one-wavefront kernel, by at least n vector-memory instructions since the previous such wait
-    (what makes leaving n operations in flight safe); and no stage loop of a product, in any of the hanging chain's
-    PANTR kernels, waits for tape rows it has only just requested."""
+    """scripts/check_vmem_counts.py (the Makefile runs it on every library it links): every marked `s_waitcnt vmcnt(n)
+    expcnt(6)` of the two-stages-ahead product sweeps is preceded, on EVERY path of the compiled control flow, by at least
+    n vector-memory instructions since the synchronisation point before it; and no stage loop of a product, in any of the
+    hanging chain's PANTR kernels, waits for tape rows it has only just requested."""
+    if not os.path.exists(pa.LIB_PATH) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("needs the built library and llvm-objdump")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_vmem_counts.py"), pa.LIB_PATH],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("marked waits checked on every path, 0 not covered") >= 4   # three solve kernels + the evaluation kernel
+
+
+def test_the_vmcnt_checker_finds_what_it_should():
+    """The checker on hand-written instruction streams: a wait that a path reaches with too few operations is reported,
+    the compiler's two lowerings of `if (c) A else B` (two branches on one condition register; a flag register set to -1
+    before and 0 inside A) are not, and a path from a full drain with nothing issued passes."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    argv, sys.argv = sys.argv, [sys.argv[0]]
+    try:
+        import check_vmem_counts as cv
+    finally:
+        sys.argv = argv
+
+    def run(lines):
+        ins = [l.strip() for l in lines.strip().splitlines()]
+        addr = [4 * i for i in range(len(ins))]            # (every instruction four bytes: branch offsets count instructions)
+        return cv.check_marked_waits("t", ins, addr)
+
+    LD, ST = "global_load_lds_dwordx4 v[0:1], off", "global_store_dwordx2 v[0:1], v[2:3], off"
+    W = lambda n: f"s_waitcnt vmcnt({n}) expcnt(6)"
+    # straight line: 2 + 3 operations behind the wait before -> vmcnt(5) is covered, vmcnt(6) is not
+    assert run("\n".join(["s_nop 0", W(2), LD, LD, ST, ST, ST, W(5), "s_endpgm"]))[:2] == (2, 0)
+    assert run("\n".join(["s_nop 0", W(2), LD, LD, ST, ST, ST, W(6), "s_endpgm"]))[:2] == (2, 1)
+    # a request under a condition: the path around it has only the three stores
+    skip = ["s_nop 0", W(2), "s_cbranch_vccz 2", LD, LD, ST, ST, ST, W(5), "s_endpgm"]
+    assert run("\n".join(skip))[:2] == (2, 1)
+    # if / else on one unchanged condition register: one of the two requests is always made
+    both = ["s_nop 0", W(2), "s_cbranch_vccz 2", LD, LD, "s_cbranch_vccnz 2", LD, LD, ST, ST, ST, W(5), "s_endpgm"]
+    assert run("\n".join(both))[:2] == (2, 0)
+    # ... but not if the register is written in between
+    clob = both[:5] + ["v_cmp_lt_f64_e32 vcc, v[0:1], v[2:3]"] + both[5:]
+    clob[2] = "s_cbranch_vccz 2"
+    assert run("\n".join(clob))[:2] == (2, 1)
+    # if / else through a flag register, the flag set BEFORE the synchronisation point
+    flag = ["s_nop 0", "s_mov_b64 s[48:49], -1", W(2), "s_and_b64 vcc, exec, s[44:45]", "s_cbranch_vccz 3", LD, LD,
+            "s_mov_b64 s[48:49], 0", "s_andn2_b64 vcc, exec, s[48:49]", "s_cbranch_vccnz 2", LD, LD, ST, ST, ST, W(5), "s_endpgm"]
+    assert run("\n".join(flag))[:2] == (2, 0)
+    flag[1] = "s_mov_b64 s[48:49], 0"                       # the flag says "A ran" on the path that skipped A: both may be skipped
+    assert run("\n".join(flag))[:2] == (2, 1)
+    # from a full drain: nothing issued since -> nothing in flight, passes; something but too little -> reported
+    assert run("\n".join(["s_nop 0", "s_waitcnt vmcnt(0)", W(5), "s_endpgm"]))[:2] == (1, 0)
+    assert run("\n".join(["s_nop 0", "s_waitcnt vmcnt(0)", LD, W(5), "s_endpgm"]))[:2] == (1, 1)
+    # the conservative build
+    assert run("\n".join(["s_nop 0", "s_waitcnt vmcnt(0) expcnt(6)", "s_endpgm"])) == (0, 0, 1)
 
 
 def test_bench_started_bare_launches_ranks_and_reports_their_failure():
