@@ -42,7 +42,7 @@ struct OracleStats {
     int32_t status, iterations, cg_iterations, accepted, rejected, qub_backtracks;
     int32_t n_psi, n_grad_psi, n_psi_grad_psi, n_grad_L, n_hess_psi_prod, n_prox_grad_step;
     int32_t outer_iterations, inner_convergence_failures;
-    int32_t n_hess_psi_prod_calls, pad1;
+    int32_t n_hess_psi_prod_calls, qub_at_prox; ///< qub_at_prox: quadratic-upper-bound backtracking steps taken at a prox iterate
     double delta, penalty_norm;
     int32_t linesearch_failures, linesearch_backtracks, lbfgs_failures, lbfgs_rejected, tau_1_accepted,
         count_tau;
@@ -190,7 +190,7 @@ static void export_stats(const Stats &s, OracleStats *o) {
     o->n_hess_psi_prod = (int32_t)s.n_hess_psi_prod;
     o->n_prox_grad_step = (int32_t)s.n_prox_grad_step;
     o->outer_iterations = s.outer_iterations; o->inner_convergence_failures = s.inner_convergence_failures;
-    o->n_hess_psi_prod_calls = (int32_t)s.n_hess_psi_prod_calls; o->pad1 = 0;
+    o->n_hess_psi_prod_calls = (int32_t)s.n_hess_psi_prod_calls; o->qub_at_prox = s.qub_at_prox;
     o->delta = s.delta; o->penalty_norm = s.penalty_norm;
     o->linesearch_failures = s.linesearch_failures; o->linesearch_backtracks = s.linesearch_backtracks;
     o->lbfgs_failures = s.lbfgs_failures; o->lbfgs_rejected = s.lbfgs_rejected;

@@ -76,6 +76,7 @@ struct SteihaugCGParams {
 struct Stats {
     int status = Busy;
     int iterations = 0, cg_iterations = 0, accepted = 0, rejected = 0, qub_backtracks = 0;
+    int qub_at_prox = 0; ///< of those, the backtracking steps taken at a prox iterate xbar (adjudication aid)
     long n_psi = 0, n_grad_psi = 0, n_psi_grad_psi = 0, n_grad_L = 0, n_hess_psi_prod = 0,
          n_prox_grad_step = 0;
     /// n_hess_psi_prod + the products with q_K = 0 the direction skips: what alpaqa's EvalCounter would show
@@ -335,6 +336,17 @@ struct PANTRSolver {
             prox->gamma = curr->gamma;
             prox->L     = curr->L;
             prox_grad_step(*prox);
+            // variant 16 (read literally): the prox iterate gets its psi(xhat) and its
+            // quadratic-upper-bound backtracking BEFORE the direction, so that J, r_J and phi_gamma(xbar) see a step
+            // size halved here; the specification (variant 0) defers both until the candidate has been rejected - the
+            // step size is then the one the direction was built with, and an accepted candidate never pays for
+            // psi(xhat(xbar)).  The two differ only where the bound test fails at xbar (s.qub_at_prox counts it).
+            if (params.variant & 16) {
+                const int before = s.qub_backtracks;
+                eval_psi_xh(*prox);
+                backtrack_qub(*prox);
+                s.qub_at_prox += s.qub_backtracks - before;
+            }
 
             // ---- Newton trust-region direction at xbar ----
             bool accept = false;
@@ -419,8 +431,12 @@ struct PANTRSolver {
                 std::swap(curr, cand);
                 ++s.accepted;
             } else {
-                eval_psi_xh(*prox);
-                backtrack_qub(*prox);
+                if (!(params.variant & 16)) {
+                    const int before = s.qub_backtracks;
+                    eval_psi_xh(*prox);
+                    backtrack_qub(*prox);
+                    s.qub_at_prox += s.qub_backtracks - before;
+                }
                 std::swap(curr, prox);
                 ++s.rejected;
             }
@@ -478,6 +494,7 @@ Stats alm_solve(const ALMParams &alm, const Inner &inner, Problem &problem, doub
         total.accepted += ps.accepted;
         total.rejected += ps.rejected;
         total.qub_backtracks += ps.qub_backtracks;
+        total.qub_at_prox += ps.qub_at_prox;
         total.n_psi += ps.n_psi; total.n_grad_psi += ps.n_grad_psi; total.n_psi_grad_psi += ps.n_psi_grad_psi;
         total.n_grad_L += ps.n_grad_L; total.n_hess_psi_prod += ps.n_hess_psi_prod;
         total.n_hess_psi_prod_calls += ps.n_hess_psi_prod_calls;

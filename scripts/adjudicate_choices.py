@@ -21,7 +21,8 @@ import oracle_binding as ob
 
 pub = json.load(open(os.path.join(ROOT, "tests", "golden", "published_series.json")))["series"]
 VARIANTS = [(0, "specification"), (1, "Lipschitz step x + h"), (2, "initial radius ||grad||"), (4, "q_K = 0"),
-            (8, "model value of the whole step")]
+            (8, "model value of the whole step"),
+            (16, "psi(xhat) + bound test at the prox iterate BEFORE the direction (SURVEY Appendix A step 2)")]
 only = [int(a) for a in sys.argv[1:]] or None
 
 
@@ -50,9 +51,10 @@ for v, name in VARIANTS:
             rho, r = spearmanr(w, p)[0], pearsonr(np.log(w + 1), np.log(p))[0]
             tot[warm] = w.sum()
             conv = sum(s["status"] == 1 for s in st)
+            qub, qub_prox, its = (sum(s[k] for s in st) for k in ("qub_backtracks", "qub_at_prox", "iterations"))
             sp.append(rho); lp.append(r)
             print(f"   {problem:22s} {'warm' if warm else 'cold'}: spearman {rho:+.2f}  log-pearson {r:+.2f}  work {w.sum():9.0f} sweeps  "
-                  f"converged {conv}/60")
+                  f"converged {conv}/60  bound test failed {qub}x ({qub_prox}x at a prox iterate) in {its} iterations")
         pr = np.mean(pub[problem]["pantr"]["cold"]) / np.mean(pub[problem]["pantr"]["warm"])
         print(f"   {problem:22s} cold/warm: work {tot[False]/tot[True]:.2f}, published time {pr:.2f}")
     print(f"   mean spearman over the six series {np.mean(sp):+.3f}, over the four with structure (not the two flat warm "

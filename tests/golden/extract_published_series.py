@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Extracts the only numbers the reference publishes for this path - the per-MPC-step solver times of the
-N = 60 runs - from its plots into tests/golden/published_series.json (data, no reference text).
+N = 60 runs and the averages per horizon (3 problems x cold/warm x 6 horizons = 36 PANTR averages, and the
+comparators') - from its plots into tests/golden/published_series.json (data, no reference text).
 
 Run in the build container (needs /root/reference; the GPU box does not have it):
     python3 tests/golden/extract_published_series.py [/root/reference]
@@ -70,7 +71,10 @@ def main():
     data = {"source": "images/mpc-<problem>-60-runtimes-mpc-last-cold-warm.pdf.svg of kul-optec/pantr-cdc2023-experiments "
                       "(README.md:36,69,106); extracted by tests/golden/extract_published_series.py",
             "unit": "seconds of solver time per MPC step (alpaqa stats.elapsed_time, mpc-driver.cpp:199-201,216-222); "
-                    "unstated CPU, one thread", "horizon": 60, "steps": 60, "series": {}}
+                    "unstated CPU, one thread", "horizon": 60, "steps": 60, "series": {},
+            # the companion plots (README.md:33,66,103): average solver time per MPC step (60 steps) against the horizon
+            "averages_source": "images/mpc-<problem>-60-avg-runtimes-quantiles-cold-warm.pdf.svg (README.md:33,66,103)",
+            "average_horizons": [10, 20, 30, 40, 50, 60], "averages": {}}
     for problem in ("hanging_chain", "quadcopter", "realistic_quadcopter"):
         last, avg = read_plot(problem, "last"), read_plot(problem, "avg")
         data["series"][problem] = {}
@@ -82,6 +86,10 @@ def main():
                 mean = sum(v) / len(v)
                 assert abs(mean / ref - 1) < 2e-3, (problem, solver, start, mean, ref)
             data["series"][problem].setdefault(solver, {})[start] = [float(f"{x:.4g}") for x in v]
+        data["averages"][problem] = {}
+        for (solver, start), v in sorted(avg.items()):  # six horizons per curve (dodo.py:70: 10, 20, ..., 60)
+            assert len(v) == 6, (problem, solver, start, len(v))
+            data["averages"][problem].setdefault(solver, {})[start] = [float(f"{x:.4g}") for x in v]
         print(problem, {k: sorted(v) for k, v in data["series"][problem].items()})
     with open(OUT, "w") as f:
         json.dump(data, f, indent=0)

@@ -49,7 +49,7 @@ class OracleStats(C.Structure):
                                     "rejected", "qub_backtracks", "n_psi", "n_grad_psi",
                                     "n_psi_grad_psi", "n_grad_L", "n_hess_psi_prod",
                                     "n_prox_grad_step", "outer_iterations",
-                                    "inner_convergence_failures", "n_hess_psi_prod_calls", "pad1")] + \
+                                    "inner_convergence_failures", "n_hess_psi_prod_calls", "qub_at_prox")] + \
                [(k, _dbl) for k in ("delta", "penalty_norm")] + \
                [(k, _i32) for k in ("linesearch_failures", "linesearch_backtracks", "lbfgs_failures",
                                     "lbfgs_rejected", "tau_1_accepted", "count_tau")] + \

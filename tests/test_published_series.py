@@ -113,3 +113,62 @@ def test_comparators_relative_cost_is_the_published_one(comparator_loops, warm):
     ratio = comparator_loops[("panoc", warm)].sum() / comparator_loops[("strucpanoc", warm)].sum()
     ref = np.mean(PUB["series"]["hanging_chain"]["panoc"][key]) / np.mean(PUB["series"]["hanging_chain"]["strucpanoc"][key])
     assert abs(ratio / ref - 1) < 0.15, (ratio, ref)
+
+
+# ---- the 36 published averages per horizon (README.md:33,66,103) ------------------------------
+AVG_H = PUB["average_horizons"]
+# the reference's realistic_quadcopter N = 50 cold run has non-converged steps (703 ms, marked x in the
+# plot: twice the N = 60 average); the oracle's run converges (60 of 60) - that one point is compared with nothing
+KNOWN_OUTLIER = ("realistic_quadcopter", False, 50)
+
+
+@pytest.fixture(scope="module")
+def work_per_horizon(closed_loops):
+    """Mean per-step work x N (an evaluation sweeps over N stages) of the oracle's closed loops at the six horizons."""
+    out = {}
+    for problem in ("hanging_chain", "quadcopter", "realistic_quadcopter"):
+        for warm in (False, True):
+            w = []
+            for N in AVG_H:
+                if N == 60:
+                    w.append(closed_loops[(problem, warm)].mean() * N)
+                    continue
+                stats = ob.mpc(N, 60, warm)[3] if problem == "hanging_chain" else ob.quad_mpc(problem, N, 60, warm)[2]
+                assert all(s["status"] == 1 for s in stats)
+                w.append(np.mean([work(s) for s in stats]) * N)
+            out[(problem, warm)] = np.array(w)
+    return out
+
+
+def test_averages_fixture_is_the_published_record():
+    """hanging_chain cold 2.21 / 7.23 / 22.1 / 56.9 / 176 / 345 ms, warm 1.76 ... 130 ms; the N = 60
+    average is the mean of the 60 per-step points of the other plot (the extraction checks it to 0.2 % for every solver)."""
+    assert AVG_H == [10, 20, 30, 40, 50, 60]
+    a = PUB["averages"]["hanging_chain"]["pantr"]
+    assert np.allclose(a["cold"], [2.21e-3, 7.23e-3, 22.1e-3, 56.9e-3, 176e-3, 345e-3], rtol=5e-3)
+    assert np.allclose(a["warm"], [1.76e-3, 5.80e-3, 13.2e-3, 23.5e-3, 50.4e-3, 130e-3], rtol=5e-3)
+    for problem in PUB["averages"]:
+        for start in ("cold", "warm"):
+            assert abs(PUB["averages"][problem]["pantr"][start][5] / published(problem, start == "warm").mean() - 1) < 2e-3
+    assert sum(len(v) for p in PUB["averages"].values() for v in p["pantr"].values()) == 36
+
+
+@pytest.mark.parametrize("problem", ["hanging_chain", "quadcopter", "realistic_quadcopter"])
+@pytest.mark.parametrize("warm", [False, True])
+def test_cost_grows_with_the_horizon_as_published(work_per_horizon, problem, warm):
+    """work(N) / work(60) of the oracle against time(N) / time(60) of the reference, six horizons, cold and warm: a
+    machine-independent shape.  Measured (work slope / time slope of the log-log fit): hanging chain 2.47 / 2.84 cold,
+    1.94 / 2.27 warm; quadcopter 2.53 / 2.74, 1.69 / 1.92; realistic_quadcopter 2.32 / 2.79 (2.32 / 2.50 without the known
+    outlier), 1.47 / 1.73; every point's ratio within [0.72, 1.95].  The work grows a little slower than the time on all
+    six curves (by 0.1 to 0.4 in the exponent): an evaluation of the reference is straight-line generated code of O(N)
+    instructions, whose cost per instruction rises with the code's size (the full-Hessian variant "fails to compile (too
+    big)", problems/CMakeLists.txt:38-39) - the count of sweeps x N cannot show that.  Asserted: the exponents differ by at
+    most 0.45 and never the other way by more than 0.1; every point within a factor of two.  Evidence, not a pin."""
+    w, t = work_per_horizon[(problem, warm)], np.array(PUB["averages"][problem]["pantr"]["warm" if warm else "cold"])
+    keep = np.array([(problem, warm, N) != KNOWN_OUTLIER for N in AVG_H])
+    h = np.log(np.array(AVG_H, float))
+    slope_w = np.polyfit(h[keep], np.log(w[keep]), 1)[0]
+    slope_t = np.polyfit(h[keep], np.log(t[keep]), 1)[0]
+    assert -0.45 <= slope_w - slope_t <= 0.10, (slope_w, slope_t)
+    ratio = (w / w[-1]) / (t / t[-1])
+    assert np.all((ratio[keep] > 0.5) & (ratio[keep] < 2.0)), ratio
