@@ -331,7 +331,9 @@ def extra_configs(torch, pa, dev, local_rank, cores, peak_measured, with_cpu):
 
 
 # ---- strong scaling over ranks: one batch dealt longest-first --------------------------------------
-def strong_mode(args, torch, pa, dev, local_rank, rank, world, distributed, rehearsal):
+def strong_mode(args, torch, pa, dev, local_rank, rank, world, distributed, rehearsal, emit=True):
+    """One batch dealt to the ranks (BASELINE.json configs[3] | configs[4]); rank 0 prints the record (emit) or
+    returns it (the multi-rank default run attaches it to the headline line as `strong`)."""
     from pantr_amd import sharding, workloads
     import torch.distributed as dist
     if args.workload == "sweep":
@@ -402,10 +404,11 @@ def strong_mode(args, torch, pa, dev, local_rank, rank, world, distributed, rehe
         if not same:
             failure = failure or "bench.py: the sharded solutions differ from the unsharded solve"
     sharding.raise_together(failure, cdev)  # every rank: rank 0's verdict on the gathered result
+    record = None
     if rank == 0:
         total = len(where) * args.steps
         dom = int(np.argmax(kms))
-        print(json.dumps({
+        record = {
             "metric": f"MPC-steps solved/sec, {args.workload} batch sharded over {world} MI355X", "value": total / elapsed,
             "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -419,9 +422,12 @@ def strong_mode(args, torch, pa, dev, local_rank, rank, world, distributed, rehe
                               "the GPU is full (many instances per CU)"},
             "roofline": dict(roofline_obj(rs[dom].alg_bytes(), kms[dom], rs[dom].kernel_name()),
                              rank0_all_launches_algorithmic_bytes=int(alg), rank0_kernel_ms=kms),
-        }), flush=True)
+        }
+        if emit:
+            print(json.dumps(record), flush=True)
     for r in rs:
         r.close()
+    return record
 
 
 def spawn_ranks(n):
@@ -429,15 +435,17 @@ def spawn_ranks(n):
     this process has made any torch.cuda / HIP call; it never makes one - with the environment torch.distributed.run
     would give them, relay rank 0's line (its stdout is this process's stdout), and leave with a failure if any
     rank failed.  Children are ended by their exact PIDs if one of them fails while the others still run."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    import tempfile
+    # rendezvous through a file of this launch's own (PANTR_BENCH_STORE; main() hands it to init_process_group): a port
+    # picked by bind-then-close could be taken by another process before the ranks meet
+    store = os.path.join(tempfile.mkdtemp(prefix="pantr_bench_"), "rendezvous")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   PANTR_BENCH_STORE="file://" + store,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.pop("MASTER_PORT", None)
         out = None if r == 0 else subprocess.DEVNULL  # rank 0 prints the JSON line
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
     rc = 0
@@ -462,6 +470,8 @@ def spawn_ranks(n):
                 except subprocess.TimeoutExpired:
                     p.kill()
             break
+    import shutil
+    shutil.rmtree(os.path.dirname(store), ignore_errors=True)
     return rc
 
 
@@ -509,7 +519,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL ("nccl"); used for barriers + one MAX reduction (+ the result gather in strong mode) only
-        dist.init_process_group(backend="gloo" if rehearsal else "nccl")
+        store = os.environ.get("PANTR_BENCH_STORE")  # set by spawn_ranks; under torch.distributed.run: env:// as usual
+        if store:
+            dist.init_process_group(backend="gloo" if rehearsal else "nccl", init_method=store, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="gloo" if rehearsal else "nccl")
 
     if args.scaling == "strong" or args.workload != "headline":
         if args.workload == "headline":
@@ -654,9 +668,28 @@ def main():
                     line["cpu_baseline"]["all_cores"] = dict(best, tried={str(l["cores"]): l["value"] for l in legs})
                 line["cpu_serial_closed_loop"] = cpu_serial_closed_loop()
             line["configs"] = extra_configs(torch, pa, dev, local_rank, cores, peak_measured, with_cpu)
-        print(json.dumps(line), flush=True)
     for r in rs:
         r.close()
+    # Several ranks, default flags (what the driver's scaling run starts): the weak headline above is N replicas of
+    # one batch and scales by construction; what shows whether sharding helps are the two batches that DO shard -
+    # BASELINE.json configs[3] (the horizon sweep) and configs[4] (the N = 120 stress batch) dealt to the ranks, a
+    # few passes each.  Attached as `strong`; the headline value stays the weak one.
+    if distributed and not args.headline_only and S == 1:
+        import copy
+        strong = {}
+        for wl in ("sweep", "stress"):
+            a2 = copy.copy(args)
+            a2.workload, a2.scaling, a2.steps, a2.warmup = wl, "strong", 3, 1
+            rec = strong_mode(a2, torch, pa, dev, local_rank, rank, world, distributed, rehearsal, emit=False)
+            if rank == 0:
+                strong[wl] = {k: rec[k] for k in ("value", "unit", "ms_per_step", "steps", "scaling", "bound")}
+                strong[wl]["instances"] = rec["config"]["instances"]
+                strong[wl]["gathered_equals_unsharded"] = rec["config"]["gathered_equals_unsharded"]
+                strong[wl]["roofline"] = {k: rec["roofline"].get(k) for k in ("kernel", "frac", "achieved", "unit")}
+        if rank == 0:
+            line["strong"] = strong
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

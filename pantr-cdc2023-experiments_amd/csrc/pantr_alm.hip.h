@@ -1283,6 +1283,7 @@ struct ScalarALProblem {
     bool spec_pending = false, spec_dead = false;
     int spec_timeouts = 0; ///< results this wavefront stopped waiting for (stats.spec_timeouts)
     double spec_tick_s = 1e-8, spec_patience_s = 1.0;
+    double spec_give_up_s = 1.0; ///< the helper's own deadline (spec_serve): how long an ended helper is waited for at most
 
     __device__ __forceinline__ void spec_request(int xh_slot, double psi_x, double gradTp, double pTp, double Lip,
                                                  const KernelParams &P, int yh_slot) {
@@ -1311,6 +1312,14 @@ struct ScalarALProblem {
                 ++spec_timeouts;
                 if (lane == 0)
                     __hip_atomic_store(&spec->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // The helper of this problem family writes into what the solver is about to use again - yhat goes to
+                // the prox iterate's m-vector slot, and it reads xhat, y, Sigma - and looks at the flag only between
+                // its sweeps: the solver goes on alone only once the helper has said that it ended (at most one sweep
+                // away; bounded like the helper's own life, should the wavefront never run again).
+                const long long t1 = wall_clock64();
+                while (__hip_atomic_load(&spec->stopped, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 &&
+                       (double)(wall_clock64() - t1) * spec_tick_s < spec_give_up_s)
+                    __builtin_amdgcn_s_sleep(2);
                 return false;
             }
         }
@@ -1361,6 +1370,12 @@ struct ScalarALProblem {
     }
     /// The helper wavefront (`this`: its own X, Xt, TG, scr, coef; the solver's vectors and m-vectors).
     __device__ __forceinline__ void spec_serve(long long t_start, double tick_s, double give_up_s) {
+        spec_serve_loop(t_start, tick_s, give_up_s);
+        wave_sync(); // whatever this wavefront wrote last is written
+        if (lane == 0)
+            __hip_atomic_store(&spec->stopped, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ void spec_serve_loop(long long t_start, double tick_s, double give_up_s) {
         int seen = 0;
         auto aborted = [&]() {
             return uniform(__hip_atomic_load(&spec->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0;
@@ -1743,11 +1758,13 @@ __global__ __launch_bounds__(2 * WAVE) void pantr_alm_spec_kernel(AlmSolveArgs a
         box.done_seq = 0;
         box.cmd      = 0;
         box.abort    = 0;
+        box.stopped  = 0;
     }
     __syncthreads(); // the only workgroup barrier: LDS is cleared and the mailbox exists
     pb.spec        = &box;
     pb.spec_tick_s = a.prm.tick_s;
     pb.spec_patience_s = a.prm.spec_patience_s;
+    pb.spec_give_up_s  = 2.0 * a.alm.max_time_s + 1.0;
     pb.tape0       = a.ws + (size_t)inst * 2 * PB::workspace_doubles(a.N);
     pb.tape        = pb.tape0;
     double *h      = lds + solver_doubles; // the helper's LDS
@@ -1759,7 +1776,7 @@ __global__ __launch_bounds__(2 * WAVE) void pantr_alm_spec_kernel(AlmSolveArgs a
         pb.TG   = reinterpret_cast<double2 *>(pb.Xt + (size_t)(a.N + 1) * M::nx);
         pb.coef = reinterpret_cast<double *>(pb.TG + 12 * (a.N + 1));
         pb.scr  = pb.coef + PB::coef_doubles(a.N);
-        pb.spec_serve(t_start, a.prm.tick_s, 2.0 * a.alm.max_time_s + 1.0);
+        pb.spec_serve(t_start, a.prm.tick_s, pb.spec_give_up_s);
         return;
     }
     __builtin_amdgcn_s_setprio(3);

@@ -234,6 +234,7 @@ __device__ __forceinline__ void wave_sum3(double &x, double &y, double &z) {
 struct alignas(16) SpecBox { // a multiple of 16 bytes: the dynamic LDS behind it stays 16-byte aligned
     int req_seq, done_seq; ///< main: requests posted; helper: requests finished
     int abort;             ///< main: it stopped waiting for a result - the helper ends at its next check
+    int stopped;           ///< helper: it has ended (set on every way out of its loop): nothing of the instance is written by it any more
     int cmd;               ///< SPEC_EVAL | SPEC_EXIT
     int xh_slot;           ///< iterate vector (pb.ivec index) holding the point to evaluate: xhat of the prox iterate
     int yh_slot;           ///< problems with general constraints: the m-vector that receives yhat there
@@ -1995,6 +1996,7 @@ __global__ __launch_bounds__(2 * WAVE, 2) void pantr_solve_spec_kernel(SolveArgs
         box.done_seq = 0;
         box.cmd = 0;
         box.abort = 0;
+        box.stopped = 0;
     }
     __syncthreads(); // the only workgroup barrier: the mailbox exists before either wavefront reads it
     // The two wavefronts build their problem objects in branches of their own, so that each sees its landing

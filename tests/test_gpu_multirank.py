@@ -31,7 +31,7 @@ def test_two_rank_sharded_batch_on_the_device(tmp_path):
     assert d["world"] == 2 and sorted(np.concatenate([d["idx0"], d["idx1"]]).tolist()) == list(range(len(d["serial"])))
 
 
-@pytest.mark.parametrize("mode", [["--headline-only"], ["--workload", "sweep", "--scaling", "strong"]])
+@pytest.mark.parametrize("mode", [["--headline-only"], ["--workload", "sweep", "--scaling", "strong"], []])
 def test_bench_launches_its_own_ranks(mode):
     """`python bench.py --gpus 2` started bare (no torch.distributed.run around it, no WORLD_SIZE): it starts its two
     ranks itself, before any HIP call of its own, and rank 0 prints the line (PANTR_BENCH_REHEARSAL: both ranks on
@@ -54,6 +54,16 @@ def test_bench_launches_its_own_ranks(mode):
     else:
         assert line["scaling"] == "weak" and line["config"]["converged"] == 600
         assert line["config"]["max_abs_dev_from_recorded_closed_loop"] == 0.0
+    if mode == []:
+        # default flags, several ranks (what the driver's scaling run starts): the weak headline carries the two batches
+        # that do shard, dealt to the ranks - BASELINE.json configs[3] and configs[4] - as `strong`
+        assert set(line["strong"]) == {"sweep", "stress"}
+        for wl, instances in (("sweep", 720), ("stress", 1024)):
+            rec = line["strong"][wl]
+            assert rec["scaling"] == "strong" and rec["instances"] == instances and rec["gathered_equals_unsharded"] is True
+            assert rec["value"] > 0 and 0 < rec["bound"]["slowest_instance_in_kernel_ms"] <= rec["bound"]["ms_per_pass"] * 1.05
+    else:
+        assert "strong" not in line or mode[0] == "--workload"
 
 
 def test_bench_line_contract():

@@ -520,3 +520,58 @@ def test_kernel_name_follows_method_speculation_and_batch_size():
     b = pa.PantrBatch("quadcopter", 70, 2, opts=tuple(pa.DODO_PANTR_OPTS) + ("speculation=off",))
     assert b.kernel_name() == "pantr_alm_kernel<QuadModelT<false>, 0, 0, 0>"         # n = 280: the generic passes
     b.close()
+
+
+def test_a_helper_that_is_late_in_the_middle_of_a_solve_changes_nothing_but_time():
+    """Two wavefronts per instance with more workgroups than the SIMDs can run side by side (768 instances: three per
+    CU, helpers and solvers sharing SIMDs) and a patience short enough to run out in the middle of solves
+    (`spec_patience=50us`, `5us`): wherever a solver wavefront stops waiting it tells its helper to stop, evaluates the
+    step itself and goes on alone - the solutions and counters are those of `speculation=off`, `spec_timeouts` says how
+    often it happened, every workgroup ends (the launch returns)."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_hanging_chain_N60_warm300.npz"))
+    x0 = np.vstack([d["x0"], d["x0"], d["x0"][:168]])
+    u0 = np.vstack([d["guess"], np.zeros_like(d["guess"]), d["guess"][:168]])
+    assert len(x0) == 768
+    base = tuple(pa.DODO_PANTR_OPTS) + ("alm.max_time=5s",)
+    b = pa.PantrBatch("hanging_chain", 60, 768, opts=base + ("speculation=off",))
+    u_off, st_off = b.solve(x0, u0)
+    b.close()
+    assert np.all(st_off["status"] == 1)
+    timeouts = {}
+    for patience in ("50us", "5us"):
+        b = pa.PantrBatch("hanging_chain", 60, 768, opts=base + ("speculation=on", f"spec_patience={patience}"))
+        assert "spec" in b.kernel_name(768)
+        u, st = b.solve(x0, u0)
+        b.close()
+        assert np.array_equal(u, u_off)
+        for k in ("status", "iterations", "cg_iterations", "accepted", "rejected", "qub_backtracks", "n_psi", "n_psi_grad_psi",
+                  "n_grad_L", "n_hess_psi_prod", "n_hess_psi_prod_calls", "n_prox_grad_step", "eps", "final_psi", "final_fbe"):
+            assert np.array_equal(st[k], st_off[k]), (patience, k)
+        timeouts[patience] = int((st["spec_timeouts"] > 0).sum())
+    assert timeouts["5us"] > 0   # (a model value takes a product's 40 us: a helper cannot be that quick)
+
+
+def test_non_finite_instances_end_like_the_oracle(rng):
+    """Instances driven to non-finite values - two chain points on top of each other (a spring of length zero: L / r is
+    infinite), a NaN in the initial guess, an infinite state - end with the oracle's status, counters and solution slot,
+    and their neighbours in the batch are not touched.  (The lane constants that replaced selects in the tangent sweeps spread a
+    NaN over more lanes of a product than the oracle's loops do; every sum over a vector is NaN either way.)"""
+    N, B = 12, 5
+    x0 = np.tile(disturbed_state(), (B, 1))
+    u0 = random_inputs(rng, B, N, -0.3, 0.3)
+    x0[1, 3:6] = x0[1, 0:3]            # point 1 on point 0
+    u0[2, 7] = np.nan
+    x0[3, 40] = np.inf
+    b = pa.PantrBatch("hanging_chain", N, B, opts=pa.DODO_PANTR_OPTS)
+    u, st = b.solve(x0, u0)
+    b.close()
+    for i in range(B):
+        u_o, st_o, _ = ob.solve(N, x0[i], u0[i])
+        assert st["status"][i] == st_o["status"], (i, st["status"][i], st_o["status"])
+        for k in ("iterations", "n_psi", "n_psi_grad_psi", "n_grad_psi", "n_grad_L", "n_hess_psi_prod", "cg_iterations"):
+            assert st[k][i] == st_o[k], (i, k)
+        assert np.array_equal(u[i], u_o, equal_nan=True)
+    # (what they end as is the specification's business: fmin / fmax drop a NaN, so the stop criterion of such an instance
+    # is tiny and it "converges" in one iteration with a cost that is not a number - on both sides alike)
+    assert st["status"][0] == 1 and st["status"][4] == 1 and np.all(np.isfinite(st["final_psi"][[0, 4]]))
+    assert not np.any(np.isfinite(st["final_psi"][1:4]))

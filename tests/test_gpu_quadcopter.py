@@ -146,8 +146,11 @@ def test_speculation_changes_nothing_but_time(rng, problem, N):
     x0 = np.vstack([ob.quad_initial_state(), ob.quad_initial_state() + 0.02 * rng.standard_normal((B - 1, 9))])
     u0 = np.tile(ob.quad_initial_guess(N), (B, 1))
     res = {}
-    for mode in ("on", "off", "late"):
-        extra = ["speculation=on", "spec_patience=0"] if mode == "late" else [f"speculation={mode}"]
+    for mode in ("on", "off", "late", "midway"):
+        # "midway": a patience that runs out in the middle of a solve, while the helper is inside a sweep that writes
+        # yhat to the prox iterate's slot - the solver goes on only once the helper has said that it ended
+        extra = {"late": ["speculation=on", "spec_patience=0"], "midway": ["speculation=on", "spec_patience=2us"]}.get(
+            mode, [f"speculation={mode}"])
         b = pa.PantrBatch(problem, N, B, opts=quad_opts(problem) + extra)
         assert ("spec" in b.kernel_name()) == (mode != "off")
         res[mode] = b.solve_al(x0, u0)
@@ -164,6 +167,11 @@ def test_speculation_changes_nothing_but_time(rng, problem, N):
     assert np.all(s2["spec_timeouts"] >= 1) and np.all(s2["spec_timeouts"] <= 2) and np.all(s1["spec_timeouts"] == 0)
     for key in ("status", "iterations", "outer_iterations", "cg_iterations", "n_hess_psi_prod", "n_psi", "n_grad_L", "eps"):
         assert np.array_equal(s2[key], s0[key]), key
+    u3, y3, s3 = res["midway"]
+    assert np.array_equal(u3, u0_) and np.array_equal(y3, y0_)
+    assert N < 60 or s3["spec_timeouts"].sum() >= 1    # (at N = 60 a helper's sweeps take tens of microseconds)
+    for key in ("status", "iterations", "outer_iterations", "cg_iterations", "n_hess_psi_prod", "n_psi", "n_grad_L", "eps", "delta"):
+        assert np.array_equal(s3[key], s0[key]), key
     assert np.all(s1["status"] == 1) and s1["rejected"].sum() > 0   # (rejections happened: results were taken)
     b = pa.PantrBatch(problem, N, 4096, opts=quad_opts(problem))
     assert "spec" not in b.kernel_name()                             # auto: large batches keep one wavefront
@@ -214,6 +222,36 @@ def test_config3_realistic_quadcopter_horizon_60():
     for k in keys + ("status",):
         assert st[k].tolist() == [s[k] for s in stats_o], k
     assert st["eps"].tolist() == [s["eps"] for s in stats_o] and st["delta"].tolist() == [s["delta"] for s in stats_o]
+
+
+def test_config1_quadcopter_horizon_12_at_its_bench_size():
+    """BASELINE.json configs[0] at the size bench.py times it: quadcopter N = 12 (n = 48, m = 52), the 60 warm
+    closed-loop steps of `benchmark-mpc-driver quadcopter 12 ss2p method=pantr num_sim=60 warm=true` with the options
+    of dodo.py:12-33,97-100.  The device closed loop equals the oracle's step for step - states, solutions,
+    multipliers, every counter - and the 60 recorded steps replayed as ONE batch (what the bench measures) reproduce
+    the oracle's u, y, eps, delta and counters."""
+    problem, N, num_sim = "quadcopter", 12, 60
+    keys = ("status", "iterations", "outer_iterations", "cg_iterations", "n_hess_psi_prod", "n_hess_psi_prod_calls", "n_psi",
+            "n_psi_grad_psi", "n_grad_L", "n_prox_grad_step", "accepted", "rejected", "qub_backtracks",
+            "inner_convergence_failures")
+    o = ob.quad_mpc_full(problem, N, num_sim, True)
+    b = pa.PantrBatch(problem, N, num_sim, opts=quad_opts(problem))
+    assert (b.n, b.m) == (48, 52)
+    states, inputs, stats, rec = b.mpc(num_sim, True, np.zeros((1, 4)), num_dist=0, record=True)
+    assert np.array_equal(states[:, 0], o["states"]) and np.array_equal(inputs[:, 0], o["inputs"])
+    assert np.array_equal(rec["guess_u"][:, 0], o["guess_u"]) and np.array_equal(rec["guess_y"][:, 0], o["guess_y"])
+    assert np.array_equal(rec["multipliers"][:, 0], o["multipliers"])
+    assert np.all(stats["status"][:, 0] == 1) and np.all(stats["eps"] <= 1e-8) and np.all(stats["delta"] <= 1e-8)
+    for k in keys:
+        assert stats[k][:, 0].tolist() == [s[k] for s in o["stats"]], k
+    # the replay: all 60 steps in one launch (the short-horizon kernel, two wavefronts per instance)
+    assert b.kernel_name(num_sim) == "pantr_alm_spec_kernel<QuadModelT<false>, 1, 1>"
+    u, y, st = b.solve_al(o["states"][:num_sim], o["guess_u"], o["guess_y"])
+    b.close()
+    assert np.array_equal(u, o["inputs"]) and np.array_equal(y, o["multipliers"])
+    for k in keys:
+        assert st[k].tolist() == [s[k] for s in o["stats"]], k
+    assert st["eps"].tolist() == [s["eps"] for s in o["stats"]] and st["delta"].tolist() == [s["delta"] for s in o["stats"]]
 
 
 @pytest.mark.parametrize("warm", [True, False])
