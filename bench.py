@@ -45,7 +45,7 @@ HORIZON = 60
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 HBM_COPY_GUIDE_GBS = 6290.0  # MI355X_MICROARCH.md:36: 6.29 TB/s measured with a float4 copy (79 % of the spec peak)
 FIXTURE = os.path.join(ROOT, "tests", "golden", "mpc_hanging_chain_N60_warm300.npz")
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 # PMC summary of the headline command (scripts/profile.sh + scripts/summarize_profiles.py)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_summary.json")
 # published mean solver time per MPC step, alpaqa PANTR, unstated CPU, 1 thread
@@ -99,6 +99,8 @@ def measured_workload_traffic(name, instances):
             return None, src
         src["traffic_over_algorithmic"] = d["traffic_over_algorithmic"]
         src["profiled_kernel_ms"] = d["kernel_trace"]["avg_ms"]
+        if "valu_issue" in d:  # the occupancy / issue counters of the same command (SQ=1 scripts/traffic_profile.sh)
+            src["valu_issue"] = d["valu_issue"]
         return float(d["hbm_traffic_bytes_per_launch"]["total"]), src
     except (OSError, KeyError, ValueError) as e:
         src["refused"] = f"no usable summary ({type(e).__name__})"
@@ -312,11 +314,11 @@ def extra_configs(torch, pa, dev, local_rank, cores, peak_measured, with_cpu):
     # configs[2]
     one("realistic_quadcopter", [workloads.closed_loop_batch("realistic_quadcopter", 60, device=local_rank)],
         "BASELINE.json configs[2]: realistic_quadcopter N=60 (n=240, m=244), all 60 warm + 60 cold time steps as one "
-        "batch of 120 ALM solves (dodo.py:96-105)")
+        "batch of 120 ALM solves (dodo.py:96-105)", traffic_name="realistic_quadcopter")
     # configs[0]: the reference's CPU-runnable case, here as the replay of its one warm run
     one("quadcopter_N12", [workloads.closed_loop_batch("quadcopter", 12, starts=(True,), device=local_rank)],
         "BASELINE.json configs[0]: quadcopter N=12 (n=48, m=52), the 60 time steps of one warm-started MPC run "
-        "(num_sim=60 warm=true num_dist=0 solver.max_iter=250) as one batch")
+        "(num_sim=60 warm=true num_dist=0 solver.max_iter=250) as one batch", traffic_name="quadcopter_N12")
     # configs[4] on ONE GPU: all 1024
     one("stress_N120", [workloads.stress_batch(1024, device=local_rank)],
         "BASELINE.json configs[4] on one GPU: hanging_chain N=120 (n=360), 1024 synthetic cold instances in one launch",

@@ -33,20 +33,27 @@ namespace {
 constexpr int ALM_NJ = 4;
 /// quadcopter: horizons up to this run the kernels that carry the tape product for short horizons (lane = (component, stage)).
 constexpr int ALM_SHORT_STAGES = ScalarALProblem<QuadModelT<false>>::SHORT_STAGES;
-/// The same for the hanging chain's PANTR kernels: instantiated for the horizons whose n = 3 N fills exactly
-/// CHAIN_NJ_A (N = 43..64: the bench batch) or CHAIN_NJ_B (N = 107..128: the stress batch) rows of 64; other
-/// horizons run the generic passes (last template argument 0).
-constexpr int CHAIN_NJ_A = 3, CHAIN_NJ_B = 6;
+/// The same for the hanging chain's PANTR kernels: the elements of an n-vector a lane owns, nj = ceil(3 N / 64), as a
+/// compile-time constant for every horizon up to N = 128 (nj = 1..6: N <= 21, 42, 64, 85, 106, 128 - the horizon sweep of
+/// BASELINE.json configs[3] runs nj = 1, 2, 3, the bench batch 3, the stress batch 6); longer horizons run the generic
+/// passes (last template argument 0).
+constexpr int CHAIN_NJ_MAX = 6;
 template <class F>
 auto with_chain_nj(int nj, F &&f) {
 #ifdef PANTR_CHAIN_GENERIC_PASSES // development switch (A/B): every horizon through the generic passes
     nj = 0;
 #endif
-    if (nj == CHAIN_NJ_A)
-        return f(std::integral_constant<int, CHAIN_NJ_A>{});
-    if (nj == CHAIN_NJ_B)
-        return f(std::integral_constant<int, CHAIN_NJ_B>{});
-    return f(std::integral_constant<int, 0>{});
+    switch (nj) {
+#ifndef PANTR_DEV_FEW_KERNELS // development builds (make DEV=1: two minutes less): only the bench and the stress batch's kernels
+    case 1: return f(std::integral_constant<int, 1>{});
+    case 2: return f(std::integral_constant<int, 2>{});
+    case 4: return f(std::integral_constant<int, 4>{});
+    case 5: return f(std::integral_constant<int, 5>{});
+#endif
+    case 3: return f(std::integral_constant<int, 3>{});
+    case 6: return f(std::integral_constant<int, 6>{});
+    default: return f(std::integral_constant<int, 0>{});
+    }
 }
 
 thread_local std::string g_last_error;
@@ -581,13 +588,15 @@ const char *pantr_version(void) {
 #define PANTR_STR2(x) #x
 #define PANTR_STR(x) PANTR_STR2(x)
 #if defined(PANTR_PHASE_TIMING) && defined(PANTR_REST_TIMING) && defined(PANTR_REST_SPLIT)
-    return "pantr-mi355x 0.4 (gfx950) +phase-timing +rest-timing +rest-split=" PANTR_STR(PANTR_REST_SPLIT);
+    return "pantr-mi355x 0.5 (gfx950) +phase-timing +rest-timing +rest-split=" PANTR_STR(PANTR_REST_SPLIT);
 #elif defined(PANTR_PHASE_TIMING) && defined(PANTR_REST_TIMING)
-    return "pantr-mi355x 0.4 (gfx950) +phase-timing +rest-timing";
+    return "pantr-mi355x 0.5 (gfx950) +phase-timing +rest-timing";
 #elif defined(PANTR_PHASE_TIMING)
-    return "pantr-mi355x 0.4 (gfx950) +phase-timing";
+    return "pantr-mi355x 0.5 (gfx950) +phase-timing";
+#elif defined(PANTR_DEV_FEW_KERNELS) || defined(PANTR_VMCNT_CONSERVATIVE) || defined(PANTR_CHAIN_GENERIC_PASSES)
+    return "pantr-mi355x 0.5 (gfx950) +development-switches"; // (same results; other kernels or waits than the product build)
 #else
-    return "pantr-mi355x 0.4 (gfx950)";
+    return "pantr-mi355x 0.5 (gfx950)";
 #endif
 }
 const char *pantr_source_hash(void) {
@@ -1088,13 +1097,23 @@ const char *pantr_batch_kernel_name(const pantr_batch_t *b, int32_t B) {
             return realistic ? "pantr_alm_kernel<QuadModelT<true>, 0, 4, 0>" : "pantr_alm_kernel<QuadModelT<false>, 0, 4, 0>";
         return names[realistic ? 1 : 0][method];
     }
-    // (the last template argument: the compile-time elements per lane, CHAIN_NJ_A | CHAIN_NJ_B, or 0 = generic passes)
+    // (the last template argument: the compile-time elements per lane, 1..CHAIN_NJ_MAX, or 0 = generic passes)
     if (method == 0) {
-        static const char *spec[3] = {"pantr_solve_spec_kernel<ChainModel, 0>", "pantr_solve_spec_kernel<ChainModel, 3>",
-                                      "pantr_solve_spec_kernel<ChainModel, 6>"};
-        static const char *solo[3] = {"pantr_solve_kernel<ChainModel, 0, 0>", "pantr_solve_kernel<ChainModel, 0, 3>",
-                                      "pantr_solve_kernel<ChainModel, 0, 6>"};
-        const int v = b->nj == CHAIN_NJ_A ? 1 : b->nj == CHAIN_NJ_B ? 2 : 0;
+        static const char *spec[CHAIN_NJ_MAX + 1] = {
+            "pantr_solve_spec_kernel<ChainModel, 0>", "pantr_solve_spec_kernel<ChainModel, 1>", "pantr_solve_spec_kernel<ChainModel, 2>",
+            "pantr_solve_spec_kernel<ChainModel, 3>", "pantr_solve_spec_kernel<ChainModel, 4>", "pantr_solve_spec_kernel<ChainModel, 5>",
+            "pantr_solve_spec_kernel<ChainModel, 6>"};
+        static const char *solo[CHAIN_NJ_MAX + 1] = {
+            "pantr_solve_kernel<ChainModel, 0, 0>", "pantr_solve_kernel<ChainModel, 0, 1>", "pantr_solve_kernel<ChainModel, 0, 2>",
+            "pantr_solve_kernel<ChainModel, 0, 3>", "pantr_solve_kernel<ChainModel, 0, 4>", "pantr_solve_kernel<ChainModel, 0, 5>",
+            "pantr_solve_kernel<ChainModel, 0, 6>"};
+        int v = b->nj >= 1 && b->nj <= CHAIN_NJ_MAX ? b->nj : 0;
+#ifdef PANTR_CHAIN_GENERIC_PASSES
+        v = 0;
+#endif
+#ifdef PANTR_DEV_FEW_KERNELS
+        v = (v == 3 || v == 6) ? v : 0;
+#endif
         return use_speculation(b, B) ? spec[v] : solo[v];
     }
     return method == 1 ? "pantr_solve_kernel<ChainModel, 1, 0>" : "pantr_solve_kernel<ChainModel, 2, 0>";

@@ -574,12 +574,12 @@ struct WaveProblem {
             if (STORE)
                 M::traj_store(L, X + (size_t)k * M::TRAJ_DOUBLES, s);
             M::cost_accumulate(L, s, uc, true, acc);
-            s = M::rk4(L, s, uc);
+            s = M::rk4(L, s, uc, xs());
         }
         if (STORE)
             M::traj_store(L, X + (size_t)N * M::TRAJ_DOUBLES, s);
         M::cost_accumulate(L, s, 0.0, false, acc);
-        return M::cost_total(L, acc);
+        return M::cost_total(L, acc, xs());
     }
 
     /// psi and grad psi (forward sweep, then adjoint sweep over the stored trajectory).
@@ -648,31 +648,21 @@ struct WaveProblem {
         asm volatile("s_waitcnt vmcnt(%0) expcnt(6)" ::"n"(N_) : "memory");
 #endif
     }
-    /// The lanes the tangent sweeps run on: both substage chains side by side (chain_model.hip.h, PairLane), or -
-    /// -DPANTR_CHAIN_ROW_PRODUCT, the form of rounds 2-4 kept for A/B - interleaved on the rows of `Lane`.
-#ifdef PANTR_CHAIN_ROW_PRODUCT
+    /// The lanes the tangent sweeps run on (chain_model.hip.h: both substage chains side by side, as in every sweep).
     using TanLane = Lane;
-    static constexpr int TAN_ST_STORES = 4; ///< d_t stores of a forward stage: one per substage
-#else
-    using TanLane = typename M::PairLane;
-    static constexpr int TAN_ST_STORES = M::PAIR_ST_STORES_PER_STAGE; ///< one per substage pair
-#endif
+    static constexpr int TAN_ST_STORES = M::PAIR_ST_STORES_PER_STAGE; ///< d_t stores of a forward stage: one per substage pair
     // What the waits of the two-stages-ahead sweeps may leave in flight, from ONE place: the vector-memory operations
     // a stage issues behind its request (the model names what its functions issue).
     static constexpr int FWD_STAGE_STORES  = TAN_ST_STORES + 1;     ///< + the tangent-state row (xt_store)
     static constexpr int FWD_ROW_TRANSFERS = M::FWD_ROW_TRANSFERS;  ///< prefetch_fwd<true>: the K rows of a stage
     static constexpr int REV_ROW_TRANSFERS = M::REV_ROW_TRANSFERS;  ///< prefetch_rev_xt: K, M, d_t rows and the tangent-state row
     /// The lanes of a product, built where the product starts (the lane index passes through an empty asm: the lane
-    /// constants are then recomputed per product - a few dozen integer operations - instead of living in registers,
-    /// and spilling, through the whole solve).
+    /// constants of the tangent sweeps - byte offsets into the landing buffers, masks as doubles - are then recomputed per
+    /// product, a few dozen integer operations, instead of living in registers, and spilling, through the whole solve).
     __device__ __forceinline__ TanLane tan_lane() const {
-#ifdef PANTR_CHAIN_ROW_PRODUCT
-        return L;
-#else
         int lane = L.l;
         asm volatile("" : "+v"(lane));
         return TanLane(lane);
-#endif
     }
     __device__ __forceinline__ void hess_prod_tape_d2(const double *v, double *Hv) const {
         wave_sync();
@@ -690,8 +680,9 @@ struct WaveProblem {
         // K from this sweep, M requested a product ahead (prime), the tangent spring vectors and the tangent-state
         // row of stage N - 1 written by the last stage straight into its landing buffer.
         State s_t{0.0, 0.0};
-        auto stage_fwd = [&](int k, char *cur, char *nxt2, char *prev, auto last) {
-            constexpr bool LAST = decltype(last)::value;
+        // `kind`: 0 = a stage that is not the last, 1 = the last stage of N > 1 stages, 2 = the only stage (N = 1)
+        auto stage_fwd = [&](int k, char *cur, char *nxt2, char *prev, auto kind) {
+            constexpr bool LAST = decltype(kind)::value != 0, ONLY = decltype(kind)::value == 2;
             // stage k's K rows have landed in `cur`; in flight behind them may be: stage k+1's rows (FWD_ROW_TRANSFERS
             // operations, issued at the start of stage k-1) and the FWD_STAGE_STORES stores stage k-1 issued after them
             if constexpr (!LAST) {
@@ -699,11 +690,10 @@ struct WaveProblem {
                     wait_vmem_but<FWD_ROW_TRANSFERS>(); // stage 1's rows (a stage that is not the last: N > 1)
                 else
                     wait_vmem_but<FWD_ROW_TRANSFERS + FWD_STAGE_STORES>();
+            } else if constexpr (ONLY) {
+                wait_vmem();
             } else {
-                if (k == 0)
-                    wait_vmem(); // N = 1
-                else
-                    wait_vmem_but<FWD_STAGE_STORES>(); // nothing was requested after its rows but stage k-1's stores
+                wait_vmem_but<FWD_STAGE_STORES>(); // nothing was requested after its rows but stage k-1's stores
             }
             if constexpr (!LAST) {
                 // FWD_ROW_TRANSFERS operations either way: the K rows of stage k + 2, or - stage N - 2, which has none
@@ -739,24 +729,30 @@ struct WaveProblem {
         if (!primed)
             prime();
         {
-            constexpr std::false_type F{};
-            constexpr std::true_type LASTT{};
+            constexpr std::integral_constant<int, 0> F{};
+            constexpr std::integral_constant<int, 1> LASTT{};
             const int NL = N - 1; // the last stage by itself: its landing buffer is a constant in each of the three cases
+            if (NL == 0) {
+                stage_fwd(0, tbuf0, tbuf2, tbuf2, std::integral_constant<int, 2>{});
+            } else {
             // three stages per trip, straight through (a lone wavefront pays some twenty cycles for every taken branch:
             // one stage per trip with a three-way branch on k mod 3 cost the memory-bound launches 6-9 %)
-            for (int k = 0; k < NL; k += 3) {
+            int k = 0;
+            do { // (NL >= 1: at least one stage runs before the last one - also in the compiled control flow)
                 stage_fwd(k, tbuf0, tbuf2, tbuf2, F);
                 if (k + 1 < NL)
                     stage_fwd(k + 1, tbuf1, tbuf0, tbuf0, F);
                 if (k + 2 < NL)
                     stage_fwd(k + 2, tbuf2, tbuf1, tbuf1, F);
-            }
+                k += 3;
+            } while (k < NL);
             if (NL % 3 == 0)
                 stage_fwd(NL, tbuf0, tbuf2, tbuf2, LASTT);
             else if (NL % 3 == 1)
                 stage_fwd(NL, tbuf1, tbuf0, tbuf0, LASTT);
             else
                 stage_fwd(NL, tbuf2, tbuf1, tbuf1, LASTT);
+            }
         }
         // (nothing to wait for here: a wavefront's LDS accesses execute in order, and so do its vector-memory
         // operations - the rows the adjoint sweep requests were stored by this wavefront at least a stage earlier)
@@ -1879,14 +1875,19 @@ __device__ __forceinline__ InnerResult inner_solve(PB &pb, const KernelParams &P
 // ---------------------------------------------------------------------------------------
 // The solve kernel for problems without general constraints (m = 0: ALM = one inner solve)
 // ---------------------------------------------------------------------------------------
-/// How far ahead the products of the two PANTR kernels of the hanging chain request their tape rows.  One
-/// wavefront per instance is what large batches run: a thousand and more wavefronts stream their tapes at once
-/// and the memory system delivers bytes-in-flight / latency - two stages ahead (N = 120, 1024 instances: 704 ->
-/// 521 ms per pass; the bench batch tiled eight times 19.9 -> 21.3 k steps/s).  Two wavefronts per instance is
-/// what small batches run, where a product is bound by its own instructions and the second stage in flight only
-/// costs some (67.6 -> 74.9 ms on the 600-instance bench batch): one stage ahead.  profiles/r04_prefetch_depth.txt.
+/// How far ahead the products of the two PANTR kernels of the hanging chain request their tape rows: two stages, both.
+/// One wavefront per instance is what large batches run: a thousand and more wavefronts stream their tapes at once and
+/// the memory system delivers bytes-in-flight / latency (round 4: N = 120, 1024 instances: 704 -> 521 ms per pass).  Two
+/// wavefronts per instance is what small batches run; in round 4 a stage of a product took 870 cycles there, one stage
+/// ahead covered a trip to the Infinity Cache and the second stage in flight only cost instructions (67.6 -> 74.9 ms).
+/// With both substage chains side by side (round 5) a stage is 640 / 870 cycles and one stage ahead no longer covers the
+/// trip while the batch is busy: two stages ahead takes the mean solve of the bench batch from 23.2 to 21.2 ms (the pass,
+/// which ends on one straggler running alone out of L2, from 54.6 to 53.9 ms).  LDS of a workgroup: 49 KiB (three per CU).
 constexpr int CHAIN_SOLVE_PREFETCH_DEPTH = 2;
-constexpr int CHAIN_SPEC_PREFETCH_DEPTH  = 1;
+#ifndef PANTR_SPEC_DEPTH // development switch (A/B)
+#define PANTR_SPEC_DEPTH 2
+#endif
+constexpr int CHAIN_SPEC_PREFETCH_DEPTH  = PANTR_SPEC_DEPTH;
 template <class M, int METHOD, int NJ = 0>
 using SolveProblemT = WaveProblem<M, METHOD == 0, false, METHOD == 0 ? CHAIN_SOLVE_PREFETCH_DEPTH : 1, NJ>;
 template <class M, int NJ = 0>
@@ -2146,9 +2147,10 @@ __global__ __launch_bounds__(WAVE) void pantr_simulate_kernel(int B, const doubl
     if (inst >= B)
         return;
     typename M::Lane L(lane);
+    __shared__ double xs[M::PAIR_XS_DOUBLES]; // exchange rows of the component gather
     auto s    = M::load_x0(L, x + (size_t)inst * M::nx);
     double uc = M::load_input(L, u + (size_t)inst * u_stride);
-    auto r    = M::rk4(L, s, uc);
+    auto r    = M::rk4(L, s, uc, xs);
     M::store_x(L, xn + (size_t)inst * M::nx, r);
 }
 

@@ -10,7 +10,8 @@ the request for the rows the stage is about to read (they complete in order).  I
 marked wait before this one, so the check is: on EVERY path through the control-flow graph from the nearest earlier
 synchronisation point - a marked wait, a full `s_waitcnt vmcnt(0)`, or the kernel's entry - to the marked wait, at least n
 vector-memory instructions (LDS-DMA transfers, global loads and stores, scratch accesses) are issued; a path from a
-full drain (or the entry) with NO such instruction at all is accepted as well (nothing is in flight then).  The minimum
+full drain (or the entry) WITHOUT ANY LDS-DMA REQUEST on it is accepted as well (the rows a wait is for are requested
+by LDS-DMA: with no such request since the drain they were requested before it, and have landed).  The minimum
 over the paths is taken (round 4 took, at a join, the predecessor with more operations: a path with fewer was never
 looked at).  Second check, all PANTR kernels of the chain: no stage loop of a product holds a full wait right behind
 an LDS-DMA request (the compiler puts one in front of an LDS read it cannot tell from the landing buffers).
@@ -201,12 +202,13 @@ def check_marked_waits(name, ins, addr):
         checked += 1
         # Shortest backward path (weight 1 per vector-memory instruction) to the nearest synchronisation point.  A search
         # state is "control is about to reach instruction i, and on the rest of the way to the wait these facts hold there".
-        heap, dist, worst, tick = [(0, 0, w, ())], {}, None, 0
+        # (`dma`: the path holds an LDS-DMA request - part of the state: a path without one is judged differently below)
+        heap, dist, worst, tick = [(0, 0, w, (), False)], {}, None, 0
         while heap:
-            c, _, i, know = heapq.heappop(heap)
-            if dist.get((i, know), 1 << 30) <= c:
+            c, _, i, know, dma = heapq.heappop(heap)
+            if dist.get((i, know, dma), 1 << 30) <= c:
                 continue
-            dist[(i, know)] = c
+            dist[(i, know, dma)] = c
             for p, taken in preds[i]:
                 facts = dict(know)
                 op = ins[p].split(" ", 1)[0]
@@ -224,14 +226,16 @@ def check_marked_waits(name, ins, addr):
                 if MARKED.match(ins[p]):
                     ok, kind = cp >= n, "the marked wait before it"
                 elif ins[p] == "s_waitcnt vmcnt(0)" or ins[p].startswith("s_waitcnt vmcnt(0) "):
-                    ok, kind = cp >= n or cp == 0, "a full wait"
+                    # everything older than a full wait has landed: the rows this wait is for can only be in flight if
+                    # they were requested on the way from there - a way without any LDS-DMA request is safe
+                    ok, kind = cp >= n or not dma, "a full wait"
                 elif not preds[p]:
-                    ok, kind = cp >= n or cp == 0, "the kernel's entry"
+                    ok, kind = cp >= n or not dma, "the kernel's entry"
                 else:
                     cp += 1 if VMEM.match(ins[p]) else 0
                     if cp < n:  # (a path that already has its n operations needs no further look)
                         tick += 1
-                        heapq.heappush(heap, (cp, tick, p, tuple(sorted(facts.items()))))
+                        heapq.heappush(heap, (cp, tick, p, tuple(sorted(facts.items())), dma or ins[p].startswith("global_load_lds_")))
                     continue
                 if not ok and facts and not feasible(ins, preds, p, facts):
                     continue  # what the path assumes is contradicted by an assignment further up, whichever way it came

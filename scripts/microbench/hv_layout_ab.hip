@@ -13,13 +13,13 @@
 // and must produce the same bits: the program compares the final tangent state, every stored d_t, the
 // product's output vector and the final adjoint, then prints shader cycles per stage for each sweep.
 //   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -o hv_layout_ab hv_layout_ab.hip && ./hv_layout_ab
-#include "../../pantr-cdc2023-experiments_amd/csrc/chain_model.hip.h"
+#include "chain_row_layout.hip.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 using namespace pantr;
-using M = ChainModel;
+using M = ChainRowModel;
 
 constexpr int NST   = 60;                 // stages per sweep
 constexpr int RING  = 8;                  // stages of tape kept in LDS

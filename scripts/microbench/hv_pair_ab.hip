@@ -13,13 +13,13 @@
 // second chain to fill a gather's latency with, so the shorter one should win).
 // Prints shader cycles per stage and checks bit equality of the final tangent state, every stored d_t, Hv and the
 // final adjoint.   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -o hv_pair_ab hv_pair_ab.hip
-#include "../../pantr-cdc2023-experiments_amd/csrc/chain_model.hip.h"
+#include "chain_row_layout.hip.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 using namespace pantr;
-using M = ChainModel;
+using M = ChainRowModel;
 
 constexpr int NST   = 60;
 constexpr int RING  = 8;

@@ -8,7 +8,7 @@ ratio to the algorithmic bytes the workload script printed.  usage: summarize_tr
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, workloads = sys.argv[1], sys.argv[2:]
-KERNEL = "pantr_solve_"
+KERNELS = ("pantr_solve_", "pantr_alm_")  # the solve kernels of the hanging chain / of the quadcopter family
 
 
 def newest(pattern):
@@ -22,16 +22,38 @@ for w in workloads:
     run = json.loads(line)
     out = {"tag": tag, "workload": w, "command": f"python3 scripts/traffic_workload.py {w}", "run": run}
     for r in csv.DictReader(open(newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")))):
-        if KERNEL in r["Name"]:
+        if any(k in r["Name"] for k in KERNELS) and "eval" not in r["Name"]:
             out["kernel_trace"] = {"kernel": r["Name"], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                                    "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6}
     pmc = {}
     for name in ("pmc_fetch", "pmc_write"):
         f = newest(os.path.join(src, name, "*", "*_counter_collection.csv"))
-        rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in KERNELS) and "eval" not in r["Kernel_Name"]]
         vals = [float(r["Counter_Value"]) for r in rows]
         pmc[rows[0]["Counter_Name"]] = {"per_launch_KiB": sum(vals) / len(vals), "launches": len(vals)}
+    # the occupancy / issue counters, where the passes were taken (SQ=1 scripts/traffic_profile.sh ...)
+    for name in ("pmc_sq", "pmc_sq2"):
+        f = newest(os.path.join(src, name, "*", "*_counter_collection.csv"))
+        if not f:
+            continue
+        rows = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in KERNELS) and "eval" not in r["Kernel_Name"]]
+        for cname in sorted({r["Counter_Name"] for r in rows}):
+            vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == cname]
+            # (one row per dispatch and counter; rocprofv3 sums a counter over the chip's shader engines)
+            pmc[cname] = {"per_launch": sum(vals) / len(vals), "launches": len(vals)}
     out["pmc"] = pmc
+    if "SQ_INSTS_VALU" in pmc and "SQ_BUSY_CYCLES" in pmc:
+        ms_ = out["kernel_trace"]["avg_ms"]
+        valu, waves = pmc["SQ_INSTS_VALU"]["per_launch"], pmc["SQ_WAVES"]["per_launch"]
+        out["valu_issue"] = {
+            "valu_instructions_per_wavefront": valu / waves,
+            # a 64-wide VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs; clock from the wave-cycle counters is not
+            # available here, so the fraction is stated against the kernel's duration at 2.4 GHz
+            "simd_issue_slots_used_frac": 4.0 * valu / (256 * 4 * 2.4e9 * ms_ * 1e-3),
+            "wait_any_over_busy": pmc["SQ_WAIT_ANY"]["per_launch"] / pmc["SQ_BUSY_CYCLES"]["per_launch"] if "SQ_WAIT_ANY" in pmc else None,
+        }
+        if "SQ_WAVE_CYCLES" in pmc:
+            out["valu_issue"]["wave_cycles_per_valu_instruction"] = pmc["SQ_WAVE_CYCLES"]["per_launch"] / valu
     rd, wr = 2 * pmc["FETCH_SIZE"]["per_launch_KiB"] * 1024, pmc["WRITE_SIZE"]["per_launch_KiB"] * 1024
     ms = out["kernel_trace"]["avg_ms"]
     alg = run["algorithmic_bytes_per_launch"]
@@ -42,7 +64,7 @@ for w in workloads:
     out["traffic_GBps"] = (rd + wr) / (ms * 1e-3) / 1e9
     out["frac_of_8TBps_algorithmic"] = alg / (ms * 1e-3) / 8e12
     out["frac_of_8TBps_traffic"] = (rd + wr) / (ms * 1e-3) / 8e12
-    out["bytes_per_product"] = (rd + wr) / run["n_hess_psi_prod_total"]
+    out["bytes_per_product"] = (rd + wr) / max(run["n_hess_psi_prod_total"], 1)
     dst = os.path.join(ROOT, "profiles", f"{tag}_{w}_traffic.json")
     json.dump(out, open(dst, "w"), indent=1)
     print(w, f"kernel {ms:.1f} ms, read {rd/1e9:.1f} GB + write {wr/1e9:.1f} GB = {(rd+wr)/1e9:.1f} GB per launch "

@@ -4,6 +4,8 @@ rocprofv3 passes of scripts/traffic_profile.sh run (kernel trace, FETCH_SIZE, WR
 
     traffic_workload.py stress [opt=value ...]   BASELINE.json configs[4]: N = 120, 1024 synthetic cold instances
     traffic_workload.py tile8  [opt=value ...]   the 600-instance bench batch tiled 8 times (4800 instances, N = 60)
+    traffic_workload.py realistic_quadcopter     BASELINE.json configs[2]: N = 60, the 60 warm + 60 cold steps as one batch of 120
+    traffic_workload.py quadcopter_N12           BASELINE.json configs[0]: N = 12, the 60 steps of one warm run as one batch
 
 Extra arguments are solver options (e.g. residency=3).  Prints one JSON line with the launch's kernel time (HIP
 events), steps/s, the algorithmic bytes of SURVEY.md 8(d) from the instances' own counters, and the kernel name."""
@@ -17,9 +19,15 @@ from pantr_amd import workloads
 what = sys.argv[1] if len(sys.argv) > 1 else "stress"
 extra = tuple(a for a in sys.argv[2:] if "=" in a)
 launches = 3
+y0 = None
 if what == "stress":
     w = workloads.stress_batch(1024)
     X0, U0, N = w["x0"], w["u0"], 120
+    opts = tuple(w["opts"]) + extra
+elif what in ("realistic_quadcopter", "quadcopter_N12"):
+    w = (workloads.closed_loop_batch("realistic_quadcopter", 60) if what == "realistic_quadcopter"
+         else workloads.closed_loop_batch("quadcopter", 12, starts=(True,)))
+    X0, U0, y0, N = w["x0"], w["u0"], w["y0"], w["horizon"]
     opts = tuple(w["opts"]) + extra
 else:
     R = int(what[4:]) if what.startswith("tile") else 8
@@ -28,12 +36,19 @@ else:
     X0, U0, N = np.tile(x0, (R, 1)), np.tile(u0, (R, 1)), 60
     opts = tuple(pa.DODO_PANTR_OPTS) + ("alm.max_time=5s",) + extra
 B = len(X0)
-batch = pa.PantrBatch("hanging_chain", N, B, opts=opts)
+problem = w["problem"] if y0 is not None else "hanging_chain"
+batch = pa.PantrBatch(problem, N, B, opts=opts)
 ms = []
 for _ in range(launches):
-    u, st = batch.solve(X0, U0)
+    if y0 is not None:
+        u, y, st = batch.solve_al(X0, U0, y0)
+    else:
+        u, st = batch.solve(X0, U0)
     ms.append(batch.last_kernel_ms())
-alg = int(pa.algorithmic_bytes(st, N, 57, 3))
+if y0 is not None:
+    alg = int(pa.algorithmic_bytes(st, N, 9, 4, m=batch.m))
+else:
+    alg = int(pa.algorithmic_bytes(st, N, 57, 3))
 k = min(ms[1:])
 print(json.dumps({"workload": what, "options": list(extra), "instances": B, "horizon": N, "launches": launches,
                   "kernel": batch.kernel_name(B), "kernel_ms": ms, "steps_per_s": B / (k * 1e-3),

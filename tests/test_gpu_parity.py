@@ -389,11 +389,12 @@ def test_solve_device_refuses_pointers_it_cannot_see():
     b.close()
 
 
-def test_idle_row_of_the_lane_layout_stays_zero(rng):
-    """chain_model.hip.h: quad_sum adds rows 0..3 of the 16c+p lane layout and relies on the idle row 3
-    (lanes 48..63) holding exactly 0; the lanes p = 10..15 of rows 0..2 may hold anything.  The stored
-    trajectory rows ({x, v} per lane, 1 KiB per stage) show what the lanes carried through a forward
-    sweep: row 3 must be all +0.0 / -0.0 in every stage, and the active lanes must be finite."""
+def test_lane_layout_of_the_stored_trajectory(rng):
+    """chain_model.hip.h: lane = 32 chain + 10 component + point; both halves of the wavefront carry the full state, lanes
+    30, 31 of a half are idle.  The stored trajectory rows ({x, v} per lane, 1 KiB per stage) show what the lanes carried
+    through a forward sweep: the two halves hold the same bits in every stage, the idle lanes stay at zero (nothing is
+    ever summed over them, but a non-finite value there could reach a neighbour through a masked fma), the active lanes
+    are finite, and the stage-0 row is the initial state itself."""
     import ctypes as C
     N, B = 22, 3
     b = pa.PantrBatch("hanging_chain", N, B)
@@ -405,10 +406,11 @@ def test_idle_row_of_the_lane_layout_stays_zero(rng):
                                                  rows.ctypes.data_as(C.c_void_p))
         assert rc == 0
         lanes = rows.reshape(N + 1, 64, 2)
-        assert np.all(lanes[:, 48:, :] == 0.0)
-        active = np.array([16 * c + p for c in range(3) for p in range(10)])
+        assert np.array_equal(lanes[:, :32, :], lanes[:, 32:, :])
+        assert np.all(lanes[:, [30, 31, 62, 63], :] == 0.0)
+        active = np.array([10 * c + p for c in range(3) for p in range(10)])
         assert np.all(np.isfinite(lanes[:, active, :]))
-        # the stage-0 row is the initial state itself: lane 16c+p holds component c of point p
+        # lane 10c+p holds component c of point p
         assert np.array_equal(lanes[0, active, 0], x0[inst][[3 * p + c for c in range(3) for p in range(10)]])
     b.close()
 
@@ -500,11 +502,16 @@ def test_kernel_name_follows_method_speculation_and_batch_size():
     assert b.kernel_name() == "pantr_solve_spec_kernel<ChainModel, 3>"
     lds_on, _ = b.footprint()
     b.close()
-    assert lds_off == lds_auto < lds_on <= 160 * 1024 // 4   # (1024 instances: one wavefront each; four two-wavefront workgroups fit a CU)
+    assert lds_off == lds_auto < lds_on <= 160 * 1024 // 3   # (1024 instances: one wavefront each; three two-wavefront workgroups fit a CU)
     b = pa.PantrBatch("hanging_chain", 120, 1024, opts=pa.DODO_PANTR_OPTS)
     assert b.kernel_name(256) == "pantr_solve_spec_kernel<ChainModel, 6>"   # auto: two per CU would fit up to 512 instances ...
     assert b.kernel_name(512) == "pantr_solve_kernel<ChainModel, 0, 6>"     # ... but 512 x 120 stages load the memory system
     b.close()
+    # the elements of a decision vector a lane owns, nj = ceil(3 N / 64), are a compile-time constant of the kernel up to six
+    for N, nj in ((10, 1), (21, 1), (22, 2), (30, 2), (50, 3), (70, 4), (100, 5), (128, 6), (129, 0), (200, 0)):
+        b = pa.PantrBatch("hanging_chain", N, 4, opts=pa.DODO_PANTR_OPTS)
+        assert b.kernel_name() == f"pantr_solve_spec_kernel<ChainModel, {nj}>", (N, b.kernel_name())
+        b.close()
     b = pa.PantrBatch("hanging_chain", 60, 8, opts=pa.DODO_OPTS["panoc"])
     assert b.kernel_name() == "pantr_solve_kernel<ChainModel, 1, 0>"
     b.close()

@@ -363,9 +363,12 @@ def test_the_vmcnt_checker_finds_what_it_should():
     assert run("\n".join(flag))[:2] == (2, 0)
     flag[1] = "s_mov_b64 s[48:49], 0"                       # the flag says "A ran" on the path that skipped A: both may be skipped
     assert run("\n".join(flag))[:2] == (2, 1)
-    # from a full drain: nothing issued since -> nothing in flight, passes; something but too little -> reported
+    # from a full drain: no LDS-DMA request since -> the rows were requested before it and have landed, passes (whatever
+    # stores were issued); a request but too few operations behind it -> reported
     assert run("\n".join(["s_nop 0", "s_waitcnt vmcnt(0)", W(5), "s_endpgm"]))[:2] == (1, 0)
+    assert run("\n".join(["s_nop 0", "s_waitcnt vmcnt(0)", ST, W(5), "s_endpgm"]))[:2] == (1, 0)
     assert run("\n".join(["s_nop 0", "s_waitcnt vmcnt(0)", LD, W(5), "s_endpgm"]))[:2] == (1, 1)
+    assert run("\n".join(["s_nop 0", "s_waitcnt vmcnt(0)", LD, ST, ST, ST, ST, ST, W(5), "s_endpgm"]))[:2] == (1, 0)
     # the conservative build
     assert run("\n".join(["s_nop 0", "s_waitcnt vmcnt(0) expcnt(6)", "s_endpgm"])) == (0, 0, 1)
 
