@@ -361,6 +361,33 @@ struct ChainModel {
     __device__ static __forceinline__ double xt_lds(const Lane &L, const char *buf) {
         return reinterpret_cast<const double *>(buf + LDS_STAGE_BYTES)[L.q];
     }
+    // ---- products that keep the tangent STATE of every stage instead of its tangent spring vectors (large batches) ----
+    // Where a launch is bound by the memory system, bytes are what a product costs: the tangent tape (1 KiB per stage
+    // written, 1 KiB read back) and the tangent-state row (256 B each way) are 2.5 of the 9.25 KiB a stage moves.  The
+    // forward sweep can store the tangent state at the stage's start instead - 57 numbers: one 512-byte row, positions from
+    // the lower half of the wavefront, velocities from the upper - and the adjoint sweep run the stage's forward tangent
+    // once more from it (86 instructions; the K rows are in the landing buffer anyway), which puts the d_t where the
+    // tape would have landed them: 7 KiB per stage.  Same expressions on the same operands: same bits.
+    static constexpr int S_ROW_DOUBLES = 64; ///< state row per stage: x at slots 0..31 (lane & 31), v at 32..63
+    __device__ static __forceinline__ void s_store(const Lane &L, double *row, const State &s_t) {
+        row[(L.l & 31) + (L.hi ? 32 : 0)] = L.hi ? s_t.v : s_t.x;
+    }
+    /// The state row of a stage (two 256-byte transfers) to the start of the landing buffer's tangent-tape area: it is
+    /// read into registers before the stage's recomputed d_t are written over it.
+    __device__ static __forceinline__ void prefetch_s(const Lane &L, const double *srow, char *buf) {
+        lds_dma_256(reinterpret_cast<const char *>(srow) + L.l * 4, buf + TAPE_STAGE_BYTES);
+        lds_dma_256(reinterpret_cast<const char *>(srow) + 256 + L.l * 4, buf + TAPE_STAGE_BYTES + 256);
+    }
+    /// K and M rows and the state row of a stage: REV_ROW_TRANSFERS operations, like prefetch_rev_xt.
+    __device__ static __forceinline__ void prefetch_rev_s(const Lane &L, const double4 *tape_stage, const double *srow, char *buf) {
+        static_assert(REV_ROW_TRANSFERS == 4 + 2, "lds_dma_rows<4>, then two lds_dma_256");
+        lds_dma_rows<4>(reinterpret_cast<const char *>(tape_stage) + L.l * 16, buf);
+        prefetch_s(L, srow, buf);
+    }
+    __device__ static __forceinline__ State s_lds(const Lane &L, const char *buf) {
+        const double *s = reinterpret_cast<const double *>(buf + TAPE_STAGE_BYTES) + (L.l & 31);
+        return {s[0], s[32]};
+    }
 
     // ---- tangent sweeps over the tape ---------------------------------------------------------------
     /// st stores of a forward stage: one per substage PAIR (each stores both chains' d_t)

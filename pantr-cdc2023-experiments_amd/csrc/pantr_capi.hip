@@ -534,7 +534,9 @@ int run_eval(pantr_batch *b, int32_t B, int mode, double gamma, const double *x0
     a.x0 = b->d_x0; a.u = b->d_u; a.v = v ? b->d_v : nullptr;
     a.out_s = b->d_s; a.out_v = b->d_o1; a.out_v2 = b->d_o2; a.ws = b->d_ws; a.gamma = gamma;
     a.box = b->box;
-    if (b->eval_depth == 2)
+    if (b->eval_depth == 3)
+        hipLaunchKernelGGL((pantr_eval_kernel<ChainModel, 3>), dim3(B), dim3(WAVE), eval_lds_bytes(*b), 0, a);
+    else if (b->eval_depth == 2)
         hipLaunchKernelGGL((pantr_eval_kernel<ChainModel, 2>), dim3(B), dim3(WAVE), eval_lds_bytes(*b), 0, a);
     else
         hipLaunchKernelGGL((pantr_eval_kernel<ChainModel, 1>), dim3(B), dim3(WAVE), eval_lds_bytes(*b), 0, a);
@@ -1316,7 +1318,7 @@ extern "C" int pantr_debug_read_workspace(pantr_batch_t *b, int32_t inst, int64_
 /// Tests / development: the prefetch depth (1 | 2) of the products the chain's evaluation kernel runs.
 extern "C" void pantr_debug_set_eval_prefetch_depth(pantr_batch_t *b, int depth) {
     if (b)
-        b->eval_depth = depth == 2 ? 2 : 1;
+        b->eval_depth = depth == 2 || depth == 3 ? depth : 1;
 }
 
 extern "C" void pantr_debug_set_eval_reps(pantr_batch_t *b, int r) {

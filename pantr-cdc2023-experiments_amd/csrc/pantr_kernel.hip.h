@@ -256,8 +256,12 @@ enum : int { SPEC_EVAL = 1, SPEC_EXIT = 2, SPEC_MODEL = 3 };
 // ---------------------------------------------------------------------------------------
 /// DEPTH: how many stages ahead a Hessian-vector product requests its tape rows (1 | 2; hess_prod_tape).
 /// NJ_: 0, or nj = npad / 64 known at compile time - the element-wise passes are then straight-line code (Owned<NJ>).
-template <class M, bool ITER_GLOBAL = false, bool SPEC = false, int DEPTH = 1, int NJ_ = 0>
+/// RECOMP (DEPTH == 2 only): the products keep the tangent state of every stage instead of the tangent spring vectors
+/// and run the stage's forward tangent again inside the adjoint sweep (chain_model.hip.h, s_store): 7 instead of 9.25 KiB
+/// per stage for 86 more instructions - what the one-wavefront kernel of large, memory-bound batches wants.
+template <class M, bool ITER_GLOBAL = false, bool SPEC = false, int DEPTH = 1, int NJ_ = 0, bool RECOMP = false>
 struct WaveProblem {
+    static_assert(!RECOMP || DEPTH == 2, "the recomputing products are a form of the two-stages-ahead sweeps");
     static_assert(DEPTH == 1 || DEPTH == 2, "one or two stages ahead");
     static constexpr int PREFETCH_DEPTH = DEPTH;
     using Lane  = typename M::Lane;
@@ -653,7 +657,7 @@ struct WaveProblem {
     static constexpr int TAN_ST_STORES = M::PAIR_ST_STORES_PER_STAGE; ///< d_t stores of a forward stage: one per substage pair
     // What the waits of the two-stages-ahead sweeps may leave in flight, from ONE place: the vector-memory operations
     // a stage issues behind its request (the model names what its functions issue).
-    static constexpr int FWD_STAGE_STORES  = TAN_ST_STORES + 1;     ///< + the tangent-state row (xt_store)
+    static constexpr int FWD_STAGE_STORES  = RECOMP ? 1 : TAN_ST_STORES + 1; ///< + the tangent-state row (xt_store); RECOMP: the state row alone
     static constexpr int FWD_ROW_TRANSFERS = M::FWD_ROW_TRANSFERS;  ///< prefetch_fwd<true>: the K rows of a stage
     static constexpr int REV_ROW_TRANSFERS = M::REV_ROW_TRANSFERS;  ///< prefetch_rev_xt: K, M, d_t rows and the tangent-state row
     /// The lanes of a product, built where the product starts (the lane index passes through an empty asm: the lane
@@ -663,6 +667,10 @@ struct WaveProblem {
         int lane = L.l;
         asm volatile("" : "+v"(lane));
         return TanLane(lane);
+    }
+    /// RECOMP: the state row of stage k (the tangent tape's region of the workspace holds these rows instead)
+    __device__ __forceinline__ double *srow(int k) const {
+        return reinterpret_cast<double *>(st) + (size_t)k * M::S_ROW_DOUBLES;
     }
     __device__ __forceinline__ void hess_prod_tape_d2(const double *v, double *Hv) const {
         wave_sync();
@@ -680,6 +688,7 @@ struct WaveProblem {
         // K from this sweep, M requested a product ahead (prime), the tangent spring vectors and the tangent-state
         // row of stage N - 1 written by the last stage straight into its landing buffer.
         State s_t{0.0, 0.0};
+        State s_last{0.0, 0.0}; // RECOMP: the tangent state at the start of the last stage
         // `kind`: 0 = a stage that is not the last, 1 = the last stage of N > 1 stages, 2 = the only stage (N = 1)
         auto stage_fwd = [&](int k, char *cur, char *nxt2, char *prev, auto kind) {
             constexpr bool LAST = decltype(kind)::value != 0, ONLY = decltype(kind)::value == 2;
@@ -705,19 +714,33 @@ struct WaveProblem {
                     M::template prefetch_fwd<true>(L, tape + (size_t)(k + 2) * M::TAPE_D4_PER_STAGE, nxt2);
                 } else {
                     const int kk = k > 0 ? k - 1 : 0;
-                    M::prefetch_st_xt(L, st + (size_t)kk * M::ST_D4_PER_STAGE, Xt + (size_t)kk * M::XT_DOUBLES, nxt2);
+                    if constexpr (RECOMP)
+                        M::prefetch_s(L, srow(kk), nxt2);
+                    else
+                        M::prefetch_st_xt(L, st + (size_t)kk * M::ST_D4_PER_STAGE, Xt + (size_t)kk * M::XT_DOUBLES, nxt2);
                 }
             } else {
                 // all rows of stage N - 2 for the adjoint sweep's second stage (its K and M rows are in LDS already:
                 // they come again, so that the adjoint sweep's first stage, too, has REV_ROW_TRANSFERS operations
                 // behind it; N = 1: of stage 0 itself, into a buffer nobody reads)
                 const int kk = k > 0 ? k - 1 : 0;
-                M::prefetch_rev_xt(L, tape + (size_t)kk * M::TAPE_D4_PER_STAGE, st + (size_t)kk * M::ST_D4_PER_STAGE,
-                                   Xt + (size_t)kk * M::XT_DOUBLES, prev);
+                if constexpr (RECOMP)
+                    M::prefetch_rev_s(L, tape + (size_t)kk * M::TAPE_D4_PER_STAGE, srow(kk), prev);
+                else
+                    M::prefetch_rev_xt(L, tape + (size_t)kk * M::TAPE_D4_PER_STAGE, st + (size_t)kk * M::ST_D4_PER_STAGE,
+                                       Xt + (size_t)kk * M::XT_DOUBLES, prev);
             }
             const double uc_t = M::load_input(T, v + M::nu * k);
             double4 *st_k;
-            if constexpr (!LAST) {
+            if constexpr (RECOMP) {
+                // the state at the stage's start goes to HBM (the last stage's stays in registers: s_last); the d_t of
+                // this sweep go nowhere - the landing buffer's tangent-tape area, which the adjoint sweep fills anew
+                if constexpr (!LAST)
+                    M::s_store(T, srow(k), s_t);
+                else
+                    s_last = s_t;
+                st_k = reinterpret_cast<double4 *>(cur + M::TAPE_STAGE_BYTES);
+            } else if constexpr (!LAST) {
                 M::xt_store(T, Xt + (size_t)k * M::XT_DOUBLES, s_t);
                 st_k = st + (size_t)k * M::ST_D4_PER_STAGE;
             } else {
@@ -765,6 +788,7 @@ struct WaveProblem {
         // explicit ones below ----
         State lam_t{0.0, 0.0};
         M::cost_grad_x_add_tan(T, T.end ? s_t.x : s_t.v, lam_t);
+        bool first_rev = true; // RECOMP: stage N - 1 takes its state from registers
         // `tail`: 0 = a stage k >= 2 (it asks for the rows of stage k - 2), 1 = stage 1, 2 = stage 0 (nothing left to ask
         // for; stage 0 is followed by nothing: a full wait) - stages 1 and 0 always sit in tbuf1 and tbuf0
         auto stage_rev = [&](int k, char *cur, char *nxt2, auto tail) {
@@ -776,11 +800,26 @@ struct WaveProblem {
                 wait_vmem();
             else
                 wait_vmem_but<REV_ROW_TRANSFERS>();
-            const double xt = M::xt_lds(T, cur);
-            double uc_t = M::load_input(T, v + M::nu * k);
-            if constexpr (TAIL == 0) // two stages ahead
-                M::prefetch_rev_xt(L, tape + (size_t)(k - 2) * M::TAPE_D4_PER_STAGE, st + (size_t)(k - 2) * M::ST_D4_PER_STAGE,
-                                   Xt + (size_t)(k - 2) * M::XT_DOUBLES, nxt2);
+            double xt, uc_t = M::load_input(T, v + M::nu * k);
+            State s_k{0.0, 0.0};
+            if constexpr (RECOMP) { // the state at the stage's start: registers (stage N - 1) or the row that landed
+                const State s_row = M::s_lds(T, cur);
+                s_k = {first_rev ? s_last.x : s_row.x, first_rev ? s_last.v : s_row.v};
+                xt  = T.end ? s_k.x : s_k.v;
+            } else {
+                xt = M::xt_lds(T, cur);
+            }
+            if constexpr (TAIL == 0) { // two stages ahead
+                if constexpr (RECOMP)
+                    M::prefetch_rev_s(L, tape + (size_t)(k - 2) * M::TAPE_D4_PER_STAGE, srow(k - 2), nxt2);
+                else
+                    M::prefetch_rev_xt(L, tape + (size_t)(k - 2) * M::TAPE_D4_PER_STAGE, st + (size_t)(k - 2) * M::ST_D4_PER_STAGE,
+                                       Xt + (size_t)(k - 2) * M::XT_DOUBLES, nxt2);
+            }
+            if constexpr (RECOMP) { // the stage's forward tangent once more: its d_t, where the tape would have landed them
+                M::rk4_tan(T, cur, s_k, uc_t, reinterpret_cast<double4 *>(cur + M::TAPE_STAGE_BYTES), xs());
+                first_rev = false;
+            }
             State sbar_t;
             double ubar_t;
             M::rk4_adj_tan(T, cur, lam_t, sbar_t, ubar_t, xs());
@@ -1884,12 +1923,17 @@ __device__ __forceinline__ InnerResult inner_solve(PB &pb, const KernelParams &P
 /// trip while the batch is busy: two stages ahead takes the mean solve of the bench batch from 23.2 to 21.2 ms (the pass,
 /// which ends on one straggler running alone out of L2, from 54.6 to 53.9 ms).  LDS of a workgroup: 49 KiB (three per CU).
 constexpr int CHAIN_SOLVE_PREFETCH_DEPTH = 2;
+#ifndef PANTR_SOLVE_RECOMPUTE // development switch (A/B): 0 = the one-wavefront kernel keeps the tangent tape
+#define PANTR_SOLVE_RECOMPUTE 1
+#endif
+/// The one-wavefront kernel - large, memory-bound batches - runs the products that recompute (WaveProblem, RECOMP).
+constexpr bool CHAIN_SOLVE_RECOMPUTE = PANTR_SOLVE_RECOMPUTE != 0;
 #ifndef PANTR_SPEC_DEPTH // development switch (A/B)
 #define PANTR_SPEC_DEPTH 2
 #endif
 constexpr int CHAIN_SPEC_PREFETCH_DEPTH  = PANTR_SPEC_DEPTH;
 template <class M, int METHOD, int NJ = 0>
-using SolveProblemT = WaveProblem<M, METHOD == 0, false, METHOD == 0 ? CHAIN_SOLVE_PREFETCH_DEPTH : 1, NJ>;
+using SolveProblemT = WaveProblem<M, METHOD == 0, false, METHOD == 0 ? CHAIN_SOLVE_PREFETCH_DEPTH : 1, NJ, METHOD == 0 && CHAIN_SOLVE_RECOMPUTE>;
 template <class M, int NJ = 0>
 using SpecProblemT = WaveProblem<M, true, true, CHAIN_SPEC_PREFETCH_DEPTH, NJ>;
 
@@ -2063,14 +2107,15 @@ struct EvalArgs {
 
 /// DEPTH: how far ahead the products of this kernel request their tape rows (both forms of hess_prod_tape are
 /// tested against the oracle through it).
-template <class M, int DEPTH = 1>
+template <class M, int DEPTH_ = 1>
 __global__ __launch_bounds__(WAVE) void pantr_eval_kernel(EvalArgs a) {
+    constexpr int DEPTH = DEPTH_ == 3 ? 2 : DEPTH_; // 3: two stages ahead, recomputing (the one-wavefront solve kernel's form)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x, inst = blockIdx.x;
     if (inst >= a.B)
         return;
     typename M::Lane L(lane);
-    using PB = WaveProblem<M, false, false, DEPTH>;
+    using PB = WaveProblem<M, false, false, DEPTH, 0, DEPTH_ == 3>;
     __shared__ __attribute__((aligned(16))) char landing[(DEPTH + 1) * PB::LANDING_BYTES];
     PB pb{L, a.box, lds, a.N, a.n, a.npad, a.nj, {}, nullptr, nullptr, nullptr, nullptr, landing, landing + PB::LANDING_BYTES};
     if constexpr (DEPTH == 2)
