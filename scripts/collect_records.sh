@@ -4,7 +4,7 @@
 #   scripts/collect_records.sh r03
 set -e
 cd "$(dirname "$0")/.."
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=gpurun_out/$TAG
 for f in bench bench_streams4; do
     [ -s $R/$f.json ] && tail -1 $R/$f.json > profiles/${TAG}_$f.json
@@ -20,5 +20,7 @@ cp "$(ls -t gpurun_out/prof_rows/*/*_kernel_stats.csv | head -1)" profiles/${TAG
 [ -s $R/product_under_load.txt ] && grep -v amdgpu.ids $R/product_under_load.txt > profiles/${TAG}_product_under_load.txt
 python scripts/summarize_profiles.py $TAG > /dev/null
 python scripts/summarize_traffic.py $TAG stress tile8
+[ -d gpurun_out/traffic/realistic_quadcopter ] && python scripts/summarize_traffic.py $TAG realistic_quadcopter quadcopter_N12
+[ -s $R/straggler_phases.txt ] && grep -v amdgpu.ids $R/straggler_phases.txt > profiles/${TAG}_straggler_phases.txt
 python scripts/kernel_resources.py > profiles/${TAG}_kernel_resources.txt 2> /dev/null || true
 ls -la profiles/ | grep ${TAG}_
