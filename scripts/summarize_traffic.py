@@ -21,14 +21,19 @@ for w in workloads:
     line = [l for l in open(os.path.join(src, "stats.log")) if l.startswith("{")][-1]
     run = json.loads(line)
     out = {"tag": tag, "workload": w, "command": f"python3 scripts/traffic_workload.py {w}", "run": run}
-    for r in csv.DictReader(open(newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")))):
-        if any(k in r["Name"] for k in KERNELS) and "eval" not in r["Name"]:
-            out["kernel_trace"] = {"kernel": r["Name"], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
-                                   "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6}
+    # the timed launches: the solve kernel at the workload's batch size (one workgroup of 64 or 128 threads per instance) - a
+    # workload that first records its closed loops launches the same kernel many times on single instances
+    grids = {run["instances"] * 64, run["instances"] * 128}
+    timed = lambda name, grid: any(k in name for k in KERNELS) and "eval" not in name and int(grid) in grids
+    rows = [r for r in csv.DictReader(open(newest(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))))
+            if timed(r["Kernel_Name"], r["Grid_Size_X"])]
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+    out["kernel_trace"] = {"kernel": rows[0]["Kernel_Name"], "calls": len(durs), "avg_ms": sum(durs) / len(durs),
+                           "min_ms": min(durs), "max_ms": max(durs), "source": "rocprofv3 --kernel-trace: the launches at the workload's grid size"}
     pmc = {}
     for name in ("pmc_fetch", "pmc_write"):
         f = newest(os.path.join(src, name, "*", "*_counter_collection.csv"))
-        rows = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in KERNELS) and "eval" not in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if timed(r["Kernel_Name"], r["Grid_Size"])]
         vals = [float(r["Counter_Value"]) for r in rows]
         pmc[rows[0]["Counter_Name"]] = {"per_launch_KiB": sum(vals) / len(vals), "launches": len(vals)}
     # the occupancy / issue counters, where the passes were taken (SQ=1 scripts/traffic_profile.sh ...)
@@ -36,7 +41,7 @@ for w in workloads:
         f = newest(os.path.join(src, name, "*", "*_counter_collection.csv"))
         if not f:
             continue
-        rows = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in KERNELS) and "eval" not in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if timed(r["Kernel_Name"], r["Grid_Size"])]
         for cname in sorted({r["Counter_Name"] for r in rows}):
             vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == cname]
             # (one row per dispatch and counter; rocprofv3 sums a counter over the chip's shader engines)
@@ -53,7 +58,7 @@ for w in workloads:
             "wait_any_over_busy": pmc["SQ_WAIT_ANY"]["per_launch"] / pmc["SQ_BUSY_CYCLES"]["per_launch"] if "SQ_WAIT_ANY" in pmc else None,
         }
         if "SQ_WAVE_CYCLES" in pmc:
-            out["valu_issue"]["wave_cycles_per_valu_instruction"] = pmc["SQ_WAVE_CYCLES"]["per_launch"] / valu
+            out["valu_issue"]["sq_wave_cycles_over_insts_valu_in_counter_units"] = pmc["SQ_WAVE_CYCLES"]["per_launch"] / valu
     rd, wr = 2 * pmc["FETCH_SIZE"]["per_launch_KiB"] * 1024, pmc["WRITE_SIZE"]["per_launch_KiB"] * 1024
     ms = out["kernel_trace"]["avg_ms"]
     alg = run["algorithmic_bytes_per_launch"]
