@@ -327,7 +327,8 @@ def extra_configs(torch, pa, dev, local_rank, cores, peak_measured, with_cpu):
     hw = workloads.headline_batch(device=local_rank, num_sim=300, horizon=HORIZON)
     tiled = dict(hw, x0=np.tile(hw["x0"], (8, 1)), u0=np.tile(hw["u0"], (8, 1)), sol=None, warm=np.tile(hw["warm"], 8))
     one("tile8", [tiled], "the 600-instance bench batch tiled 8 times: 4800 hanging_chain N=60 instances in one launch (one "
-        "wavefront per instance, seven per compute unit): where the kernel is bound by the memory system", traffic_name="tile8",
+        "wavefront per instance, six resident per compute unit (LDS), started longest first by the time each took in the pass "
+        "before - launch_order=auto): where the kernel is bound by the memory system", traffic_name="tile8",
         with_cpu=False)
     return out
 

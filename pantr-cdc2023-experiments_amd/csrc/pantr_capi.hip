@@ -102,6 +102,11 @@ struct pantr_batch {
     int num_cus = 256; ///< compute units of `device` (hipDeviceAttributeMultiprocessorCount)
     int32_t *d_order     = nullptr;
     bool have_order      = false;
+    // launch_order=previous|auto: the order the next launch uses, ranked on the device from the solve before it
+    int32_t *d_order_prev = nullptr;
+    double *d_cost        = nullptr;
+    int32_t prev_B        = 0;     ///< batch size d_order_prev describes (0: nothing ranked yet)
+    int32_t order_source  = 0;     ///< what the most recent launch used: 0 natural, 1 pantr_batch_set_launch_order, 2 the solve before it
     int32_t trace_instances = 0, trace_cap = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
@@ -363,6 +368,76 @@ int upload_bounds(pantr_batch *b) {
     return PANTR_OK;
 }
 
+// ---- launch order from the solve before (launch_order=previous|auto) --------------------------------------
+// A launch with more workgroups than the chip holds at once ends with whatever instance started last; when that is
+// a long one, the pass is its start time plus its whole solve.  Instances of an MPC batch need about the work they
+// needed a time step earlier, so the time each took in the solve before this one on the handle is a usable forecast:
+// two small kernels behind every solve kernel rank the instances by it, longest first, for the next launch (in the
+// stream; nothing comes to the host).  The bench batch tiled eight times into one launch: 170 -> 130 ms.
+__global__ void launch_cost_kernel(int B, const DeviceStats *stats, double *cost) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) {
+        const double t = stats[i].elapsed_s;
+        cost[i] = t == t ? t : 0.0;
+    }
+}
+/// order[rank of i] = i, rank = how many instances cost more (ties: the lower index first): a permutation whatever
+/// the costs are.
+__global__ void launch_rank_kernel(int B, const double *cost, int32_t *order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B)
+        return;
+    const double c = cost[i];
+    int rank = 0;
+    for (int j = 0; j < B; ++j) {
+        const double cj = cost[j];
+        rank += (cj > c || (cj == c && j < i)) ? 1 : 0;
+    }
+    order[rank] = i;
+}
+/// Workgroups of `kernel` the chip holds at once (INT32_MAX if the runtime cannot say).
+template <class K>
+int32_t resident_workgroups(const pantr_batch *b, K kernel, int block, size_t lds) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu <= 0) {
+        (void)hipGetLastError();
+        return INT32_MAX;
+    }
+    return per_cu * b->num_cus;
+}
+/// Does this launch take (and leave behind) an order ranked from the solve before it?
+bool ranks_launches(const pantr_batch *b, int32_t B, int32_t resident) {
+    if (b->have_order || b->opts.launch_order == 0)
+        return false;
+    return b->opts.launch_order == 1 || B > resident;
+}
+/// The order array of a launch of B instances (nullptr: by index); records where it came from.
+const int32_t *launch_order_for(pantr_batch *b, int32_t B, int32_t resident) {
+    if (b->have_order) {
+        b->order_source = 1;
+        return b->d_order;
+    }
+    if (ranks_launches(b, B, resident) && b->prev_B == B) {
+        b->order_source = 2;
+        return b->d_order_prev;
+    }
+    b->order_source = 0;
+    return nullptr;
+}
+/// Behind a solve kernel: rank its instances for the next launch of the same size.
+int rank_for_next_launch(pantr_batch *b, int32_t B, int32_t resident, const DeviceStats *d_stats, hipStream_t stream) {
+    if (!ranks_launches(b, B, resident)) {
+        b->prev_B = 0;
+        return PANTR_OK;
+    }
+    const int block = 256, grid = (B + block - 1) / block;
+    hipLaunchKernelGGL(launch_cost_kernel, dim3(grid), dim3(block), 0, stream, (int)B, d_stats, b->d_cost);
+    hipLaunchKernelGGL(launch_rank_kernel, dim3(grid), dim3(block), 0, stream, (int)B, (const double *)b->d_cost, b->d_order_prev);
+    HIP_TRY(hipGetLastError());
+    b->prev_B = B;
+    return PANTR_OK;
+}
+
 int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, double *d_y,
                  DeviceStats *d_stats, hipStream_t stream) {
     if (int rc = check_supported(b->opts))
@@ -396,10 +471,15 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
         a.trace_cap = b->trace_cap; a.trace_instances = b->trace_instances;
         a.x0 = d_x0; a.u = d_u; a.y = d_y; a.ws = b->d_ws; a.lbfgs = d_lbfgs; a.stats = d_stats;
         a.trace = b->trace_instances > 0 ? b->d_trace : nullptr;
-        a.order = b->have_order ? b->d_order : nullptr;
         a.prm   = to_kernel_params(b->opts, b->tick_s, b->box);
         a.alm   = to_alm_params(b->opts);
         HIP_TRY(hipEventRecord(b->ev_start, stream));
+        int32_t resident = INT32_MAX;
+        auto go = [&](auto kernel, int block, size_t lds) {
+            resident = B > b->num_cus ? resident_workgroups(b, kernel, block, lds) : INT32_MAX;
+            a.order  = launch_order_for(b, B, resident);
+            hipLaunchKernelGGL(kernel, dim3(B), dim3(block), lds, stream, a);
+        };
         with_quad_model(b, [&](auto model) {
             using M = decltype(model);
             const bool fixed_nj = b->nj == ALM_NJ;
@@ -409,46 +489,51 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
             if (method == 0 && use_alm_speculation(b, B)) {
                 if constexpr (HAS_SHORT)
                     if (short_horizon) {
-                        hipLaunchKernelGGL((pantr_alm_spec_kernel<M, 1, 1>), dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
+                        go(&pantr_alm_spec_kernel<M, 1, 1>, 2 * WAVE, alm_spec_lds_bytes(*b));
                         return 0;
                     }
                 if (fixed_nj)
-                    hipLaunchKernelGGL((pantr_alm_spec_kernel<M, ALM_NJ, 0>), dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
+                    go(&pantr_alm_spec_kernel<M, ALM_NJ, 0>, 2 * WAVE, alm_spec_lds_bytes(*b));
                 else
-                    hipLaunchKernelGGL((pantr_alm_spec_kernel<M, 0, 0>), dim3(B), dim3(2 * WAVE), alm_spec_lds_bytes(*b), stream, a);
+                    go(&pantr_alm_spec_kernel<M, 0, 0>, 2 * WAVE, alm_spec_lds_bytes(*b));
             } else if (method == 0) {
                 if constexpr (HAS_SHORT)
                     if (short_horizon) {
-                        hipLaunchKernelGGL((pantr_alm_kernel<M, 0, 1, 1>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+                        go(&pantr_alm_kernel<M, 0, 1, 1>, WAVE, b->lds_bytes);
                         return 0;
                     }
                 if (fixed_nj)
-                    hipLaunchKernelGGL((pantr_alm_kernel<M, 0, ALM_NJ, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+                    go(&pantr_alm_kernel<M, 0, ALM_NJ, 0>, WAVE, b->lds_bytes);
                 else
-                    hipLaunchKernelGGL((pantr_alm_kernel<M, 0, 0, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+                    go(&pantr_alm_kernel<M, 0, 0, 0>, WAVE, b->lds_bytes);
             }
             else if (method == 1)
-                hipLaunchKernelGGL((pantr_alm_kernel<M, 1, 0, 0>), dim3(B), dim3(WAVE), b->lds_bytes_cmp, stream, a);
+                go(&pantr_alm_kernel<M, 1, 0, 0>, WAVE, b->lds_bytes_cmp);
             else
-                hipLaunchKernelGGL((pantr_alm_kernel<M, 2, 0, 0>), dim3(B), dim3(WAVE), b->lds_bytes_cmp, stream, a);
+                go(&pantr_alm_kernel<M, 2, 0, 0>, WAVE, b->lds_bytes_cmp);
             return 0;
         });
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(b->ev_stop, stream));
         b->timed = true;
-        return PANTR_OK;
+        return rank_for_next_launch(b, B, resident, d_stats, stream);
     }
     SolveArgs a{};
     a.B = B; a.N = b->N; a.n = b->n; a.npad = b->npad; a.nj = b->nj;
     a.trace_cap = b->trace_cap; a.trace_instances = b->trace_instances;
     a.x0 = d_x0; a.u = d_u; a.ws = b->d_ws; a.lbfgs = d_lbfgs; a.stats = d_stats;
     a.trace = b->trace_instances > 0 ? b->d_trace : nullptr;
-    a.order = b->have_order ? b->d_order : nullptr;
     a.prm   = to_kernel_params(b->opts, b->tick_s, b->box);
     a.lbv = b->d_bounds; a.ubv = b->d_bounds + b->npad;
     if (method != 0 && b->lds_bytes + WaveProblem<ChainModel>::tape_lds_bytes() > 160 * 1024)
         return fail(PANTR_ERR_OUT_OF_RANGE, "horizon too long for method=panoc|strucpanoc: their vectors do not fit the 160 KiB LDS");
     HIP_TRY(hipEventRecord(b->ev_start, stream));
+    int32_t resident = INT32_MAX;
+    auto go = [&](auto kernel, int block, size_t lds) {
+        resident = B > b->num_cus ? resident_workgroups(b, kernel, block, lds) : INT32_MAX;
+        a.order  = launch_order_for(b, B, resident);
+        hipLaunchKernelGGL(kernel, dim3(B), dim3(block), lds, stream, a);
+    };
     if (method == 0 && use_speculation(b, B)) {
         const size_t lds = residency_lds(b, spec_lds_bytes(*b), 2 * SpecProblemT<ChainModel>::tape_lds_bytes() + sizeof(SpecBox));
         if (int rc = with_chain_nj(b->nj, [&](auto nj) {
@@ -456,7 +541,7 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
                 if (b->opts.residency > 0)
                     if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(&pantr_solve_spec_kernel<ChainModel, NJ>), lds))
                         return rc;
-                hipLaunchKernelGGL((pantr_solve_spec_kernel<ChainModel, NJ>), dim3(B), dim3(2 * WAVE), lds, stream, a);
+                go(&pantr_solve_spec_kernel<ChainModel, NJ>, 2 * WAVE, lds);
                 return 0;
             }))
             return rc;
@@ -467,18 +552,18 @@ int launch_solve(pantr_batch *b, int32_t B, const double *d_x0, double *d_u, dou
                 if (b->opts.residency > 0)
                     if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(&pantr_solve_kernel<ChainModel, 0, NJ>), lds))
                         return rc;
-                hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 0, NJ>), dim3(B), dim3(WAVE), lds, stream, a);
+                go(&pantr_solve_kernel<ChainModel, 0, NJ>, WAVE, lds);
                 return 0;
             }))
             return rc;
     } else if (method == 1)
-        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 1, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+        go(&pantr_solve_kernel<ChainModel, 1, 0>, WAVE, b->lds_bytes);
     else
-        hipLaunchKernelGGL((pantr_solve_kernel<ChainModel, 2, 0>), dim3(B), dim3(WAVE), b->lds_bytes, stream, a);
+        go(&pantr_solve_kernel<ChainModel, 2, 0>, WAVE, b->lds_bytes);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev_stop, stream));
     b->timed = true;
-    return PANTR_OK;
+    return rank_for_next_launch(b, B, resident, d_stats, stream);
 }
 
 int check_batch(const pantr_batch *b, int32_t B) {
@@ -813,7 +898,7 @@ int pantr_batch_create(const char *problem, int32_t horizon, int32_t max_instanc
         (rc = dev_alloc(b->d_v, B * nv)) || (rc = dev_alloc(b->d_o1, B * nv)) ||
         (rc = dev_alloc(b->d_o2, B * nv)) || (rc = dev_alloc(b->d_s, B * 4)) ||
         (rc = dev_alloc(b->d_ws, std::max<size_t>(B * b->ws_per_instance, 1))) || (rc = dev_alloc(b->d_stats, B)) ||
-        (rc = dev_alloc(b->d_order, B)) || (rc = dev_alloc(b->d_y, B * mv)) || (rc = dev_alloc(b->d_sig, B * mv)) ||
+        (rc = dev_alloc(b->d_order, B)) || (rc = dev_alloc(b->d_order_prev, B)) || (rc = dev_alloc(b->d_cost, B)) || (rc = dev_alloc(b->d_y, B * mv)) || (rc = dev_alloc(b->d_sig, B * mv)) ||
         (rc = dev_alloc(b->d_om, B * mv)) || (rc = dev_alloc(b->d_uinit, nv)) ||
         (rc = dev_alloc(b->d_bounds, 2 * (size_t)b->npad)))
         return rc;
@@ -833,7 +918,7 @@ void pantr_batch_destroy(pantr_batch_t *b) {
     (void)hipSetDevice(b->device);
     for (void *p : {(void *)b->d_x0, (void *)b->d_u, (void *)b->d_v, (void *)b->d_o1, (void *)b->d_o2,
                     (void *)b->d_s, (void *)b->d_ws, (void *)b->d_trace, (void *)b->d_stats,
-                    (void *)b->d_order, (void *)b->d_y, (void *)b->d_sig, (void *)b->d_om, (void *)b->d_uinit,
+                    (void *)b->d_order, (void *)b->d_order_prev, (void *)b->d_cost, (void *)b->d_y, (void *)b->d_sig, (void *)b->d_om, (void *)b->d_uinit,
                     (void *)b->d_lbfgs, (void *)b->d_bounds})
         if (p)
             (void)hipFree(p);
@@ -1221,6 +1306,25 @@ int pantr_batch_set_launch_order(pantr_batch_t *b, int32_t B, const int32_t *ord
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemcpy(b->d_order, order, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice));
     b->have_order = true;
+    return PANTR_OK;
+}
+
+int pantr_batch_last_launch_order(pantr_batch_t *b, int32_t B, int32_t *source, int32_t *next_order) {
+    if (!b)
+        return fail(PANTR_ERR_INVALID_ARGUMENT, "null batch handle");
+    if (!b->timed)
+        return fail(PANTR_ERR_RUNTIME, "no solve has been launched on this handle");
+    if (source)
+        *source = b->order_source;
+    if (next_order) {
+        if (int rc = check_batch(b, B))
+            return rc;
+        if (b->prev_B != B)
+            return fail(PANTR_ERR_RUNTIME, "the most recent solve left no ranking for a launch of this size (launch_order, batch size)");
+        HIP_TRY(hipSetDevice(b->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(next_order, b->d_order_prev, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     return PANTR_OK;
 }
 

@@ -347,7 +347,9 @@ struct WaveProblem {
 
     /// Static LDS of a kernel using this problem: the DEPTH + 1 landing buffers.
     /// bytes of one landing buffer (DEPTH == 2: with the tangent-state row behind the tangent tape)
-    static constexpr int LANDING_BYTES = DEPTH == 2 ? M::LDS_STAGE_BYTES_XT : M::LDS_STAGE_BYTES;
+    // (products that recompute the forward tangent have no tangent-state row to land: 3 x 256 bytes less, which is what
+    // lets a sixth workgroup of the N = 60 one-wavefront kernel into a compute unit's 160 KiB)
+    static constexpr int LANDING_BYTES = DEPTH == 2 && !RECOMP ? M::LDS_STAGE_BYTES_XT : M::LDS_STAGE_BYTES;
     __host__ __device__ static size_t tape_lds_bytes() { return (size_t)(DEPTH + 1) * LANDING_BYTES; }
     /// Doubles of HBM workspace one instance needs: X and Xt rows, the tape, the tangent tape, and
     /// (used by the ITER_GLOBAL layout) the iterate vectors.

@@ -185,6 +185,13 @@ struct SolverOptions {
     /// second-order tapes; fewer instances in flight keep that working set inside the 256 MiB Infinity Cache.
     /// 0 = auto (what the LDS of the kernel allows).  Same results either way.
     int32_t residency = 0;
+    /// `launch_order=auto|natural|previous` (an option of this implementation): in which order the workgroups of a
+    /// launch start the instances.  previous: longest first by the time each instance took in the solve before it on
+    /// this handle (MPC instances at consecutive time steps need similar work; with more workgroups than fit the chip
+    /// the pass otherwise ends with whatever long instance happened to start last); natural: by index; auto:
+    /// previous wherever the launch has more workgroups than the chip holds at once.  pantr_batch_set_launch_order
+    /// overrides all three.  Results do not depend on it.  -1 = auto, 0 = natural, 1 = previous.
+    int32_t launch_order = -1;
     /// `spec_patience=<duration>` (an option of this implementation): how long a solver wavefront waits for a
     /// result of its helper before it evaluates the step itself, tells the helper to stop and posts no further
     /// requests (pantr_stats_t::spec_timeouts counts these).  Same results either way.
@@ -441,6 +448,15 @@ inline SetResult set_option(SolverOptions &o, std::string_view kv, std::string &
         err = "Invalid value '" + std::string(v) + "' for 'residency' (auto, or workgroups per compute unit 1..32)";
         return SetResult::BadValue;
     }
+    if (kv.substr(0, 13) == "launch_order=") {
+        std::string_view v = kv.substr(13);
+        if (v == "auto" || v == "natural" || v == "previous") {
+            o.launch_order = v == "auto" ? -1 : v == "previous" ? 1 : 0;
+            return SetResult::Ok;
+        }
+        err = "Invalid value '" + std::string(v) + "' for 'launch_order' (auto, natural, previous)";
+        return SetResult::BadValue;
+    }
     auto eq = kv.find('=');
     if (eq == std::string_view::npos) {
         auto dot = kv.find('.');
@@ -487,6 +503,10 @@ inline bool get_option(const SolverOptions &o, std::string_view key, double &out
     }
     if (key == "residency") {
         out = o.residency;
+        return true;
+    }
+    if (key == "launch_order") {
+        out = o.launch_order;
         return true;
     }
     if (key == "spec_patience") {

@@ -88,7 +88,7 @@ EXPORTS = (
     "pantr_batch_get_box_D", "pantr_batch_eval_psi_grad_psi_al", "pantr_batch_eval_hess_psi_prod_al",
     "pantr_batch_get_initial_guess", "pantr_batch_get_initial_state", "pantr_batch_set_param",
     "pantr_batch_get_param", "pantr_batch_solve", "pantr_batch_solve_device",
-    "pantr_batch_last_kernel_ms", "pantr_batch_set_launch_order", "pantr_batch_set_trace",
+    "pantr_batch_last_kernel_ms", "pantr_batch_set_launch_order", "pantr_batch_last_launch_order", "pantr_batch_set_trace",
     "pantr_batch_get_trace", "pantr_batch_eval_psi", "pantr_batch_eval_psi_grad_psi",
     "pantr_batch_eval_hess_psi_prod", "pantr_batch_eval_prox_grad_step",
     "pantr_batch_simulate_dynamics", "pantr_batch_mpc", "pantr_last_error", "pantr_version", "pantr_device_count",
@@ -161,6 +161,7 @@ def lib():
         L.pantr_batch_solve_device.argtypes = [vp, _i32, vp, vp, vp, vp, vp]
         L.pantr_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pantr_batch_set_launch_order.argtypes = [vp, _i32, vp]
+        L.pantr_batch_last_launch_order.argtypes = [vp, _i32, C.POINTER(_i32), vp]
         L.pantr_batch_set_trace.argtypes = [vp, _i32, _i32]
         L.pantr_batch_get_trace.argtypes = [vp, vp]
         L.pantr_batch_eval_psi.argtypes = [vp, _i32, vp, vp, vp]
@@ -472,6 +473,18 @@ class PantrBatch:
             return
         order = np.ascontiguousarray(order, dtype=np.int32)
         _check(lib().pantr_batch_set_launch_order(self._h, len(order), _ptr(order)))
+
+    def last_launch_order(self, B=None):
+        """(source, next_order): what the most recent launch's workgroup order came from ("index", "user",
+        "previous solve") and, with B, the ranking that solve left for the next launch of B instances (None if none)."""
+        src = _i32()
+        _check(lib().pantr_batch_last_launch_order(self._h, 0, C.byref(src), None))
+        nxt = None
+        if B is not None:
+            nxt = np.zeros(B, dtype=np.int32)
+            if lib().pantr_batch_last_launch_order(self._h, B, None, _ptr(nxt)) != 0:
+                nxt = None
+        return ("index", "user", "previous solve")[src.value], nxt
 
     def set_trace(self, instances, cap):
         _check(lib().pantr_batch_set_trace(self._h, instances, cap))

@@ -17,7 +17,10 @@ import pantr_amd as pa
 from pantr_amd import workloads
 
 what = sys.argv[1] if len(sys.argv) > 1 else "stress"
-extra = tuple(a for a in sys.argv[2:] if "=" in a)
+extra = tuple(a for a in sys.argv[2:] if "=" in a and not a.startswith("order="))
+# order=prev: from the second launch on, workgroups start the instances longest first by the products each needed in
+# the launch before (pantr_batch_set_launch_order; results do not depend on the order)
+order_prev = "order=prev" in sys.argv[2:]
 launches = 3
 y0 = None
 if what == "stress":
@@ -38,20 +41,24 @@ else:
 B = len(X0)
 problem = w["problem"] if y0 is not None else "hanging_chain"
 batch = pa.PantrBatch(problem, N, B, opts=opts)
-ms = []
+ms, sources = [], []
 for _ in range(launches):
     if y0 is not None:
         u, y, st = batch.solve_al(X0, U0, y0)
     else:
         u, st = batch.solve(X0, U0)
     ms.append(batch.last_kernel_ms())
+    sources.append(batch.last_launch_order()[0])
+    if order_prev:
+        from pantr_amd import sharding
+        batch.set_launch_order(sharding.launch_order(st["n_hess_psi_prod"].astype(float)))
 if y0 is not None:
     alg = int(pa.algorithmic_bytes(st, N, 9, 4, m=batch.m))
 else:
     alg = int(pa.algorithmic_bytes(st, N, 57, 3))
 k = min(ms[1:])
-print(json.dumps({"workload": what, "options": list(extra), "instances": B, "horizon": N, "launches": launches,
-                  "kernel": batch.kernel_name(B), "kernel_ms": ms, "steps_per_s": B / (k * 1e-3),
+print(json.dumps({"workload": what, "options": list(extra) + (["order=prev"] if order_prev else []), "instances": B, "horizon": N, "launches": launches,
+                  "kernel": batch.kernel_name(B), "kernel_ms": ms, "launch_order": sources, "steps_per_s": B / (k * 1e-3),
                   "converged": int((st["status"] == 1).sum()), "algorithmic_bytes_per_launch": alg,
                   "algorithmic_GBps": alg / (k * 1e-3) / 1e9, "frac_of_8TBps": alg / (k * 1e-3) / 8e12,
                   "n_hess_psi_prod_total": int(st["n_hess_psi_prod"].sum()), "source_hash": pa.source_hash()}))

@@ -489,6 +489,72 @@ def test_residency_caps_workgroups_per_cu_and_changes_nothing_else():
         assert np.all(st["status"] == 1)
 
 
+def test_launch_order_from_the_solve_before_changes_nothing_but_time():
+    """`launch_order=previous|auto`: behind every solve kernel the instances are ranked on the device, longest first
+    by the time each took, and the next launch of that size starts them in that order.  Same solutions and counters
+    whatever the order; auto does it only for launches with more workgroups than the chip holds at once; an order set
+    with pantr_batch_set_launch_order wins; quadcopter family alike."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_hanging_chain_N60_warm300.npz"))
+    idx = np.arange(0, 300, 4)
+    x0 = np.vstack([d["x0"][idx], d["x0"][idx]])
+    u0 = np.vstack([d["guess"][idx], np.zeros_like(d["guess"][idx])])
+    B = len(x0)
+    base = tuple(pa.DODO_PANTR_OPTS)
+    b = pa.PantrBatch("hanging_chain", 60, B, opts=base + ("launch_order=natural",))
+    u_ref, st_ref = b.solve(x0, u0)
+    assert b.last_launch_order(B) == ("index", None)
+    b.close()
+    b = pa.PantrBatch("hanging_chain", 60, B, opts=base + ("launch_order=previous",))
+    u, st = b.solve(x0, u0)
+    src, nxt = b.last_launch_order(B)
+    assert src == "index"                                   # nothing to go by in the first launch
+    assert sorted(nxt.tolist()) == list(range(B))           # a permutation ...
+    t = st["elapsed_s"][nxt]
+    assert np.all(t[:-1] >= t[1:])                          # ... longest first by the time each instance took
+    assert np.array_equal(u, u_ref) and np.array_equal(st["n_hess_psi_prod"], st_ref["n_hess_psi_prod"])
+    for _ in range(2):
+        u, st = b.solve(x0, u0)
+        assert b.last_launch_order()[0] == "previous solve"
+        assert np.array_equal(u, u_ref) and np.array_equal(st["n_hess_psi_prod"], st_ref["n_hess_psi_prod"])
+        assert np.array_equal(st["iterations"], st_ref["iterations"]) and np.all(st["status"] == 1)
+    u, st = b.solve(x0[:40], u0[:40])                       # another batch size: the ranking does not apply
+    assert b.last_launch_order()[0] == "index" and np.array_equal(u, u_ref[:40])
+    b.set_launch_order(np.arange(B - 1, -1, -1))            # an order of the caller's wins
+    u, st = b.solve(x0, u0)
+    assert b.last_launch_order(B) == ("user", None) and np.array_equal(u, u_ref)
+    b.set_launch_order(None)
+    b.close()
+    # auto: only where the launch has more workgroups than the chip holds at once
+    b = pa.PantrBatch("hanging_chain", 60, B, opts=base)
+    b.solve(x0, u0); b.solve(x0, u0)
+    assert b.last_launch_order(B) == ("index", None)
+    b.close()
+    R = 14                                                  # 2100 workgroups of one wavefront: six fit a compute unit
+    X0, U0 = np.tile(x0, (R, 1)), np.tile(u0, (R, 1))
+    b = pa.PantrBatch("hanging_chain", 60, R * B, opts=base)
+    u1, st1 = b.solve(X0, U0)
+    assert b.last_launch_order()[0] == "index"
+    u2, st2 = b.solve(X0, U0)
+    assert b.last_launch_order()[0] == "previous solve"
+    b.close()
+    assert np.array_equal(u1, u2) and np.array_equal(u1, np.tile(u_ref, (R, 1)))
+    assert np.array_equal(st1["n_hess_psi_prod"], st2["n_hess_psi_prod"])
+    # quadcopter family (ALM kernels)
+    from pantr_amd import workloads
+    w = workloads.closed_loop_batch("quadcopter", 12, starts=(True,))
+    opts = tuple(w["opts"])
+    ref = None
+    for extra in (("launch_order=natural",), ("launch_order=previous",)):
+        b = pa.PantrBatch("quadcopter", 12, len(w["x0"]), opts=opts + extra)
+        for k in range(2):
+            u, y, st = b.solve_al(w["x0"], w["u0"], w["y0"])
+            assert b.last_launch_order()[0] == ("previous solve" if extra[0].endswith("previous") and k else "index")
+            if ref is None:
+                ref = (u, y, st["iterations"].copy())
+            assert np.array_equal(u, ref[0]) and np.array_equal(y, ref[1]) and np.array_equal(st["iterations"], ref[2])
+        b.close()
+
+
 def test_kernel_name_follows_method_speculation_and_batch_size():
     """pantr_batch_kernel_name: what measurement code names its dominant kernel with."""
     b = pa.PantrBatch("hanging_chain", 60, 1024, opts=pa.DODO_PANTR_OPTS)

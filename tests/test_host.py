@@ -101,6 +101,14 @@ def test_option_grammar():
         with pytest.raises(pa.PantrError) as e:
             p.set(bad)
         assert e.value.code == -1 and bad.split("=")[0] in str(e.value)
+    # launch_order=auto|natural|previous
+    assert p.get("launch_order") == -1
+    for text, value in (("launch_order=previous", 1), ("launch_order=natural", 0), ("launch_order=auto", -1)):
+        p.set(text)
+        assert p.get("launch_order") == value
+    with pytest.raises(pa.PantrError) as e:
+        p.set("launch_order=random")
+    assert e.value.code == -1 and "launch_order" in str(e.value)
 
 
 def test_no_cpu_fallback():
