@@ -21,6 +21,22 @@ cp "$(ls -t gpurun_out/prof_rows/*/*_kernel_stats.csv | head -1)" profiles/${TAG
 python scripts/summarize_profiles.py $TAG > /dev/null
 python scripts/summarize_traffic.py $TAG stress tile8
 [ -d gpurun_out/traffic/realistic_quadcopter ] && python scripts/summarize_traffic.py $TAG realistic_quadcopter quadcopter_N12
+# both quadcopter digests side by side in one file (configs[2] and configs[0])
+python - $TAG <<'PY'
+import json, os, sys
+tag = sys.argv[1]
+out = {}
+for w in ("realistic_quadcopter", "quadcopter_N12"):
+    f = f"profiles/{tag}_{w}_traffic.json"
+    if os.path.exists(f):
+        d = json.load(open(f))
+        out[w] = {k: d[k] for k in ("command", "kernel_trace", "hbm_traffic_bytes_per_launch", "traffic_over_algorithmic",
+                                     "valu_issue") if k in d}
+        out[w]["csrc_sha256"] = d["run"].get("source_hash")
+        out[w]["digest"] = f
+if out:
+    json.dump(out, open(f"profiles/{tag}_quad_summary.json", "w"), indent=1)
+PY
 [ -s $R/straggler_phases.txt ] && grep -v amdgpu.ids $R/straggler_phases.txt > profiles/${TAG}_straggler_phases.txt
 python scripts/kernel_resources.py > profiles/${TAG}_kernel_resources.txt 2> /dev/null || true
 ls -la profiles/ | grep ${TAG}_
