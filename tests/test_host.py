@@ -394,3 +394,33 @@ def test_bench_started_bare_launches_ranks_and_reports_their_failure():
     assert r.returncode != 0 and time.time() - t < 120
     assert r.stderr.count("bench.py needs an MI355X") == 2          # both ranks were started, both said why they left
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # and no result line was made up
+
+
+def test_concurrent_batches_take_four_streams_longest_first():
+    """bench.plan_streams: batches launched together go on at most four streams (the runtime's hardware queues per
+    process: streams that share one run in turn), the longest first, a fifth and sixth behind the least loaded."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class FakeStream:
+        pass
+
+    class FakeTorch:
+        class cuda:
+            Stream = FakeStream
+
+    class R:
+        def __init__(self, B, N):
+            self.B, self.w = B, {"horizon": N}
+
+    rs = [R(120, N) for N in (10, 20, 30, 40, 50, 60)]
+    plan = bench.plan_streams(rs, FakeTorch)
+    assert [r.w["horizon"] for r, _ in plan] == [60, 50, 40, 30, 20, 10]           # longest first
+    streams = [s for _, s in plan]
+    assert len({id(s) for s in streams}) == 4                                       # four streams for six batches
+    assert len({id(s) for s in streams[:4]}) == 4                                   # the four longest each on their own
+    assert streams[4] is streams[3] and streams[5] is streams[3]                    # 20 and 10 behind 30: 900 + 400 + 100 < 1600
+    assert [r for r, _ in bench.plan_streams(rs[:2], FakeTorch)] == [rs[1], rs[0]]  # fewer batches: a stream each
+    assert len({id(s) for _, s in bench.plan_streams(rs[:2], FakeTorch)}) == 2
+    empty = [R(0, 60), R(5, 10)]                                                    # a rank that got no rows of a horizon
+    assert [r for r, _ in bench.plan_streams(empty, FakeTorch)] == [empty[1], empty[0]]
