@@ -670,6 +670,12 @@ struct WaveProblem {
         asm volatile("" : "+v"(lane));
         return TanLane(lane);
     }
+    __device__ __forceinline__ const Lane &address_lane(const TanLane &T) const {
+        if constexpr (NJ_ >= 4)
+            return T;
+        else
+            return L;
+    }
     /// RECOMP: the state row of stage k (the tangent tape's region of the workspace holds these rows instead)
     __device__ __forceinline__ double *srow(int k) const {
         return reinterpret_cast<double *>(st) + (size_t)k * M::S_ROW_DOUBLES;
@@ -680,6 +686,11 @@ struct WaveProblem {
         const long long hv_t0_ = clock64();
 #endif
         const TanLane T = tan_lane();
+        // The lanes the transfers' addresses are formed from: the kernels with four or more elements per lane are
+        // short of registers - with the problem's own lanes (L) the compiler keeps `base + 16 lane` of every tape in
+        // registers through the whole solve and reloads them from scratch memory inside the stage loops (a wait for
+        // every vector-memory operation in flight each time); formed from the product's lanes they live a product long.
+        const Lane &A = address_lane(T);
         // Control flow of both sweeps (round 5): a stage body issues the same number of vector-memory operations behind
         // its wait whatever k is - where a forward stage has nothing to request it requests something useful to the
         // adjoint sweep instead, and the adjoint stages that request nothing (1 and 0) are bodies of their own.  The
@@ -713,13 +724,13 @@ struct WaveProblem {
                 // rest of the stage's rows; N = 2: of stage 0, not yet written - nobody reads that buffer)
                 static_assert(FWD_ROW_TRANSFERS == 2, "prefetch_st_xt issues two operations, like prefetch_fwd");
                 if (k + 2 < N) {
-                    M::template prefetch_fwd<true>(L, tape + (size_t)(k + 2) * M::TAPE_D4_PER_STAGE, nxt2);
+                    M::template prefetch_fwd<true>(A, tape + (size_t)(k + 2) * M::TAPE_D4_PER_STAGE, nxt2);
                 } else {
                     const int kk = k > 0 ? k - 1 : 0;
                     if constexpr (RECOMP)
-                        M::prefetch_s(L, srow(kk), nxt2);
+                        M::prefetch_s(A, srow(kk), nxt2);
                     else
-                        M::prefetch_st_xt(L, st + (size_t)kk * M::ST_D4_PER_STAGE, Xt + (size_t)kk * M::XT_DOUBLES, nxt2);
+                        M::prefetch_st_xt(A, st + (size_t)kk * M::ST_D4_PER_STAGE, Xt + (size_t)kk * M::XT_DOUBLES, nxt2);
                 }
             } else {
                 // all rows of stage N - 2 for the adjoint sweep's second stage (its K and M rows are in LDS already:
@@ -727,9 +738,9 @@ struct WaveProblem {
                 // behind it; N = 1: of stage 0 itself, into a buffer nobody reads)
                 const int kk = k > 0 ? k - 1 : 0;
                 if constexpr (RECOMP)
-                    M::prefetch_rev_s(L, tape + (size_t)kk * M::TAPE_D4_PER_STAGE, srow(kk), prev);
+                    M::prefetch_rev_s(A, tape + (size_t)kk * M::TAPE_D4_PER_STAGE, srow(kk), prev);
                 else
-                    M::prefetch_rev_xt(L, tape + (size_t)kk * M::TAPE_D4_PER_STAGE, st + (size_t)kk * M::ST_D4_PER_STAGE,
+                    M::prefetch_rev_xt(A, tape + (size_t)kk * M::TAPE_D4_PER_STAGE, st + (size_t)kk * M::ST_D4_PER_STAGE,
                                        Xt + (size_t)kk * M::XT_DOUBLES, prev);
             }
             const double uc_t = M::load_input(T, v + M::nu * k);
@@ -752,7 +763,7 @@ struct WaveProblem {
             s_t = M::rk4_tan(T, cur, s_t, uc_t, st_k, xs());
         };
         if (!primed)
-            prime();
+            prime(A);
         {
             constexpr std::integral_constant<int, 0> F{};
             constexpr std::integral_constant<int, 1> LASTT{};
@@ -813,9 +824,9 @@ struct WaveProblem {
             }
             if constexpr (TAIL == 0) { // two stages ahead
                 if constexpr (RECOMP)
-                    M::prefetch_rev_s(L, tape + (size_t)(k - 2) * M::TAPE_D4_PER_STAGE, srow(k - 2), nxt2);
+                    M::prefetch_rev_s(A, tape + (size_t)(k - 2) * M::TAPE_D4_PER_STAGE, srow(k - 2), nxt2);
                 else
-                    M::prefetch_rev_xt(L, tape + (size_t)(k - 2) * M::TAPE_D4_PER_STAGE, st + (size_t)(k - 2) * M::ST_D4_PER_STAGE,
+                    M::prefetch_rev_xt(A, tape + (size_t)(k - 2) * M::TAPE_D4_PER_STAGE, st + (size_t)(k - 2) * M::ST_D4_PER_STAGE,
                                        Xt + (size_t)(k - 2) * M::XT_DOUBLES, nxt2);
             }
             if constexpr (RECOMP) { // the stage's forward tangent once more: its d_t, where the tape would have landed them
@@ -854,32 +865,32 @@ struct WaveProblem {
             stage_rev(0, tbuf0, tbuf1, std::integral_constant<int, 2>{});
         }
         wave_sync();
-        prime(); // for the next product (the CG algebra runs meanwhile)
+        prime(A); // for the next product (the CG algebra runs meanwhile)
         primed = true;
     }
     /// What a product two stages ahead wants in flight before it starts: the M rows of the last two stages (where the
     /// adjoint sweep starts; the oldest requests), then the K rows of stages 0 and 1 (the youngest two: stage 0's
     /// wait leaves them in flight).
-    __device__ __forceinline__ void prime() const {
+    __device__ __forceinline__ void prime(const Lane &A) const {
         // (a branch per buffer, not a selected address: every transfer names its landing buffer as a constant - with
         // a selected one the compiler lost track of what the stage loops' LDS accesses can alias: 960 bytes of scratch)
         auto m_rows = [&](int k) {
             const double4 *rows = tape + (size_t)k * M::TAPE_D4_PER_STAGE;
             if (k % 3 == 0)
-                M::template prefetch_m<true>(L, rows, tbuf0);
+                M::template prefetch_m<true>(A, rows, tbuf0);
             else if (k % 3 == 1)
-                M::template prefetch_m<true>(L, rows, tbuf1);
+                M::template prefetch_m<true>(A, rows, tbuf1);
             else
-                M::template prefetch_m<true>(L, rows, tbuf2);
+                M::template prefetch_m<true>(A, rows, tbuf2);
         };
         m_rows(N - 1);
         if (N > 1)
             m_rows(N - 2);
         asm volatile("" ::: "memory");
-        M::template prefetch_fwd<true>(L, tape, tbuf0);
+        M::template prefetch_fwd<true>(A, tape, tbuf0);
         asm volatile("" ::: "memory");
         if (N > 1)
-            M::template prefetch_fwd<true>(L, tape + (size_t)M::TAPE_D4_PER_STAGE, tbuf1);
+            M::template prefetch_fwd<true>(A, tape + (size_t)M::TAPE_D4_PER_STAGE, tbuf1);
     }
     // ---- DEPTH == 1 -------------------------------------------------------------------------------
     // One stage ahead: a full wait at every stage start.  The two landing buffers are distinct __shared__ objects
