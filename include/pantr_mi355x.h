@@ -96,8 +96,8 @@ typedef struct pantr_problem_data pantr_problem_data_t; /* numeric data read fro
  * are the same whatever their value): "speculation=auto|on|off" (method=pantr: a second wavefront per instance
  * evaluates ahead; auto = on for batches that leave the SIMDs idle), "spec_patience=<duration>" (how long a solver
  * wavefront waits for that helper before it goes on alone, default 1s; pantr_stats_t::spec_timeouts),
- * "residency=auto|<k>" (at most k workgroups per compute unit: a measurement aid), "launch_order=auto|natural|
- * previous" (pantr_batch_last_launch_order below). */
+ * "residency=auto|<k>" (at most k workgroups per compute unit: a measurement aid), "launch_order=natural|previous|
+ * auto" (pantr_batch_last_launch_order below). */
 int pantr_params_create(pantr_params_t **out);
 void pantr_params_destroy(pantr_params_t *p);
 int pantr_params_set(pantr_params_t *p, const char *kv);
@@ -185,9 +185,9 @@ int pantr_batch_last_kernel_ms(pantr_batch_t *b, float *ms);
 /* Launch order: order[B] lists instance indices in the order workgroups should start them
  * (longest-expected-first); NULL restores identity.  Used by the next solve calls. */
 int pantr_batch_set_launch_order(pantr_batch_t *b, int32_t B, const int32_t *order);
-/* Without such an order, option "launch_order=previous" (or "auto" where a launch has more workgroups than the chip
- * holds at once) starts the instances longest first by the time each took in the solve before it on this handle,
- * ranked on the device behind every solve kernel.  source (may be NULL): what the most recent launch used - 0 by index,
+/* Without such an order, option "launch_order=previous" (or "auto": where a launch has more workgroups than the chip
+ * holds at once; the default is "natural") starts the instances longest first by the time each took in the solve
+ * before it on this handle, ranked on the device behind every solve kernel - for batches that are solved again.  source (may be NULL): what the most recent launch used - 0 by index,
  * 1 pantr_batch_set_launch_order, 2 the solve before it; next_order (may be NULL): the B indices that solve left
  * behind for the next launch of B instances (PANTR_ERR_RUNTIME if it left none).  Synchronises the device. */
 int pantr_batch_last_launch_order(pantr_batch_t *b, int32_t B, int32_t *source, int32_t *next_order);

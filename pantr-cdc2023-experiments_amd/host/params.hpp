@@ -185,13 +185,17 @@ struct SolverOptions {
     /// second-order tapes; fewer instances in flight keep that working set inside the 256 MiB Infinity Cache.
     /// 0 = auto (what the LDS of the kernel allows).  Same results either way.
     int32_t residency = 0;
-    /// `launch_order=auto|natural|previous` (an option of this implementation): in which order the workgroups of a
-    /// launch start the instances.  previous: longest first by the time each instance took in the solve before it on
-    /// this handle (MPC instances at consecutive time steps need similar work; with more workgroups than fit the chip
-    /// the pass otherwise ends with whatever long instance happened to start last); natural: by index; auto:
-    /// previous wherever the launch has more workgroups than the chip holds at once.  pantr_batch_set_launch_order
-    /// overrides all three.  Results do not depend on it.  -1 = auto, 0 = natural, 1 = previous.
-    int32_t launch_order = -1;
+    /// `launch_order=natural|previous|auto` (an option of this implementation): in which order the workgroups of a
+    /// launch start the instances.  natural (default): by index.  previous: longest first by the time each instance
+    /// took in the solve before it on this handle - for batches that are solved AGAIN (replays, parameter studies,
+    /// repeated passes): with more workgroups than fit the chip the pass otherwise ends with whatever long instance
+    /// happened to start last (the bench batch tiled eight times: 170 -> 130 ms).  auto: previous wherever the launch
+    /// has more workgroups than the chip holds at once.  A genuine closed loop has no use for it: what an instance
+    /// needed a time step earlier says nothing about what it needs now (4800 controllers, 16 steps: rank correlation
+    /// between consecutive steps -0.3 ... 0.3, 1.79 s either way - profiles/r05_closed_loop_order.txt), hence the
+    /// default.  pantr_batch_set_launch_order overrides all three.  Results do not depend on it.
+    /// -1 = auto, 0 = natural, 1 = previous.
+    int32_t launch_order = 0;
     /// `spec_patience=<duration>` (an option of this implementation): how long a solver wavefront waits for a
     /// result of its helper before it evaluates the step itself, tells the helper to stop and posts no further
     /// requests (pantr_stats_t::spec_timeouts counts these).  Same results either way.

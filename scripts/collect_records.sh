@@ -37,6 +37,7 @@ for w in ("realistic_quadcopter", "quadcopter_N12"):
 if out:
     json.dump(out, open(f"profiles/{tag}_quad_summary.json", "w"), indent=1)
 PY
+[ -s $R/closed_loop_order.txt ] && grep -v amdgpu.ids $R/closed_loop_order.txt > profiles/${TAG}_closed_loop_order.txt
 [ -s $R/straggler_phases.txt ] && grep -v amdgpu.ids $R/straggler_phases.txt > profiles/${TAG}_straggler_phases.txt
 python scripts/kernel_resources.py > profiles/${TAG}_kernel_resources.txt 2> /dev/null || true
 ls -la profiles/ | grep ${TAG}_

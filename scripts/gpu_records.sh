@@ -6,7 +6,8 @@
 #                                    passes of the memory-bound workloads (scripts/traffic_profile.sh stress tile8)
 #   scripts/gpu_records.sh <tag> b   the same passes + the SQ counters for the quadcopter configurations (configs[2], [0]),
 #                                    the kernel trace of the other solve kernels (scripts/rows_workload.py), the batch tiled
-#                                    R times, per-phase times (profiling build), the multi-rank bench modes started bare
+#                                    R times, per-phase times (profiling build), 4800 genuine closed loops with and without the
+#                                    start order of the step before, the multi-rank bench modes started bare
 #                                    with two ranks on the one GPU (gloo, PANTR_BENCH_REHEARSAL=1), bench.py --streams 4
 # Afterwards, on the build box: scripts/collect_records.sh <tag>, then (the PMC digests now match the sources) once more
 #   python bench.py > gpurun_out/<tag>/bench.json   for the line whose roofline.traffic fields are filled.
@@ -28,7 +29,8 @@ else
   timeout -k 10 120 python scripts/saturation_timing.py 1 2 4 8 > $OUT/saturation.txt 2>&1
   PANTR_LIB_PATH=$P/lib/libpantr_mi355x_phase.so timeout -k 10 300 python scripts/phase_timing.py > $OUT/phase_timing.txt 2>&1
   PANTR_LIB_PATH=$P/lib/libpantr_mi355x_phase.so timeout -k 10 200 python scripts/straggler_phases.py auto > $OUT/straggler_phases.txt 2>&1
-  PANTR_LIB_PATH=$P/lib/libpantr_mi355x_phase.so timeout -k 10 300 python scripts/product_time_under_load.py > $OUT/product_under_load.txt 2>&1
+  PANTR_LIB_PATH=$P/lib/libpantr_mi355x_phase.so timeout -k 10 300 python scripts/product_time_under_load.py launch_order=auto > $OUT/product_under_load.txt 2>&1
+  timeout -k 10 200 python scripts/closed_loop_order.py 4800 16 > $OUT/closed_loop_order.txt 2>&1
   for W in sweep stress; do
     PANTR_BENCH_REHEARSAL=1 timeout -k 10 300 python bench.py --gpus 2 --steps 3 --warmup 1 --workload $W --scaling strong > $OUT/rehearsal_strong_$W.log 2>&1
   done

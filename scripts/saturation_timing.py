@@ -12,7 +12,7 @@ x0 = np.vstack([d["x0"], d["x0"]]); u0 = np.vstack([d["guess"], np.zeros_like(d[
 for R in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     X0, U0 = np.tile(x0, (R, 1)), np.tile(u0, (R, 1))
     B = len(X0)
-    batch = pa.PantrBatch("hanging_chain", 60, B, opts=pa.DODO_PANTR_OPTS + ("alm.max_time=5s",))
+    batch = pa.PantrBatch("hanging_chain", 60, B, opts=pa.DODO_PANTR_OPTS + ("alm.max_time=5s", "launch_order=auto"))
     lds, ws = batch.footprint()
     for _ in range(2):
         u, st = batch.solve(X0, U0)

@@ -490,20 +490,22 @@ def test_residency_caps_workgroups_per_cu_and_changes_nothing_else():
 
 
 def test_launch_order_from_the_solve_before_changes_nothing_but_time():
-    """`launch_order=previous|auto`: behind every solve kernel the instances are ranked on the device, longest first
-    by the time each took, and the next launch of that size starts them in that order.  Same solutions and counters
-    whatever the order; auto does it only for launches with more workgroups than the chip holds at once; an order set
-    with pantr_batch_set_launch_order wins; quadcopter family alike."""
+    """`launch_order=previous|auto` (the default is natural): behind every solve kernel the instances are ranked on the
+    device, longest first by the time each took, and the next launch of that size starts them in that order.  Same
+    solutions and counters whatever the order; auto does it only for launches with more workgroups than the chip holds
+    at once; an order set with pantr_batch_set_launch_order wins; quadcopter family alike."""
     d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_hanging_chain_N60_warm300.npz"))
     idx = np.arange(0, 300, 4)
     x0 = np.vstack([d["x0"][idx], d["x0"][idx]])
     u0 = np.vstack([d["guess"][idx], np.zeros_like(d["guess"][idx])])
     B = len(x0)
     base = tuple(pa.DODO_PANTR_OPTS)
-    b = pa.PantrBatch("hanging_chain", 60, B, opts=base + ("launch_order=natural",))
-    u_ref, st_ref = b.solve(x0, u0)
-    assert b.last_launch_order(B) == ("index", None)
-    b.close()
+    for opts in (base, base + ("launch_order=natural",)):    # the default is natural
+        b = pa.PantrBatch("hanging_chain", 60, B, opts=opts)
+        b.solve(x0, u0)
+        u_ref, st_ref = b.solve(x0, u0)
+        assert b.last_launch_order(B) == ("index", None)
+        b.close()
     b = pa.PantrBatch("hanging_chain", 60, B, opts=base + ("launch_order=previous",))
     u, st = b.solve(x0, u0)
     src, nxt = b.last_launch_order(B)
@@ -525,13 +527,13 @@ def test_launch_order_from_the_solve_before_changes_nothing_but_time():
     b.set_launch_order(None)
     b.close()
     # auto: only where the launch has more workgroups than the chip holds at once
-    b = pa.PantrBatch("hanging_chain", 60, B, opts=base)
+    b = pa.PantrBatch("hanging_chain", 60, B, opts=base + ("launch_order=auto",))
     b.solve(x0, u0); b.solve(x0, u0)
     assert b.last_launch_order(B) == ("index", None)
     b.close()
     R = 14                                                  # 2100 workgroups of one wavefront: six fit a compute unit
     X0, U0 = np.tile(x0, (R, 1)), np.tile(u0, (R, 1))
-    b = pa.PantrBatch("hanging_chain", 60, R * B, opts=base)
+    b = pa.PantrBatch("hanging_chain", 60, R * B, opts=base + ("launch_order=auto",))
     u1, st1 = b.solve(X0, U0)
     assert b.last_launch_order()[0] == "index"
     u2, st2 = b.solve(X0, U0)

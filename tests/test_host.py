@@ -101,8 +101,8 @@ def test_option_grammar():
         with pytest.raises(pa.PantrError) as e:
             p.set(bad)
         assert e.value.code == -1 and bad.split("=")[0] in str(e.value)
-    # launch_order=auto|natural|previous
-    assert p.get("launch_order") == -1
+    # launch_order=natural|previous|auto (default: natural)
+    assert p.get("launch_order") == 0
     for text, value in (("launch_order=previous", 1), ("launch_order=natural", 0), ("launch_order=auto", -1)):
         p.set(text)
         assert p.get("launch_order") == value
